@@ -1,0 +1,199 @@
+/*
+ * wfae.h — C ABI of libwfae.so: hand-written HIP/gfx950 kernels for the
+ * conv-autoencoder training hot path of Autobot37/weatherforecastingtoolkit.
+ *
+ * The reference has NO native/FFI boundary (it is 100 % Python, every kernel
+ * is a stock ATen op reached through torch.nn — SURVEY.md §0.1, §8b), so this
+ * ABI is defined by the build.  Each entry point names the reference call
+ * site whose ATen op it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - all tensors are dense fp32, NCHW, caller-owned DEVICE pointers
+ *     (torch: tensor.data_ptr()); the library never allocates, frees or
+ *     retains device memory;
+ *   - `ws`/`ws_bytes` is caller-provided scratch (query with
+ *     wfae_workspace_bytes); contents are undefined after the call;
+ *   - `stream` is a hipStream_t passed as void* (torch:
+ *     torch.cuda.current_stream().cuda_stream); every launch goes to it, no
+ *     implicit device synchronisation;
+ *   - return 0 on success, a negative wfae_status otherwise; never throws or
+ *     aborts; wfae_last_error_string() describes the calling thread's last
+ *     failure;
+ *   - re-entrant and thread-safe: no mutable global state.
+ *   - `accumulate` != 0 means "out += result" (gradient accumulation),
+ *     0 means "out = result".
+ */
+#ifndef WFAE_H
+#define WFAE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* wfae_stream_t;
+
+typedef enum {
+  WFAE_OK = 0,
+  WFAE_ERR_BAD_SHAPE = -1,
+  WFAE_ERR_NULL_POINTER = -2,
+  WFAE_ERR_WORKSPACE = -3,
+  WFAE_ERR_LAUNCH = -4,
+  WFAE_ERR_UNSUPPORTED = -5
+} wfae_status;
+
+int wfae_version(void);
+const char* wfae_last_error_string(void);
+/* upper bound of scratch bytes any single call needs for a problem whose
+ * largest weight tensor has `max_weight_elems` elements. */
+size_t wfae_workspace_bytes(int64_t max_weight_elems);
+
+/* ---- 1x1 convolution as an fp32-MFMA GEMM on NCHW ------------------------
+ * replaces nn.Conv2d(C, C/4, 1) / (C/4, C, 1) in Bottleneck
+ * (pipeline/models/ae_64x8x8_lin.py:15,19) and the latent projections
+ * enc[4] / dec[0] (:69,79).
+ * y[n,co,p] = sum_ci w[co,ci] x[n,ci,p] (+ bias[co]) (+ res[n*res_img_stride + co*HW + p])
+ * res_img_stride = Cout*HW for the Bottleneck residual (:22), 0 for the
+ * broadcast pos_emb add (:91). */
+int wfae_conv1x1_fwd(const float* x, const float* w, const float* bias, const float* res,
+                     int64_t res_img_stride, float* y, int NB, int Cin, int Cout, int HW,
+                     wfae_stream_t stream);
+int wfae_conv1x1_bwd_data(const float* dy, const float* w, float* dx, int NB, int Cin, int Cout,
+                          int HW, wfae_stream_t stream);
+int wfae_conv1x1_bwd_weight(const float* dy, const float* x, float* dw, int NB, int Cin, int Cout,
+                            int HW, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
+
+/* ---- nn.Linear (to_latent / from_latent, ae_64x8x8_lin.py:74-75,92,98) ---
+ * y[b,o] = sum_i x[b,i] w[o,i] + bias[o] */
+int wfae_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In,
+                    int Out, void* ws, size_t ws_bytes, wfae_stream_t stream);
+int wfae_linear_bwd_data(const float* dy, const float* w, float* dx, int B, int In, int Out,
+                         wfae_stream_t stream);
+int wfae_linear_bwd_weight(const float* dy, const float* x, float* dw, int B, int In, int Out,
+                           int accumulate, wfae_stream_t stream);
+
+/* ---- 4x4 stride-2 pad-1 convolution pair ---------------------------------
+ * "hi" = the 2H x 2W side with Chi channels, "lo" = the H x W side with Clo
+ * channels.  Both nn.Conv2d(Chi, Clo, 4, 2, 1) weights (Clo,Chi,4,4)
+ * (EncBlock.down[0], ae_64x8x8_lin.py:31) and nn.ConvTranspose2d(Clo, Chi, 4,
+ * 2, 1) weights (Clo,Chi,4,4) (DecBlock.up[0], :42) are laid out
+ * [lo][hi][ky][kx], so three kernels serve six operations:
+ *   down : lo[n,l,oy,ox] = sum_{h,ky,kx} w[l,h,ky,kx] hi[n,h,2oy-1+ky,2ox-1+kx]
+ *          = Conv2d forward            = ConvTranspose2d backward-data
+ *   up   : hi[n,h,iy,ix] = sum_{l,ky,kx: iy=2oy-1+ky} w[l,h,ky,kx] lo[n,l,oy,ox]
+ *          = ConvTranspose2d forward   = Conv2d backward-data
+ *   wgrad: dw[l,h,ky,kx] = sum_{n,oy,ox} lo[n,l,oy,ox] hi[n,h,2oy-1+ky,2ox-1+kx]
+ *          = Conv2d backward-weight (lo=dy, hi=x) = ConvTranspose2d
+ *            backward-weight (lo=x, hi=dy)
+ * Hlo,Wlo are the lo-side spatial dims. */
+int wfae_conv4x4s2_down(const float* hi, const float* w, float* lo, int NB, int Chi, int Clo,
+                        int Hlo, int Wlo, wfae_stream_t stream);
+int wfae_conv4x4s2_up(const float* lo, const float* w, float* hi, int NB, int Chi, int Clo, int Hlo,
+                      int Wlo, void* ws, size_t ws_bytes, wfae_stream_t stream);
+int wfae_conv4x4s2_wgrad(const float* lo, const float* hi, float* dw, int NB, int Chi, int Clo,
+                         int Hlo, int Wlo, int accumulate, void* ws, size_t ws_bytes,
+                         wfae_stream_t stream);
+
+/* ---- direct (im2col-free, LDS-tiled VALU) convolution ---------------------
+ * grouped 3x3 pad 1 of Bottleneck (ae_64x8x8_lin.py:17), the 128->1 3x3 output
+ * conv (:84) and the 1->256 4x4 s2 input conv (:31 with in_ch=1).
+ * w is (Cout, Cin/groups, KS, KS).  KS in {3,4}, stride in {1,2}.
+ * bwd_data supports stride 1 only (stride-2 data gradients go through
+ * wfae_conv4x4s2_up). */
+int wfae_dconv_fwd(const float* x, const float* w, const float* bias, float* y, int NB, int Cin,
+                   int Cout, int H, int W, int KS, int stride, int pad, int groups,
+                   wfae_stream_t stream);
+int wfae_dconv_bwd_data(const float* dy, const float* w, float* dx, int NB, int Cin, int Cout,
+                        int H, int W, int KS, int pad, int groups, wfae_stream_t stream);
+int wfae_dconv_bwd_weight(const float* dy, const float* x, float* dw, int NB, int Cin, int Cout,
+                          int H, int W, int KS, int stride, int pad, int groups, int accumulate,
+                          void* ws, size_t ws_bytes, wfae_stream_t stream);
+
+/* ---- BatchNorm2d (+GELU) --------------------------------------------------
+ * nn.BatchNorm2d(eps=1e-5, momentum=0.1) followed by nn.GELU()
+ * (ae_64x8x8_lin.py:14,16,18,32,43).
+ * bn_stats_train: per-channel batch mean / biased variance over (N,H,W)
+ *   (fp64 accumulation), writes save_mean, save_invstd, the folded
+ *   scale = gamma*invstd and shift = beta - mean*scale, and updates
+ *   running_mean/var (unbiased var, momentum) in place.
+ * bn_fold_eval: scale/shift from running statistics (module.eval()).
+ * bn_act_fwd: y = act(x*scale[c] + shift[c]); act 0 = identity, 1 = exact GELU.
+ * bn_act_bwd: given dy = dL/dy, x and the saved statistics, computes
+ *   dgamma, dbeta and dx (+ res, the residual-branch gradient of
+ *   Bottleneck, :22).  training=0 uses the eval-mode formula. */
+int wfae_bn_stats_train(const float* x, int NB, int C, int HW, const float* gamma,
+                        const float* beta, float eps, float momentum, float* running_mean,
+                        float* running_var, float* save_mean, float* save_invstd, float* scale,
+                        float* shift, void* ws, size_t ws_bytes, wfae_stream_t stream);
+int wfae_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, float* save_mean, float* save_invstd,
+                      float* scale, float* shift, int C, wfae_stream_t stream);
+int wfae_bn_act_fwd(const float* x, const float* scale, const float* shift, float* y, int NB, int C,
+                    int HW, int act, wfae_stream_t stream);
+int wfae_bn_act_bwd(const float* dy, const float* x, const float* gamma, const float* scale,
+                    const float* shift, const float* save_mean, const float* save_invstd,
+                    const float* res, float* dx, float* dgamma, float* dbeta, int NB, int C, int HW,
+                    int act, int training, int accumulate, void* ws, size_t ws_bytes,
+                    wfae_stream_t stream);
+
+/* ---- element-wise / reductions -------------------------------------------- */
+int wfae_gelu_fwd(const float* x, float* y, int64_t n, wfae_stream_t stream);   /* nn.GELU */
+int wfae_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, wfae_stream_t stream);
+int wfae_sigmoid_fwd(const float* x, float* y, int64_t n, wfae_stream_t stream); /* :86,102 */
+int wfae_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, wfae_stream_t stream);
+int wfae_add(const float* a, const float* b, float* out, int64_t n, wfae_stream_t stream);
+/* out[c] (+)= sum_{o,i} x[o,c,i]: conv-bias / pos_emb / linear-bias gradients */
+int wfae_reduce_sum(const float* x, int outer, int C, int inner, float* out, int accumulate,
+                    void* ws, size_t ws_bytes, wfae_stream_t stream);
+
+/* ---- sigmoid + L1 loss (ae_64x8x8_lin.py:102 + experiments/ae_v2/train.py:55)
+ * recon = sigmoid(h); loss[0] = weight * mean |recon - x|  (fp64 accumulation).
+ * bwd: dh = gloss[0] * weight * sign(recon-x) * recon*(1-recon) / n */
+int wfae_sigmoid_l1_fwd(const float* h, const float* x, float* recon, float* loss, float weight,
+                        int64_t n, void* ws, size_t ws_bytes, wfae_stream_t stream);
+int wfae_sigmoid_l1_bwd(const float* recon, const float* x, const float* gloss, float weight,
+                        float* dh, int64_t n, wfae_stream_t stream);
+/* plain L1 (F.l1_loss) on an existing reconstruction: loss and dL/drecon */
+int wfae_l1_fwd(const float* recon, const float* x, float* loss, float weight, int64_t n, void* ws,
+                size_t ws_bytes, wfae_stream_t stream);
+int wfae_l1_bwd(const float* recon, const float* x, const float* gloss, float weight, float* drecon,
+                int64_t n, wfae_stream_t stream);
+
+/* ---- SSIM / PSNR (pytorch_msssim.ssim at experiments/ae_v2/train.py:62;
+ * torchmetrics SSIM/PSNR at pipeline/metrics.py:71-84).  11-tap Gaussian
+ * sigma 1.5, valid window, K=(0.01,0.03), data_range 1.
+ * ssim_fwd: out[0] = mean over images of mean over the (H-10)x(W-10) map.
+ * ssim_bwd: dy = gout[0] * d ssim / d y  (gradient w.r.t. the second image).
+ * psnr: out[0] = mean_n 10 log10(range_n^2 / mse_n), range_n = max-min of
+ * target n; clamp01 != 0 clamps both inputs to [0,1] first (metrics.py:92-93). */
+int wfae_ssim_fwd(const float* x, const float* y, float* out, int NB, int H, int W, int clamp01,
+                  void* ws, size_t ws_bytes, wfae_stream_t stream);
+int wfae_ssim_bwd(const float* x, const float* y, const float* gout, float* dy, int NB, int H, int W,
+                  void* ws, size_t ws_bytes, wfae_stream_t stream);
+int wfae_psnr(const float* pred, const float* target, float* out, int NB, int HW, int clamp01,
+              void* ws, size_t ws_bytes, wfae_stream_t stream);
+
+/* ---- AdamW (torch.optim.AdamW via pipeline/helpers.py:63-74) ---------------
+ * p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+ * p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps),  g pre-multiplied by grad_scale
+ * (1/world_size after a sum all-reduce). */
+int wfae_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+               float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
+               float grad_scale, wfae_stream_t stream);
+/* out[0] = sum x^2 (fp64 accumulation, written as fp64): grad-norm tracking
+ * (pipeline/helpers.py:250-256) */
+int wfae_sumsq(const float* x, int64_t n, double* out, void* ws, size_t ws_bytes,
+               wfae_stream_t stream);
+
+/* ---- loader contract on device (pipeline/datasets/sevire/sevir.py:749-794,
+ * 98-139): uint8 VIL (NB,H,W,T) 'NHWT' -> fp32 (NB,T,H,W) 'NTHW' scaled by
+ * 1/255. */
+int wfae_vil_u8_to_f32(const uint8_t* src, float* dst, int NB, int H, int W, int T, float scale,
+                       wfae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WFAE_H */

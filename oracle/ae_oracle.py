@@ -1,0 +1,232 @@
+"""ORACLE — test infrastructure only, never the product path.
+
+CPU fp32 restatement of the reference's conv-autoencoder training hot path,
+written functionally over a flat ``state_dict`` (no nn.Module tree), with the
+torch CPU built-ins the reference itself executes (F.conv2d, F.batch_norm,
+F.gelu, F.linear, F.l1_loss, torch.optim.AdamW).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module; the product (`weatherforecastingtoolkit_amd`) never does.
+
+Pinned: ``tests/golden/*.npz`` were produced in the build container by
+importing the real reference modules from /root/reference
+(``tests/golden/make_goldens.py``) and ``tests/test_oracle_golden.py`` checks
+this restatement against them.  SSIM/PSNR follow the published defaults of
+pytorch_msssim / torchmetrics, which are not installed and not vendored in the
+reference: that part is "parity unpinned" (SURVEY.md §8c).
+
+Reference lines followed (relative to /root/reference):
+  Bottleneck            pipeline/models/ae_64x8x8_lin.py:7-22
+  EncBlock / DecBlock   pipeline/models/ae_64x8x8_lin.py:27-47
+  PosAwareAE_TF         pipeline/models/ae_64x8x8_lin.py:52-106
+  Loss.forward (live)   experiments/ae_v2/train.py:54-74
+  adamw_optimizer       pipeline/helpers.py:63-74
+  cosine_warmup         pipeline/helpers.py:76-107
+  metrics.ssim / psnr   pipeline/metrics.py:71-93
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+# ---------------------------------------------------------------- blocks ---
+def _bn(x, sd, p, training):
+    """nn.BatchNorm2d(eps=1e-5, momentum=0.1) — ae_64x8x8_lin.py:14,16,18,32,43.
+    In training mode updates running stats in ``sd`` in place like the module."""
+    rm, rv = sd[p + ".running_mean"], sd[p + ".running_var"]
+    y = F.batch_norm(x, rm, rv, sd[p + ".weight"], sd[p + ".bias"], training, BN_MOMENTUM, BN_EPS)
+    if training:
+        sd[p + ".num_batches_tracked"] += 1
+    return y
+
+
+def bottleneck(x, sd, p, training, groups=8):
+    """x + f(x), f = BN,GELU,1x1,BN,GELU,g3x3,BN,GELU,1x1 — ae_64x8x8_lin.py:7-22."""
+    c = x.shape[1]
+    mid = c // 4
+    g = min(groups, mid)
+    h = F.gelu(_bn(x, sd, p + ".f.0", training))
+    h = F.conv2d(h, sd[p + ".f.2.weight"])
+    h = F.gelu(_bn(h, sd, p + ".f.3", training))
+    h = F.conv2d(h, sd[p + ".f.5.weight"], padding=1, groups=g)
+    h = F.gelu(_bn(h, sd, p + ".f.6", training))
+    h = F.conv2d(h, sd[p + ".f.8.weight"])
+    return x + h
+
+
+def _num_res(sd, p):
+    j = 0
+    while f"{p}.res.{j}.f.2.weight" in sd:
+        j += 1
+    return j
+
+
+def enc_block(x, sd, p, training, groups=8):
+    """Conv2d(4,s2,p1,no bias) -> BN -> GELU -> bottlenecks — ae_64x8x8_lin.py:27-36."""
+    h = F.conv2d(x, sd[p + ".down.0.weight"], stride=2, padding=1)
+    h = F.gelu(_bn(h, sd, p + ".down.1", training))
+    for j in range(_num_res(sd, p)):
+        h = bottleneck(h, sd, f"{p}.res.{j}", training, groups)
+    return h
+
+
+def dec_block(x, sd, p, training, groups=8):
+    """ConvTranspose2d(4,s2,p1,no bias) -> BN -> GELU -> bottlenecks — :38-47."""
+    h = F.conv_transpose2d(x, sd[p + ".up.0.weight"], stride=2, padding=1)
+    h = F.gelu(_bn(h, sd, p + ".up.1", training))
+    for j in range(_num_res(sd, p)):
+        h = bottleneck(h, sd, f"{p}.res.{j}", training, groups)
+    return h
+
+
+def _count(sd, fmt):
+    i = 0
+    while fmt.format(i) in sd:
+        i += 1
+    return i
+
+
+def encode(x, sd, training, groups=8):
+    """enc(x) + pos_emb -> flatten -> to_latent — ae_64x8x8_lin.py:88-94."""
+    n_enc = _count(sd, "enc.{}.down.0.weight")
+    h = x
+    for i in range(n_enc):
+        h = enc_block(h, sd, f"enc.{i}", training, groups)
+    h = F.conv2d(h, sd[f"enc.{n_enc}.weight"], sd[f"enc.{n_enc}.bias"])
+    h = h + sd["pos_emb"]
+    return F.linear(h.flatten(1), sd["to_latent.weight"], sd["to_latent.bias"])
+
+
+def decode(z, sd, training, groups=8):
+    """from_latent -> view(B,C,hw,hw) -> dec -> sigmoid — ae_64x8x8_lin.py:96-102.
+    hw comes from pos_emb (8 in the reference; 24 for the 384 extension)."""
+    pe = sd["pos_emb"]
+    h = F.linear(z, sd["from_latent.weight"], sd["from_latent.bias"])
+    h = h.view(z.shape[0], pe.shape[1], pe.shape[2], pe.shape[3])
+    h = F.conv2d(h, sd["dec.0.weight"], sd["dec.0.bias"])
+    k = 1
+    while f"dec.{k}.up.0.weight" in sd:
+        h = dec_block(h, sd, f"dec.{k}", training, groups)
+        k += 1
+    h = F.conv2d(h, sd[f"dec.{k}.weight"], sd[f"dec.{k}.bias"], padding=1)
+    return torch.sigmoid(h)
+
+
+def forward(x, sd, training=True, groups=8):
+    """returns (recon, z) — ae_64x8x8_lin.py:104-106."""
+    z = encode(x, sd, training, groups)
+    return decode(z, sd, training, groups), z
+
+
+# ------------------------------------------------------------------ loss ---
+def _gauss_1d(size=11, sigma=1.5, dtype=torch.float32):
+    c = torch.arange(size, dtype=dtype) - size // 2
+    g = torch.exp(-(c ** 2) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+def ssim(x, y, data_range=1.0, size_average=True):
+    """pytorch_msssim.ssim defaults (call site experiments/ae_v2/train.py:62):
+    11-tap Gaussian sigma 1.5, valid window, K=(0.01,0.03); mean over the map
+    per (n,c) then mean.  UNPINNED third-party arithmetic."""
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    ch = x.shape[1]
+    g = _gauss_1d(dtype=x.dtype).to(x.device)
+    wv = g.view(1, 1, -1, 1).repeat(ch, 1, 1, 1)
+    wh = g.view(1, 1, 1, -1).repeat(ch, 1, 1, 1)
+
+    def filt(t):
+        return F.conv2d(F.conv2d(t, wv, groups=ch), wh, groups=ch)
+
+    mu1, mu2 = filt(x), filt(y)
+    s11 = filt(x * x) - mu1 * mu1
+    s22 = filt(y * y) - mu2 * mu2
+    s12 = filt(x * y) - mu1 * mu2
+    cs = (2 * s12 + c2) / (s11 + s22 + c2)
+    m = ((2 * mu1 * mu2 + c1) / (mu1 * mu1 + mu2 * mu2 + c1)) * cs
+    per = m.flatten(2).mean(-1)
+    return per.mean() if size_average else per.mean(1)
+
+
+def psnr(pred, target):
+    """pipeline/metrics.py:77-84: torchmetrics PeakSignalNoiseRatio() with
+    data_range=None per single-sample call => range = max(target)-min(target)
+    of that sample; mean over samples.  UNPINNED (torchmetrics absent)."""
+    tot = 0.0
+    for i in range(pred.shape[0]):
+        p, g = pred[i], target[i]
+        mse = torch.mean((p - g) ** 2)
+        r = g.max() - g.min()
+        tot += float(10.0 * torch.log10(r * r / mse))
+    return tot / pred.shape[0]
+
+
+def loss_fn(recon, x, recon_weight=1.0, perceptual_weight=0.0):
+    """Live branch of Loss.forward — experiments/ae_v2/train.py:54-74."""
+    rec = recon_weight * F.l1_loss(recon, x, reduction="mean")
+    if perceptual_weight > 0:
+        rec = rec + perceptual_weight * (1 - ssim(x.repeat(1, 3, 1, 1), recon.repeat(1, 3, 1, 1), 1.0))
+    return rec
+
+
+# ------------------------------------------------------------- optimiser ---
+def lr_at(step, start_lr, peak_lr, final_lr, total_steps, warmup_steps):
+    """Closed form of SequentialLR[LinearLR, CosineAnnealingLR] as built by
+    cosine_warmup_scheduler (pipeline/helpers.py:76-107) after `step`
+    scheduler.step() calls.  warmup_steps may be non-integer (train.py:258)."""
+    if step < warmup_steps:
+        sf = start_lr / peak_lr
+        return peak_lr * (sf + (1.0 - sf) * min(step, warmup_steps) / warmup_steps)
+    t = step - math.ceil(warmup_steps) if warmup_steps != int(warmup_steps) else step - int(warmup_steps)
+    tmax = total_steps - warmup_steps
+    return final_lr + (peak_lr - final_lr) * (1 + math.cos(math.pi * t / tmax)) / 2
+
+
+def make_optimizer(params, lr=5e-5, weight_decay=1e-4, beta1=0.9, beta2=0.999):
+    """adamw_optimizer — pipeline/helpers.py:63-74."""
+    return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, betas=(beta1, beta2))
+
+
+def make_scheduler(opt, start_lr, final_lr, peak_lr, total_steps, warmup_steps):
+    """cosine_warmup_scheduler — pipeline/helpers.py:76-107 (same torch classes)."""
+    for g in opt.param_groups:
+        g["lr"] = peak_lr
+    w = torch.optim.lr_scheduler.LinearLR(opt, start_factor=start_lr / peak_lr, end_factor=1.0, total_iters=warmup_steps)
+    c = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=total_steps - warmup_steps, eta_min=final_lr)
+    return torch.optim.lr_scheduler.SequentialLR(opt, schedulers=[w, c], milestones=[warmup_steps])
+
+
+# ------------------------------------------------------------ train step ---
+def to_torch_sd(np_sd, requires_grad=True):
+    sd = OrderedDict()
+    for k, v in np_sd.items():
+        t = torch.from_numpy(v.copy()) if v.ndim else torch.tensor(int(v), dtype=torch.int64)
+        if requires_grad and t.dtype.is_floating_point and "running_" not in k:
+            t.requires_grad_(True)
+        sd[k] = t
+    return sd
+
+
+def trainable(sd):
+    return [(k, v) for k, v in sd.items() if v.requires_grad]
+
+
+def train_step(x, sd, opt=None, sched=None, recon_weight=1.0, perceptual_weight=0.0):
+    """fwd -> loss -> bwd -> AdamW -> LR schedule, the order of
+    Model.training_step + Lightning (experiments/ae_v2/train.py:209-223,254-261)."""
+    for _, p in trainable(sd):
+        p.grad = None
+    recon, z = forward(x, sd, training=True)
+    loss = loss_fn(recon, x, recon_weight, perceptual_weight)
+    loss.backward()
+    if opt is not None:
+        opt.step()
+        if sched is not None:
+            sched.step()
+    return recon.detach(), z.detach(), float(loss.detach())

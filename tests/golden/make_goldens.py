@@ -1,0 +1,339 @@
+"""Generate tests/golden/*.npz by IMPORTING THE REAL REFERENCE (build container
+only; /root/reference does not exist on the GPU box).
+
+    python tests/golden/make_goldens.py [--only g1,g3,...]
+
+Nothing from the reference is copied: the script imports
+pipeline.models.ae_64x8x8_lin from /root/reference, loads weights from the
+build's counter-based generator (weatherforecastingtoolkit_amd/synth.py), runs
+the reference on CPU fp32 and stores inputs' seeds, outputs, losses and
+gradient summaries.  It also cross-checks oracle/ae_oracle.py against the
+reference on the same tensors and refuses to write a fixture if they differ.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from weatherforecastingtoolkit_amd import synth  # noqa: E402
+from oracle import ae_oracle as orc  # noqa: E402
+
+import pipeline.models.ae_64x8x8_lin as ref  # noqa: E402  (the real reference)
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+# ------------------------------------------------------------------ G1 ---
+def g1_ops():
+    """Per-op vectors from the torch modules the reference instantiates."""
+    out = {}
+    seed = 11
+
+    def case(name, mod, x, extra=None):
+        x = T(x).requires_grad_(True)
+        y = mod(x)
+        gy = T(synth.uniform(seed, name + "/gy", tuple(y.shape), -1, 1))
+        y.backward(gy)
+        out[name + "/x"] = x.detach().numpy()
+        out[name + "/y"] = y.detach().numpy()
+        out[name + "/gy"] = gy.numpy()
+        out[name + "/gx"] = x.grad.numpy()
+        for n, p in mod.named_parameters():
+            out[f"{name}/{n}"] = p.detach().numpy()
+            out[f"{name}/g_{n}"] = p.grad.numpy()
+        for n, b in mod.named_buffers():
+            out[f"{name}/buf_{n}"] = b.detach().numpy()
+
+    def setw(mod, name):
+        with torch.no_grad():
+            for n, p in mod.named_parameters():
+                if isinstance(mod, nn.BatchNorm2d):
+                    lo, hi = (0.8, 1.2) if n == "weight" else (-0.1, 0.1)
+                else:
+                    lo, hi = -0.3, 0.3
+                p.copy_(T(synth.uniform(seed, f"{name}/{n}", tuple(p.shape), lo, hi)))
+        return mod
+
+    # the exact layer configurations of ae_64x8x8_lin.py:15-19,31,42,69,79,84
+    case("conv4s2", setw(nn.Conv2d(3, 8, 4, stride=2, padding=1, bias=False), "conv4s2"),
+         synth.uniform(seed, "conv4s2/x", (2, 3, 16, 16), -1, 1))
+    case("conv4s2_c1", setw(nn.Conv2d(1, 16, 4, stride=2, padding=1, bias=False), "conv4s2_c1"),
+         synth.uniform(seed, "conv4s2_c1/x", (2, 1, 16, 24), 0, 1))
+    case("convT4s2", setw(nn.ConvTranspose2d(8, 4, 4, stride=2, padding=1, bias=False), "convT4s2"),
+         synth.uniform(seed, "convT4s2/x", (2, 8, 8, 8), -1, 1))
+    case("conv1x1", setw(nn.Conv2d(32, 8, 1, bias=False), "conv1x1"),
+         synth.uniform(seed, "conv1x1/x", (2, 32, 8, 8), -1, 1))
+    case("conv1x1_bias", setw(nn.Conv2d(16, 64, 1), "conv1x1_bias"),
+         synth.uniform(seed, "conv1x1_bias/x", (2, 16, 8, 8), -1, 1))
+    case("gconv3", setw(nn.Conv2d(32, 32, 3, padding=1, groups=8, bias=False), "gconv3"),
+         synth.uniform(seed, "gconv3/x", (2, 32, 16, 16), -1, 1))
+    case("conv3_out", setw(nn.Conv2d(16, 1, 3, padding=1), "conv3_out"),
+         synth.uniform(seed, "conv3_out/x", (2, 16, 16, 16), -1, 1))
+    case("linear", setw(nn.Linear(256, 64), "linear"),
+         synth.uniform(seed, "linear/x", (4, 256), -1, 1))
+    bn = setw(nn.BatchNorm2d(8), "bn").train()
+    case("bn_train", bn, synth.uniform(seed, "bn/x", (4, 8, 8, 8), -2, 3))
+    bn_gelu = nn.Sequential(setw(nn.BatchNorm2d(8), "bng"), nn.GELU()).train()
+    case("bn_gelu_train", bn_gelu, synth.uniform(seed, "bng/x", (4, 8, 8, 8), -2, 3))
+    bn_e = setw(nn.BatchNorm2d(8), "bne").eval()
+    with torch.no_grad():
+        bn_e.running_mean.copy_(T(synth.uniform(seed, "bne/rm", (8,), -0.5, 0.5)))
+        bn_e.running_var.copy_(T(synth.uniform(seed, "bne/rv", (8,), 0.5, 1.5)))
+    case("bn_eval", bn_e, synth.uniform(seed, "bne/x", (4, 8, 8, 8), -2, 3))
+    case("gelu", nn.GELU(), synth.uniform(seed, "gelu/x", (2, 4, 8, 8), -4, 4))
+
+    # sigmoid + L1 (experiments/ae_v2/train.py:55 after ae_64x8x8_lin.py:102)
+    h = T(synth.uniform(seed, "sl1/h", (2, 1, 16, 16), -3, 3)).requires_grad_(True)
+    x = T(synth.uniform(seed, "sl1/x", (2, 1, 16, 16), 0, 1))
+    loss = F.l1_loss(torch.sigmoid(h), x, reduction="mean")
+    loss.backward()
+    out["sl1/h"], out["sl1/x"] = h.detach().numpy(), x.numpy()
+    out["sl1/loss"], out["sl1/gh"] = loss.detach().numpy(), h.grad.numpy()
+    save("g1_ops", **out)
+
+
+# ------------------------------------------------------------------ G2 ---
+def _load_np(mod, seed, tag):
+    sd = mod.state_dict()
+    new = {}
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            new[k] = v
+        elif k.endswith("running_mean"):
+            new[k] = T(synth.uniform(seed, f"{tag}/{k}", tuple(v.shape), -0.05, 0.05))
+        elif k.endswith("running_var"):
+            new[k] = T(synth.uniform(seed, f"{tag}/{k}", tuple(v.shape), 0.9, 1.1))
+        elif v.ndim == 1 and k.endswith(".weight"):
+            new[k] = T(synth.uniform(seed, f"{tag}/{k}", tuple(v.shape), 0.8, 1.2))
+        elif v.ndim == 1:
+            new[k] = T(synth.uniform(seed, f"{tag}/{k}", tuple(v.shape), -0.1, 0.1))
+        else:
+            b = 1.0 / np.sqrt(np.prod(v.shape[1:]))
+            new[k] = T(synth.uniform(seed, f"{tag}/{k}", tuple(v.shape), -b, b))
+    mod.load_state_dict(new)
+    return mod
+
+
+def g2_blocks():
+    out = {}
+    seed = 22
+    cases = [
+        ("bottleneck32", ref.Bottleneck(32), (2, 32, 16, 16), orc.bottleneck),
+        ("bottleneck64", ref.Bottleneck(64), (3, 64, 8, 8), orc.bottleneck),
+        ("encblock", ref.EncBlock(1, 32, num_blocks=1), (2, 1, 32, 32), orc.enc_block),
+        ("encblock2", ref.EncBlock(16, 32, num_blocks=2), (2, 16, 16, 16), orc.enc_block),
+        ("decblock", ref.DecBlock(32, 16, num_blocks=1), (2, 32, 8, 8), orc.dec_block),
+    ]
+    for name, mod, shp, ofn in cases:
+        mod = _load_np(mod, seed, name).train()
+        sd0 = {k: v.clone() for k, v in mod.state_dict().items()}
+        x = T(synth.uniform(seed, name + "/x", shp, -1, 1)).requires_grad_(True)
+        y = mod(x)
+        gy = T(synth.uniform(seed, name + "/gy", tuple(y.shape), -1, 1))
+        y.backward(gy)
+        # oracle cross-check on identical tensors
+        osd = {k: v.clone() for k, v in sd0.items()}
+        for k, v in osd.items():
+            if v.dtype.is_floating_point and "running_" not in k:
+                v.requires_grad_(True)
+        ox = x.detach().clone().requires_grad_(True)
+        oy = ofn(ox, _prefixed(osd), "m", True)
+        oy.backward(gy)
+        assert torch.equal(oy, y), name
+        assert torch.allclose(ox.grad, x.grad, rtol=0, atol=0), name
+        out[name + "/x"], out[name + "/y"] = x.detach().numpy(), y.detach().numpy()
+        out[name + "/gy"], out[name + "/gx"] = gy.numpy(), x.grad.numpy()
+        for k, v in sd0.items():
+            out[f"{name}/sd/{k}"] = v.numpy()
+        for k, p in mod.named_parameters():
+            out[f"{name}/grad/{k}"] = p.grad.numpy()
+        for k, b in mod.named_buffers():
+            out[f"{name}/after/{k}"] = b.detach().numpy()
+    save("g2_blocks", **out)
+
+
+class _prefixed(dict):
+    """view of a state dict under the prefix 'm.'"""
+
+    def __init__(self, sd):
+        super().__init__({"m." + k: v for k, v in sd.items()})
+
+
+# --------------------------------------------------------------- G3/G4 ---
+def _make_ref_net(img_size):
+    net = ref.PosAwareAE_TF()
+    if img_size != 128:
+        # 384 extension: conv stacks untouched,
+        # bottleneck glue re-created at hw = img/16.
+        hw = img_size // 16
+        net.pos_emb = nn.Parameter(torch.randn(1, 64, hw, hw))
+        net.to_latent = nn.Linear(hw * hw * 64, 2048)
+        net.from_latent = nn.Linear(2048, hw * hw * 64)
+
+        def decode(self, z_flat):
+            B = z_flat.size(0)
+            z = self.from_latent(z_flat).view(B, self.latent_channels, hw, hw)
+            return self.act(self.dec(z))
+
+        net.decode = types.MethodType(decode, net)
+    return net
+
+
+LATTICE = 16  # recon sampled on a LATTICE x LATTICE grid per image
+
+
+def _summ(t):
+    t = t.detach().double()
+    return np.array([t.mean().item(), t.std().item(), t.abs().max().item(), t.norm().item()])
+
+
+def g_full(name, img_size, batch, steps, frames="uniform"):
+    spec = synth.ae_state_dict_spec(img_size)
+    np_sd = synth.synth_state_dict(spec, seed=0)
+    net = _make_ref_net(img_size)
+    ref_keys = list(net.state_dict().keys())
+    assert ref_keys == [k for k, _, _ in spec], "state_dict key order differs from the reference"
+    net.load_state_dict({k: (T(v) if v.ndim else torch.tensor(0)) for k, v in np_sd.items()}, strict=True)
+    net.train()
+    if frames == "uniform":
+        x = T(synth.uniform_frames(batch, img_size, seed=1234))
+    else:
+        ev = synth.blob_events(1, img_size, batch, seed=1234)
+        x = T((ev[0].transpose(2, 0, 1)[:, None].astype(np.float32)) * np.float32(1 / 255))
+    total_steps, warm = 40, 4.0
+    opt = orc.make_optimizer(net.parameters(), lr=5e-5, weight_decay=1e-4)
+    sched = orc.make_scheduler(opt, 5e-6, 5e-7, 5e-5, total_steps, warm)
+
+    osd = orc.to_torch_sd(np_sd)
+    oopt = orc.make_optimizer([p for _, p in orc.trainable(osd)], lr=5e-5, weight_decay=1e-4)
+    osched = orc.make_scheduler(oopt, 5e-6, 5e-7, 5e-5, total_steps, warm)
+
+    out = {"img_size": img_size, "batch": batch, "frames": frames, "steps": steps,
+           "sched": np.array([5e-6, 5e-5, 5e-7, total_steps, warm])}
+    idx = np.linspace(0, img_size - 1, LATTICE).round().astype(np.int64)
+    out["lattice"] = idx
+    for s in range(steps):
+        opt.zero_grad(set_to_none=True)
+        recon, z = net(x)
+        loss = F.l1_loss(recon, x, reduction="mean")  # experiments/ae_v2/train.py:55
+        loss.backward()
+        if s == 0:
+            out["recon_lattice"] = recon.detach()[:, 0][:, idx][:, :, idx].numpy()
+            out["recon_summary"] = _summ(recon)
+            out["recon_row"] = recon.detach()[0, 0, img_size // 2].numpy()
+            out["z"] = z.detach().numpy()
+            out["grad_norms"] = np.array([p.grad.double().norm().item() for _, p in net.named_parameters()])
+            out["grad_names"] = np.array([n for n, _ in net.named_parameters()])
+            out["g_dec_last_w"] = net.dec[-1].weight.grad.numpy()
+            out["g_pos_emb_sample"] = net.pos_emb.grad.flatten()[:256].numpy()
+            out["g_enc0_w"] = net.enc[0].down[0].weight.grad.numpy()
+        out[f"loss{s}"] = np.float64(loss.item())
+        opt.step()
+        sched.step()
+        out[f"lr_after{s}"] = np.float64(opt.param_groups[0]["lr"])
+        out[f"param_norms{s}"] = np.array([p.detach().double().norm().item() for _, p in net.named_parameters()])
+        # oracle cross-check, step by step
+        orecon, oz, oloss = orc.train_step(x, osd, oopt, osched)
+        assert torch.equal(orecon, recon.detach()), f"oracle recon differs at step {s}"
+        assert oloss == loss.item(), f"oracle loss differs at step {s}"
+    sd_after = net.state_dict()
+    for k in ["enc.0.down.1", "enc.3.res.3.f.6", "dec.4.res.3.f.0"]:
+        out[f"after/{k}.running_mean"] = sd_after[k + ".running_mean"].numpy()
+        out[f"after/{k}.running_var"] = sd_after[k + ".running_var"].numpy()
+        out[f"after/{k}.num_batches_tracked"] = sd_after[k + ".num_batches_tracked"].numpy()
+    for (k, v) in osd.items():
+        assert torch.equal(v.detach(), sd_after[k]), f"oracle state differs: {k}"
+    # eval-mode forward after training (BN running stats path)
+    net.eval()
+    with torch.no_grad():
+        er, ez = net(x)
+    out["eval_recon_lattice"] = er[:, 0][:, idx][:, :, idx].numpy()
+    out["eval_z"] = ez.numpy()
+    save(name, **out)
+
+
+# ------------------------------------------------------------------ G7 ---
+def g7_metrics():
+    """SSIM/PSNR from the restatement (UNPINNED: pytorch_msssim/torchmetrics absent)."""
+    out = {}
+    for i, (b, s) in enumerate([(2, 32), (2, 64), (1, 128), (3, 48)]):
+        a = T(synth.uniform(7, f"m{i}/a", (b, 1, s, s), 0, 1))
+        n = T(synth.uniform(7, f"m{i}/n", (b, 1, s, s), -0.2, 0.2))
+        p = (a + n).clamp(0, 1)
+        out[f"{i}/target"], out[f"{i}/pred"] = a.numpy(), p.numpy()
+        out[f"{i}/ssim"] = np.float64(orc.ssim(p.double(), a.double()).item())
+        out[f"{i}/psnr"] = np.float64(orc.psnr(p.double(), a.double()))
+        pp = p.clone().requires_grad_(True)
+        l = 1 - orc.ssim(a, pp)
+        l.backward()
+        out[f"{i}/ssim_loss_grad"] = pp.grad.numpy()
+    save("g7_metrics", **out)
+
+
+# ------------------------------------------------------------------ G8 ---
+def g8_sched():
+    out = {}
+    for i, (total, ratio) in enumerate([(40, 0.1), (37, 0.1), (100, 0.25), (10, 0.33)]):
+        warm = ratio * total
+        p = [nn.Parameter(torch.zeros(1))]
+        opt = orc.make_optimizer(p, lr=5e-5)
+        sch = orc.make_scheduler(opt, 5e-6, 5e-7, 5e-5, total, warm)
+        lrs = [opt.param_groups[0]["lr"]]
+        for _ in range(total):
+            opt.step()
+            sch.step()
+            lrs.append(opt.param_groups[0]["lr"])
+        out[f"{i}/cfg"] = np.array([5e-6, 5e-5, 5e-7, total, warm])
+        out[f"{i}/lrs"] = np.array(lrs)
+    save("g8_sched", **out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    only = set(a.only.split(",")) if a.only else None
+
+    def want(n):
+        return only is None or n in only
+
+    if want("g1"):
+        g1_ops()
+    if want("g2"):
+        g2_blocks()
+    if want("g3"):
+        g_full("g3_full128_b2", 128, 2, 3, "uniform")
+        g_full("g3_full128_b4_blobs", 128, 4, 1, "blobs")
+    if want("g4"):
+        g_full("g4_full384_b1", 384, 1, 1, "blobs")
+    if want("g7"):
+        g7_metrics()
+    if want("g8"):
+        g8_sched()
+
+
+if __name__ == "__main__":
+    main()

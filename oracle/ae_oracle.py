@@ -177,15 +177,23 @@ def loss_fn(recon, x, recon_weight=1.0, perceptual_weight=0.0):
 
 # ------------------------------------------------------------- optimiser ---
 def lr_at(step, start_lr, peak_lr, final_lr, total_steps, warmup_steps):
-    """Closed form of SequentialLR[LinearLR, CosineAnnealingLR] as built by
-    cosine_warmup_scheduler (pipeline/helpers.py:76-107) after `step`
-    scheduler.step() calls.  warmup_steps may be non-integer (train.py:258)."""
+    """LR after `step` scheduler.step() calls of the SequentialLR built by
+    cosine_warmup_scheduler (pipeline/helpers.py:76-107), in closed form.
+    warmup_steps may be non-integer (train.py:258): the milestone is then never
+    hit exactly, torch enters CosineAnnealingLR through its chained form and the
+    ratios telescope to (1+cos(pi t/T))/(1+cos(pi/T)) from the last linear LR.
+    Pinned against the real torch classes by tests/golden/g8_sched.npz."""
+    sf = start_lr / peak_lr
+    lin = lambda k: peak_lr * (sf + (1.0 - sf) * min(k, warmup_steps) / warmup_steps)
     if step < warmup_steps:
-        sf = start_lr / peak_lr
-        return peak_lr * (sf + (1.0 - sf) * min(step, warmup_steps) / warmup_steps)
-    t = step - math.ceil(warmup_steps) if warmup_steps != int(warmup_steps) else step - int(warmup_steps)
+        return lin(step)
     tmax = total_steps - warmup_steps
-    return final_lr + (peak_lr - final_lr) * (1 + math.cos(math.pi * t / tmax)) / 2
+    if float(warmup_steps).is_integer():
+        t = step - int(warmup_steps)
+        return final_lr + (peak_lr - final_lr) * (1 + math.cos(math.pi * t / tmax)) / 2
+    first = math.floor(warmup_steps) + 1
+    t = step - first
+    return final_lr + (lin(first - 1) - final_lr) * (1 + math.cos(math.pi * t / tmax)) / (1 + math.cos(math.pi / tmax))
 
 
 def make_optimizer(params, lr=5e-5, weight_decay=1e-4, beta1=0.9, beta2=0.999):

@@ -1,0 +1,77 @@
+// common.h — shared helpers for the libwfae.so HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/wfae.h"
+
+namespace wfae {
+
+// thread-local last-error text (wfae_last_error_string)
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(WFAE_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return WFAE_OK;
+}
+
+#define WFAE_REQUIRE(cond, code, ...) \
+  do {                                \
+    if (!(cond)) return ::wfae::fail(code, __VA_ARGS__); \
+  } while (0)
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum of a double for blocks of up to 1024 threads; result valid in thread 0.
+__device__ __forceinline__ double block_sum(double v, double* sm /* >= 16 doubles */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += sm[i];
+  }
+  return r;
+}
+
+// exact (erf) GELU and its derivative — nn.GELU(approximate='none')
+__device__ __forceinline__ float gelu_f(float u) {
+  return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_grad_f(float u) {
+  const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
+  return cdf + u * pdf;
+}
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace wfae

@@ -1,0 +1,649 @@
+// norm_act.hip — bandwidth-bound kernels of the hot path: BatchNorm2d statistics
+// (wavefront-shuffle reductions, fp64 accumulation), fused BN-apply + exact GELU,
+// their backward, sigmoid + L1 loss, element-wise helpers and channel reductions.
+// All kernels use 16-byte loads when HW % 4 == 0 (always true for the model).
+#include "common.h"
+
+using namespace wfae;
+
+namespace {
+
+constexpr int RT = 256;  // reduction block size
+
+// ------------------------------------------------------------- reductions
+// Generic per-channel reduction over x[outer][C][inner]:
+// block (c, s) reduces the s-th slice of the (outer*inner) index space.
+struct RedGeom {
+  int outer, C, inner, splits;
+  long per_split;  // elements per split (multiple of 4 when vectorised)
+};
+
+inline RedGeom red_geom(int outer, int C, int inner, long max_parts_per_c) {
+  RedGeom g;
+  g.outer = outer; g.C = C; g.inner = inner;
+  const long total = (long)outer * inner;
+  long splits = (2048 + C - 1) / C;
+  if (splits > max_parts_per_c) splits = max_parts_per_c;
+  const long min_chunk = 4096;
+  if (splits > (total + min_chunk - 1) / min_chunk) splits = (total + min_chunk - 1) / min_chunk;
+  if (splits < 1) splits = 1;
+  long per = (total + splits - 1) / splits;
+  per = (per + 3) / 4 * 4;
+  g.per_split = per;
+  g.splits = (int)((total + per - 1) / per);
+  return g;
+}
+
+// mode 0: (sum x, sum x^2)          stats
+// mode 1: (sum x, 0)                plain sum
+template <int MODE>
+__global__ __launch_bounds__(RT) void chan_reduce_kernel(const float* __restrict__ x, double* __restrict__ part,
+                                                         RedGeom g, int vec) {
+  __shared__ double sm[16];
+  const int c = blockIdx.x, s = blockIdx.y;
+  const long total = (long)g.outer * g.inner;
+  const long beg = (long)s * g.per_split;
+  long end = beg + g.per_split;
+  if (end > total) end = total;
+  double s1 = 0.0, s2 = 0.0;
+  if (vec) {
+    for (long i = beg + (long)threadIdx.x * 4; i < end; i += RT * 4) {
+      const long o = i / g.inner;
+      const long in = i - o * g.inner;
+      const float4 v = *reinterpret_cast<const float4*>(x + (o * g.C + c) * g.inner + in);
+      s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      if (MODE == 0)
+        s2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+  } else {
+    for (long i = beg + threadIdx.x; i < end; i += RT) {
+      const long o = i / g.inner;
+      const long in = i - o * g.inner;
+      const float v = x[(o * g.C + c) * g.inner + in];
+      s1 += v;
+      if (MODE == 0) s2 += (double)v * v;
+    }
+  }
+  const double r1 = block_sum(s1, sm);
+  double r2 = 0.0;
+  if (MODE == 0) r2 = block_sum(s2, sm);
+  if (threadIdx.x == 0) {
+    part[((long)c * g.splits + s) * 2 + 0] = r1;
+    part[((long)c * g.splits + s) * 2 + 1] = r2;
+  }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ part, int splits, long count, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ save_mean,
+                                   float* __restrict__ save_invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < splits; ++s) {
+    s1 += part[((long)c * splits + s) * 2 + 0];
+    s2 += part[((long)c * splits + s) * 2 + 1];
+  }
+  const double mean = s1 / (double)count;
+  double var = s2 / (double)count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float meanf = (float)mean;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  save_mean[c] = meanf;
+  save_invstd[c] = invstd;
+  const float a = gamma[c] * invstd;
+  scale[c] = a;
+  shift[c] = beta[c] - meanf * a;
+  if (running_mean) {
+    const double unb = count > 1 ? var * ((double)count / (double)(count - 1)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+__global__ void bn_fold_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                    float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                    float* __restrict__ scale, float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.0f / sqrtf(rv[c] + eps);
+  save_mean[c] = rm[c];
+  save_invstd[c] = invstd;
+  const float a = gamma[c] * invstd;
+  scale[c] = a;
+  shift[c] = beta[c] - rm[c] * a;
+}
+
+__global__ void sum_finalize_kernel(const double* __restrict__ part, int splits, int C, float* __restrict__ out,
+                                    int beta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0;
+  for (int s = 0; s < splits; ++s) s1 += part[((long)c * splits + s) * 2];
+  float v = (float)s1;
+  if (beta) v += out[c];
+  out[c] = v;
+}
+
+// ------------------------------------------------------- BN apply (+GELU)
+// grid.x = NB*C planes, grid.y = chunks of the HW plane
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float* __restrict__ y,
+                                                         int C, int HW, int vec) {
+  const int plane = blockIdx.x;
+  const int c = plane % C;
+  const float a = scale[c], b = shift[c];
+  const float* xp = x + (long)plane * HW;
+  float* yp = y + (long)plane * HW;
+  if (vec) {
+    const int n4 = HW >> 2;
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n4; i += gridDim.y * blockDim.x) {
+      float4 v = reinterpret_cast<const float4*>(xp)[i];
+      v.x = fmaf(v.x, a, b); v.y = fmaf(v.y, a, b); v.z = fmaf(v.z, a, b); v.w = fmaf(v.w, a, b);
+      if (ACT == 1) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+      reinterpret_cast<float4*>(yp)[i] = v;
+    }
+  } else {
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < HW; i += gridDim.y * blockDim.x) {
+      float v = fmaf(xp[i], a, b);
+      if (ACT == 1) v = gelu_f(v);
+      yp[i] = v;
+    }
+  }
+}
+
+// backward pass 1: per channel  sum dU  and  sum dU * xhat,  dU = dy * act'(u)
+template <int ACT>
+__global__ __launch_bounds__(RT) void bn_act_bwd_reduce_kernel(const float* __restrict__ dy,
+                                                               const float* __restrict__ x,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               double* __restrict__ part, RedGeom g, int vec) {
+  __shared__ double sm[16];
+  const int c = blockIdx.x, s = blockIdx.y;
+  const long total = (long)g.outer * g.inner;
+  const long beg = (long)s * g.per_split;
+  long end = beg + g.per_split;
+  if (end > total) end = total;
+  const float a = scale[c], b = shift[c], mu = mean[c], is = invstd[c];
+  double s1 = 0.0, s2 = 0.0;
+  auto one = [&](float xv, float dv) {
+    float du = dv;
+    if (ACT == 1) du *= gelu_grad_f(fmaf(xv, a, b));
+    s1 += du;
+    s2 += (double)du * ((xv - mu) * is);
+  };
+  if (vec) {
+    for (long i = beg + (long)threadIdx.x * 4; i < end; i += RT * 4) {
+      const long o = i / g.inner;
+      const long off = (o * g.C + c) * g.inner + (i - o * g.inner);
+      const float4 xv = *reinterpret_cast<const float4*>(x + off);
+      const float4 dv = *reinterpret_cast<const float4*>(dy + off);
+      one(xv.x, dv.x); one(xv.y, dv.y); one(xv.z, dv.z); one(xv.w, dv.w);
+    }
+  } else {
+    for (long i = beg + threadIdx.x; i < end; i += RT) {
+      const long o = i / g.inner;
+      const long off = (o * g.C + c) * g.inner + (i - o * g.inner);
+      one(x[off], dy[off]);
+    }
+  }
+  const double r1 = block_sum(s1, sm);
+  const double r2 = block_sum(s2, sm);
+  if (threadIdx.x == 0) {
+    part[((long)c * g.splits + s) * 2 + 0] = r1;
+    part[((long)c * g.splits + s) * 2 + 1] = r2;
+  }
+}
+
+// finalize: dbeta = sum dU, dgamma = sum dU*xhat; also leaves the two fp32 sums in coef[2c..]
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int splits, int C,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ coef, int beta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < splits; ++s) {
+    s1 += part[((long)c * splits + s) * 2 + 0];
+    s2 += part[((long)c * splits + s) * 2 + 1];
+  }
+  coef[2 * c + 0] = (float)s1;
+  coef[2 * c + 1] = (float)s2;
+  if (dbeta) dbeta[c] = (beta ? dbeta[c] : 0.f) + (float)s1;
+  if (dgamma) dgamma[c] = (beta ? dgamma[c] : 0.f) + (float)s2;
+}
+
+// backward pass 2: dx = gamma*invstd*(dU - sum_dU/n - xhat*sum_dUxhat/n) (+res)
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ coef,
+                                                            const float* __restrict__ res, float* __restrict__ dx,
+                                                            int C, int HW, float inv_count, int training, int vec) {
+  const int plane = blockIdx.x;
+  const int c = plane % C;
+  const float a = scale[c], b = shift[c], mu = mean[c], is = invstd[c];
+  const float gi = gamma[c] * is;
+  const float k1 = training ? coef[2 * c + 0] * inv_count : 0.f;
+  const float k2 = training ? coef[2 * c + 1] * inv_count : 0.f;
+  const long base = (long)plane * HW;
+  auto one = [&](float xv, float dv, float rv) {
+    float du = dv;
+    if (ACT == 1) du *= gelu_grad_f(fmaf(xv, a, b));
+    const float xh = (xv - mu) * is;
+    return gi * (du - k1 - xh * k2) + rv;
+  };
+  if (vec) {
+    const int n4 = HW >> 2;
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n4; i += gridDim.y * blockDim.x) {
+      const float4 xv = reinterpret_cast<const float4*>(x + base)[i];
+      const float4 dv = reinterpret_cast<const float4*>(dy + base)[i];
+      float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (res) rv = reinterpret_cast<const float4*>(res + base)[i];
+      float4 o;
+      o.x = one(xv.x, dv.x, rv.x); o.y = one(xv.y, dv.y, rv.y);
+      o.z = one(xv.z, dv.z, rv.z); o.w = one(xv.w, dv.w, rv.w);
+      reinterpret_cast<float4*>(dx + base)[i] = o;
+    }
+  } else {
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < HW; i += gridDim.y * blockDim.x)
+      dx[base + i] = one(x[base + i], dy[base + i], res ? res[base + i] : 0.f);
+  }
+}
+
+// ------------------------------------------------------------ element-wise
+enum EwOp { EW_GELU = 0, EW_GELU_BWD = 1, EW_SIGMOID = 2, EW_SIGMOID_BWD = 3, EW_ADD = 4 };
+
+template <int OP>
+__device__ __forceinline__ float ew_apply(float a, float b) {
+  if (OP == EW_GELU) return gelu_f(a);
+  if (OP == EW_GELU_BWD) return a * gelu_grad_f(b);           // a = dy, b = x
+  if (OP == EW_SIGMOID) return sigmoid_f(a);
+  if (OP == EW_SIGMOID_BWD) return a * b * (1.f - b);         // a = dy, b = y
+  return a + b;
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                 float* __restrict__ out, long n, int vec) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    const long n4 = n >> 2;
+    for (long i = i0; i < n4; i += stride) {
+      const float4 av = reinterpret_cast<const float4*>(a)[i];
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b) bv = reinterpret_cast<const float4*>(b)[i];
+      float4 o;
+      o.x = ew_apply<OP>(av.x, bv.x); o.y = ew_apply<OP>(av.y, bv.y);
+      o.z = ew_apply<OP>(av.z, bv.z); o.w = ew_apply<OP>(av.w, bv.w);
+      reinterpret_cast<float4*>(out)[i] = o;
+    }
+    for (long i = (n4 << 2) + i0; i < n; i += stride) out[i] = ew_apply<OP>(a[i], b ? b[i] : 0.f);
+  } else {
+    for (long i = i0; i < n; i += stride) out[i] = ew_apply<OP>(a[i], b ? b[i] : 0.f);
+  }
+}
+
+template <int OP>
+int launch_ew(const float* a, const float* b, float* out, int64_t n, hipStream_t st, const char* what) {
+  WFAE_REQUIRE(a && out, WFAE_ERR_NULL_POINTER, "%s: null pointer", what);
+  WFAE_REQUIRE(n >= 0, WFAE_ERR_BAD_SHAPE, "%s: bad size", what);
+  if (n == 0) return WFAE_OK;
+  const int vec = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) |
+                    reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((ew_kernel<OP>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, out, (long)n, vec);
+  return check_launch(what);
+}
+
+// ---------------------------------------------------------- sigmoid + L1
+// mode 0: recon = sigmoid(h), partial sum |recon - x| ; mode 1: h already is recon (plain L1)
+template <int MODE>
+__global__ __launch_bounds__(RT) void l1_fwd_kernel(const float* __restrict__ h, const float* __restrict__ x,
+                                                    float* __restrict__ recon, double* __restrict__ part, long n,
+                                                    int vec) {
+  __shared__ double sm[16];
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  double s = 0.0;
+  auto one = [&](float hv, float xv) {
+    const float r = MODE == 0 ? sigmoid_f(hv) : hv;
+    s += (double)fabsf(r - xv);
+    return r;
+  };
+  if (vec) {
+    const long n4 = n >> 2;
+    for (long i = i0; i < n4; i += stride) {
+      const float4 hv = reinterpret_cast<const float4*>(h)[i];
+      const float4 xv = reinterpret_cast<const float4*>(x)[i];
+      float4 r;
+      r.x = one(hv.x, xv.x); r.y = one(hv.y, xv.y); r.z = one(hv.z, xv.z); r.w = one(hv.w, xv.w);
+      if (MODE == 0) reinterpret_cast<float4*>(recon)[i] = r;
+    }
+    for (long i = (n4 << 2) + i0; i < n; i += stride) {
+      const float r = one(h[i], x[i]);
+      if (MODE == 0) recon[i] = r;
+    }
+  } else {
+    for (long i = i0; i < n; i += stride) {
+      const float r = one(h[i], x[i]);
+      if (MODE == 0) recon[i] = r;
+    }
+  }
+  const double r = block_sum(s, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
+__global__ void scalar_finalize_kernel(const double* __restrict__ part, int parts, double mul, float* out_f,
+                                       double* out_d) {
+  __shared__ double sm[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < parts; i += blockDim.x) s += part[i];
+  const double r = block_sum(s, sm);
+  if (threadIdx.x == 0) {
+    if (out_f) out_f[0] = (float)(r * mul);
+    if (out_d) out_d[0] = r * mul;
+  }
+}
+
+// mode 0: dh = g*w/n * sign(r-x) * r(1-r) ; mode 1: drecon = g*w/n * sign(r-x)
+template <int MODE>
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ recon, const float* __restrict__ x,
+                                                     const float* __restrict__ gloss, float wn,
+                                                     float* __restrict__ dh, long n) {
+  const float g = gloss[0] * wn;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float r = recon[i];
+    const float d = r - x[i];
+    float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    if (MODE == 0) sg *= r * (1.f - r);
+    dh[i] = g * sg;
+  }
+}
+
+__global__ __launch_bounds__(RT) void sumsq_kernel(const float* __restrict__ x, double* __restrict__ part, long n) {
+  __shared__ double sm[16];
+  const long stride = (long)gridDim.x * blockDim.x;
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += (double)x[i] * x[i];
+  const double r = block_sum(s, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                                                    float b1, float b2, float eps, float wd, float bc1,
+                                                    float bc2_sqrt, float gscale) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  const float step = lr / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gv = g[i] * gscale;
+    float pv = p[i];
+    pv *= 1.f - lr * wd;
+    const float mv = m[i] + (gv - m[i]) * (1.f - b1);       // lerp form used by torch (_single_tensor_adamw)
+    const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+    m[i] = mv;
+    v[i] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[i] = pv - step * (mv / denom);
+  }
+}
+
+__global__ void vil_u8_to_f32_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int H, int W, int T,
+                                     float scale, long total) {
+  // dst[n][t][h][w] = scale * src[n][h][w][t]
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int w = (int)(i % W);
+    long r = i / W;
+    const int h = (int)(r % H);
+    r /= H;
+    const int t = (int)(r % T);
+    const long n = r / T;
+    dst[i] = scale * ((float)src[((n * H + h) * W + w) * T + t] + 0.f);
+  }
+}
+
+inline int grid_1d(long n, int per_thread = 4) {
+  long b = (n / per_thread + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wfae_bn_stats_train(const float* x, int NB, int C, int HW, const float* gamma, const float* beta,
+                        float eps, float momentum, float* running_mean, float* running_var,
+                        float* save_mean, float* save_invstd, float* scale, float* shift, void* ws,
+                        size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(x && gamma && beta && save_mean && save_invstd && scale && shift, WFAE_ERR_NULL_POINTER,
+               "bn_stats_train: null pointer");
+  WFAE_REQUIRE(NB > 0 && C > 0 && HW > 0 && C <= 65535 * 32, WFAE_ERR_BAD_SHAPE, "bn_stats_train: bad shape");
+  const long maxp = (long)(ws_bytes / (sizeof(double) * 2 * (size_t)C));
+  WFAE_REQUIRE(ws && maxp >= 1, WFAE_ERR_WORKSPACE, "bn_stats_train: workspace too small");
+  RedGeom g = red_geom(NB, C, HW, maxp < 65535 ? maxp : 65535);
+  const int vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((chan_reduce_kernel<0>), dim3(C, g.splits), dim3(RT), 0, st, x, (double*)ws, g, vec);
+  int rc = check_launch("bn_stats");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, g.splits,
+                     (long)NB * HW, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
+                     save_invstd, scale, shift);
+  return check_launch("bn_finalize");
+}
+
+int wfae_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, float* save_mean, float* save_invstd,
+                      float* scale, float* shift, int C, wfae_stream_t stream) {
+  WFAE_REQUIRE(gamma && beta && running_mean && running_var && save_mean && save_invstd && scale && shift,
+               WFAE_ERR_NULL_POINTER, "bn_fold_eval: null pointer");
+  WFAE_REQUIRE(C > 0, WFAE_ERR_BAD_SHAPE, "bn_fold_eval: bad shape");
+  hipLaunchKernelGGL(bn_fold_eval_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, save_mean, save_invstd, scale, shift, C);
+  return check_launch("bn_fold_eval");
+}
+
+int wfae_bn_act_fwd(const float* x, const float* scale, const float* shift, float* y, int NB, int C,
+                    int HW, int act, wfae_stream_t stream) {
+  WFAE_REQUIRE(x && scale && shift && y, WFAE_ERR_NULL_POINTER, "bn_act_fwd: null pointer");
+  WFAE_REQUIRE(NB > 0 && C > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "bn_act_fwd: bad shape");
+  const int vec = (HW % 4 == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
+  int gy = cdiv(vec ? HW / 4 : HW, 256 * 4);
+  if (gy < 1) gy = 1;
+  if (gy > 1024) gy = 1024;
+  dim3 grid((unsigned)((long)NB * C), gy);
+  hipStream_t st = (hipStream_t)stream;
+  if (act == 1)
+    hipLaunchKernelGGL((bn_act_fwd_kernel<1>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec);
+  else
+    hipLaunchKernelGGL((bn_act_fwd_kernel<0>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec);
+  return check_launch("bn_act_fwd");
+}
+
+int wfae_bn_act_bwd(const float* dy, const float* x, const float* gamma, const float* scale,
+                    const float* shift, const float* save_mean, const float* save_invstd,
+                    const float* res, float* dx, float* dgamma, float* dbeta, int NB, int C, int HW,
+                    int act, int training, int accumulate, void* ws, size_t ws_bytes,
+                    wfae_stream_t stream) {
+  WFAE_REQUIRE(dy && x && gamma && scale && shift && save_mean && save_invstd, WFAE_ERR_NULL_POINTER,
+               "bn_act_bwd: null pointer");
+  WFAE_REQUIRE(NB > 0 && C > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "bn_act_bwd: bad shape");
+  // workspace: coef[2C] floats (16-byte aligned) followed by fp64 partials
+  const size_t coef_bytes = ((size_t)2 * C * sizeof(float) + 15) / 16 * 16;
+  WFAE_REQUIRE(ws && ws_bytes > coef_bytes + sizeof(double) * 2 * (size_t)C, WFAE_ERR_WORKSPACE,
+               "bn_act_bwd: workspace too small");
+  float* coef = (float*)ws;
+  double* part = (double*)((char*)ws + coef_bytes);
+  const long maxp = (long)((ws_bytes - coef_bytes) / (sizeof(double) * 2 * (size_t)C));
+  RedGeom g = red_geom(NB, C, HW, maxp < 65535 ? maxp : 65535);
+  const int vec = (HW % 4 == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) |
+                                      reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(res)) & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (act == 1)
+    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<1>), dim3(C, g.splits), dim3(RT), 0, st, dy, x, scale, shift,
+                       save_mean, save_invstd, part, g, vec);
+  else
+    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<0>), dim3(C, g.splits), dim3(RT), 0, st, dy, x, scale, shift,
+                       save_mean, save_invstd, part, g, vec);
+  int rc = check_launch("bn_act_bwd_reduce");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, g.splits,
+                     C, dgamma, dbeta, coef, accumulate);
+  rc = check_launch("bn_bwd_finalize");
+  if (rc) return rc;
+  if (dx) {
+    int gy = cdiv(vec ? HW / 4 : HW, 256 * 4);
+    if (gy < 1) gy = 1;
+    if (gy > 1024) gy = 1024;
+    dim3 grid((unsigned)((long)NB * C), gy);
+    const float inv_count = 1.0f / (float)((double)NB * HW);
+    if (act == 1)
+      hipLaunchKernelGGL((bn_act_bwd_dx_kernel<1>), grid, dim3(256), 0, st, dy, x, gamma, scale, shift, save_mean,
+                         save_invstd, coef, res, dx, C, HW, inv_count, training, vec);
+    else
+      hipLaunchKernelGGL((bn_act_bwd_dx_kernel<0>), grid, dim3(256), 0, st, dy, x, gamma, scale, shift, save_mean,
+                         save_invstd, coef, res, dx, C, HW, inv_count, training, vec);
+    rc = check_launch("bn_act_bwd_dx");
+  }
+  return rc;
+}
+
+int wfae_gelu_fwd(const float* x, float* y, int64_t n, wfae_stream_t s) {
+  return launch_ew<EW_GELU>(x, nullptr, y, n, (hipStream_t)s, "gelu_fwd");
+}
+int wfae_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, wfae_stream_t s) {
+  WFAE_REQUIRE(x, WFAE_ERR_NULL_POINTER, "gelu_bwd: null pointer");
+  return launch_ew<EW_GELU_BWD>(dy, x, dx, n, (hipStream_t)s, "gelu_bwd");
+}
+int wfae_sigmoid_fwd(const float* x, float* y, int64_t n, wfae_stream_t s) {
+  return launch_ew<EW_SIGMOID>(x, nullptr, y, n, (hipStream_t)s, "sigmoid_fwd");
+}
+int wfae_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, wfae_stream_t s) {
+  WFAE_REQUIRE(y, WFAE_ERR_NULL_POINTER, "sigmoid_bwd: null pointer");
+  return launch_ew<EW_SIGMOID_BWD>(dy, y, dx, n, (hipStream_t)s, "sigmoid_bwd");
+}
+int wfae_add(const float* a, const float* b, float* out, int64_t n, wfae_stream_t s) {
+  WFAE_REQUIRE(b, WFAE_ERR_NULL_POINTER, "add: null pointer");
+  return launch_ew<EW_ADD>(a, b, out, n, (hipStream_t)s, "add");
+}
+
+int wfae_reduce_sum(const float* x, int outer, int C, int inner, float* out, int accumulate, void* ws,
+                    size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(x && out, WFAE_ERR_NULL_POINTER, "reduce_sum: null pointer");
+  WFAE_REQUIRE(outer > 0 && C > 0 && inner > 0, WFAE_ERR_BAD_SHAPE, "reduce_sum: bad shape");
+  const long maxp = (long)(ws_bytes / (sizeof(double) * 2 * (size_t)C));
+  WFAE_REQUIRE(ws && maxp >= 1, WFAE_ERR_WORKSPACE, "reduce_sum: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  // channel index goes to grid.x: fold very wide C (linear bias, pos_emb) into chunks of 65535*... (grid.x is 2^31)
+  RedGeom g = red_geom(outer, C, inner, maxp < 65535 ? maxp : 65535);
+  const int vec = (inner % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  hipLaunchKernelGGL((chan_reduce_kernel<1>), dim3(C, g.splits), dim3(RT), 0, st, x, (double*)ws, g, vec);
+  int rc = check_launch("reduce_sum");
+  if (rc) return rc;
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, g.splits, C, out,
+                     accumulate);
+  return check_launch("reduce_sum_finalize");
+}
+
+static int l1_common(int mode, const float* h, const float* x, float* recon, float* loss, float weight,
+                     int64_t n, void* ws, size_t ws_bytes, hipStream_t st) {
+  WFAE_REQUIRE(h && x && loss && (mode == 1 || recon), WFAE_ERR_NULL_POINTER, "l1_fwd: null pointer");
+  WFAE_REQUIRE(n > 0, WFAE_ERR_BAD_SHAPE, "l1_fwd: bad size");
+  int blocks = grid_1d(n, 16);
+  if (blocks > 1024) blocks = 1024;
+  WFAE_REQUIRE(ws && ws_bytes >= (size_t)blocks * sizeof(double), WFAE_ERR_WORKSPACE, "l1_fwd: workspace too small");
+  const int vec = ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(x) |
+                    reinterpret_cast<uintptr_t>(recon)) & 15) == 0;
+  if (mode == 0)
+    hipLaunchKernelGGL((l1_fwd_kernel<0>), dim3(blocks), dim3(RT), 0, st, h, x, recon, (double*)ws, (long)n, vec);
+  else
+    hipLaunchKernelGGL((l1_fwd_kernel<1>), dim3(blocks), dim3(RT), 0, st, h, x, recon, (double*)ws, (long)n, vec);
+  int rc = check_launch("l1_fwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, blocks,
+                     (double)weight / (double)n, loss, (double*)nullptr);
+  return check_launch("l1_finalize");
+}
+
+int wfae_sigmoid_l1_fwd(const float* h, const float* x, float* recon, float* loss, float weight, int64_t n,
+                        void* ws, size_t ws_bytes, wfae_stream_t stream) {
+  return l1_common(0, h, x, recon, loss, weight, n, ws, ws_bytes, (hipStream_t)stream);
+}
+int wfae_l1_fwd(const float* recon, const float* x, float* loss, float weight, int64_t n, void* ws,
+                size_t ws_bytes, wfae_stream_t stream) {
+  return l1_common(1, recon, x, nullptr, loss, weight, n, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int wfae_sigmoid_l1_bwd(const float* recon, const float* x, const float* gloss, float weight, float* dh,
+                        int64_t n, wfae_stream_t stream) {
+  WFAE_REQUIRE(recon && x && gloss && dh, WFAE_ERR_NULL_POINTER, "sigmoid_l1_bwd: null pointer");
+  WFAE_REQUIRE(n > 0, WFAE_ERR_BAD_SHAPE, "sigmoid_l1_bwd: bad size");
+  hipLaunchKernelGGL((l1_bwd_kernel<0>), dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, recon, x, gloss,
+                     (float)((double)weight / (double)n), dh, (long)n);
+  return check_launch("sigmoid_l1_bwd");
+}
+int wfae_l1_bwd(const float* recon, const float* x, const float* gloss, float weight, float* drecon, int64_t n,
+                wfae_stream_t stream) {
+  WFAE_REQUIRE(recon && x && gloss && drecon, WFAE_ERR_NULL_POINTER, "l1_bwd: null pointer");
+  WFAE_REQUIRE(n > 0, WFAE_ERR_BAD_SHAPE, "l1_bwd: bad size");
+  hipLaunchKernelGGL((l1_bwd_kernel<1>), dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, recon, x, gloss,
+                     (float)((double)weight / (double)n), drecon, (long)n);
+  return check_launch("l1_bwd");
+}
+
+int wfae_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+               float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale,
+               wfae_stream_t stream) {
+  WFAE_REQUIRE(p && g && m && v, WFAE_ERR_NULL_POINTER, "adamw: null pointer");
+  WFAE_REQUIRE(n >= 0, WFAE_ERR_BAD_SHAPE, "adamw: bad size");
+  if (n == 0) return WFAE_OK;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr,
+                     beta1, beta2, eps, weight_decay, bias_corr1, sqrtf(bias_corr2), grad_scale);
+  return check_launch("adamw");
+}
+
+int wfae_sumsq(const float* x, int64_t n, double* out, void* ws, size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(x && out, WFAE_ERR_NULL_POINTER, "sumsq: null pointer");
+  WFAE_REQUIRE(n > 0, WFAE_ERR_BAD_SHAPE, "sumsq: bad size");
+  int blocks = grid_1d(n, 16);
+  if (blocks > 1024) blocks = 1024;
+  WFAE_REQUIRE(ws && ws_bytes >= (size_t)blocks * sizeof(double), WFAE_ERR_WORKSPACE, "sumsq: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(RT), 0, st, x, (double*)ws, (long)n);
+  int rc = check_launch("sumsq");
+  if (rc) return rc;
+  hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, blocks, 1.0,
+                     (float*)nullptr, out);
+  return check_launch("sumsq_finalize");
+}
+
+int wfae_vil_u8_to_f32(const uint8_t* src, float* dst, int NB, int H, int W, int T, float scale,
+                       wfae_stream_t stream) {
+  WFAE_REQUIRE(src && dst, WFAE_ERR_NULL_POINTER, "vil_u8_to_f32: null pointer");
+  WFAE_REQUIRE(NB > 0 && H > 0 && W > 0 && T > 0, WFAE_ERR_BAD_SHAPE, "vil_u8_to_f32: bad shape");
+  const long total = (long)NB * T * H * W;
+  hipLaunchKernelGGL(vil_u8_to_f32_kernel, dim3(grid_1d(total, 1)), dim3(256), 0, (hipStream_t)stream, src, dst, H,
+                     W, T, scale, total);
+  return check_launch("vil_u8_to_f32");
+}
+
+}  // extern "C"

@@ -1,0 +1,394 @@
+"""autograd glue: torch.autograd.Function wrappers whose forward AND backward are
+sequences of libwfae.so kernel launches (ops.py).  Granularity follows the
+reference's building blocks so that the fan-out of the residual stream stays
+inside one Function (no ATen gradient-accumulation kernels on the hot path):
+
+  DownUnitFn     Conv2d(4,2,1) -> BN -> GELU            EncBlock.down  (ae_64x8x8_lin.py:30-33)
+  UpUnitFn       ConvTranspose2d(4,2,1) -> BN -> GELU   DecBlock.up    (:41-44)
+  BottleneckFn   x + f(x)                               Bottleneck     (:7-22)
+  Conv1x1Fn      1x1 conv (+bias) (+broadcast pos_emb)  enc[4], dec[0] (:69,79,91)
+  LinearFn       to_latent / from_latent                (:74-75)
+  DConvFn        3x3 'same' conv, any groups            dec[5]         (:84)
+  SigmoidFn, L1LossFn, SsimFn                           (:86; experiments/ae_v2/train.py:55,62)
+
+Parameter gradients are written by the kernels straight into the tensor that
+`grad_buffer(p)` returns — a view of a flat gradient arena when an optimiser /
+data-parallel wrapper registered one (so AdamW and the RCCL all-reduce see one
+contiguous buffer), otherwise a fresh tensor — and handed back to autograd,
+which adopts it as `p.grad` without a copy.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+BN_EPS = 1e-5
+
+
+def grad_buffer(p):
+    v = getattr(p, "_wfae_grad_view", None)
+    if v is not None and p.grad is None:
+        return v
+    return torch.empty_like(p)
+
+
+def _bn_stats(x, bn, training):
+    """training: batch statistics + running-stat update; eval: fold running stats."""
+    if training:
+        st = ops.bn_stats_train(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+        bn._nbt_pending += 1
+        return st
+    return ops.bn_fold_eval(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+
+
+def _use_batch_stats(bn):
+    return bn.training or bn.running_mean is None
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------- 4x4 s2 units --
+def _down_fwd(x, w):
+    if w.shape[1] < 16:
+        return ops.dconv_fwd(x, w, None, 4, 2, 1, 1)
+    return ops.conv4x4s2_down(x, w)
+
+
+def _down_wgrad(dlo, hi, dw):
+    if hi.shape[1] < 16:
+        return ops.dconv_bwd_weight(dlo, hi, dw, 4, 2, 1, 1)
+    return ops.conv4x4s2_wgrad(dlo, hi, dw)
+
+
+class DownUnitFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, bn):
+        x = _c(x)
+        training = _use_batch_stats(bn)
+        t = _down_fwd(x, w)
+        st = _bn_stats(t, bn, training)
+        a = ops.bn_act_fwd(t, st, 1)
+        ctx.save_for_backward(x, w, gamma, t, st.mean, st.invstd, st.scale, st.shift)
+        ctx.training = training
+        ctx.beta = beta
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x, w, gamma, t, mean, invstd, scale, shift = ctx.saved_tensors
+        st = ops.BnStats.__new__(ops.BnStats)
+        st.mean, st.invstd, st.scale, st.shift = mean, invstd, scale, shift
+        dg, db = grad_buffer(gamma), grad_buffer(ctx.beta)
+        dt = ops.bn_act_bwd(_c(da), t, gamma, st, dg, db, None, 1, ctx.training)
+        dw = grad_buffer(w)
+        _down_wgrad(dt, x, dw)
+        dx = ops.conv4x4s2_up(dt, w) if ctx.needs_input_grad[0] else None
+        return dx, dw, dg, db, None
+
+
+class UpUnitFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, bn):
+        x = _c(x)
+        training = _use_batch_stats(bn)
+        t = ops.conv4x4s2_up(x, w)
+        st = _bn_stats(t, bn, training)
+        a = ops.bn_act_fwd(t, st, 1)
+        ctx.save_for_backward(x, w, gamma, t, st.mean, st.invstd, st.scale, st.shift)
+        ctx.training = training
+        ctx.beta = beta
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x, w, gamma, t, mean, invstd, scale, shift = ctx.saved_tensors
+        st = ops.BnStats.__new__(ops.BnStats)
+        st.mean, st.invstd, st.scale, st.shift = mean, invstd, scale, shift
+        dg, db = grad_buffer(gamma), grad_buffer(ctx.beta)
+        dt = ops.bn_act_bwd(_c(da), t, gamma, st, dg, db, None, 1, ctx.training)
+        dw = grad_buffer(w)
+        ops.conv4x4s2_wgrad(x, dt, dw)  # lo = x, hi = dt
+        dx = ops.conv4x4s2_down(dt, w) if ctx.needs_input_grad[0] else None
+        return dx, dw, dg, db, None
+
+
+# -------------------------------------------------------------- Bottleneck --
+def _mk_stats(mean, invstd, scale, shift):
+    st = ops.BnStats.__new__(ops.BnStats)
+    st.mean, st.invstd, st.scale, st.shift = mean, invstd, scale, shift
+    return st
+
+
+class BottleneckFn(Function):
+    @staticmethod
+    def forward(ctx, x, g1, b1, w1, g2, b2, wg, g3, b3, w3, mod):
+        x = _c(x)
+        bn1, bn2, bn3 = mod.f[0], mod.f[3], mod.f[6]
+        groups = mod.f[5].groups
+        training = _use_batch_stats(bn1)
+        st1 = _bn_stats(x, bn1, training)
+        a1 = ops.bn_act_fwd(x, st1, 1)
+        t1 = ops.conv1x1_fwd(a1, w1)
+        st2 = _bn_stats(t1, bn2, training)
+        a2 = ops.bn_act_fwd(t1, st2, 1)
+        t2 = ops.dconv_fwd(a2, wg, None, 3, 1, 1, groups)
+        st3 = _bn_stats(t2, bn3, training)
+        a3 = ops.bn_act_fwd(t2, st3, 1)
+        y = ops.conv1x1_fwd(a3, w3, None, x)
+        ctx.save_for_backward(x, a1, t1, a2, t2, a3, g1, w1, g2, wg, g3, w3,
+                              st1.mean, st1.invstd, st1.scale, st1.shift,
+                              st2.mean, st2.invstd, st2.scale, st2.shift,
+                              st3.mean, st3.invstd, st3.scale, st3.shift)
+        ctx.training = training
+        ctx.groups = groups
+        ctx.betas = (b1, b2, b3)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x, a1, t1, a2, t2, a3, g1, w1, g2, wg, g3, w3, *s) = ctx.saved_tensors
+        st1, st2, st3 = _mk_stats(*s[0:4]), _mk_stats(*s[4:8]), _mk_stats(*s[8:12])
+        tr = ctx.training
+        dy = _c(dy)
+        mid = w1.shape[0]
+        dw3 = grad_buffer(w3)
+        ops.conv1x1_bwd_weight(dy, a3, dw3)
+        da3 = ops.conv1x1_bwd_data(dy, w3)
+        dg3, db3 = grad_buffer(g3), grad_buffer(ctx.betas[2])
+        dt2 = ops.bn_act_bwd(da3, t2, g3, st3, dg3, db3, None, 1, tr)
+        del da3
+        dwg = grad_buffer(wg)
+        ops.dconv_bwd_weight(dt2, a2, dwg, 3, 1, 1, ctx.groups)
+        da2 = ops.dconv_bwd_data(dt2, wg, mid, 3, 1, ctx.groups)
+        del dt2
+        dg2, db2 = grad_buffer(g2), grad_buffer(ctx.betas[1])
+        dt1 = ops.bn_act_bwd(da2, t1, g2, st2, dg2, db2, None, 1, tr)
+        del da2
+        dw1 = grad_buffer(w1)
+        ops.conv1x1_bwd_weight(dt1, a1, dw1)
+        da1 = ops.conv1x1_bwd_data(dt1, w1)
+        del dt1
+        dg1, db1 = grad_buffer(g1), grad_buffer(ctx.betas[0])
+        dx = ops.bn_act_bwd(da1, x, g1, st1, dg1, db1, dy, 1, tr)
+        return dx, dg1, db1, dw1, dg2, db2, dwg, dg3, db3, dw3, None
+
+
+# ------------------------------------------------------------ leaf layers --
+class Conv1x1Fn(Function):
+    """y = conv1x1(x, w) + bias (+ pos broadcast over the batch)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, pos):
+        x = _c(x)
+        y = ops.conv1x1_fwd(x, w, bias, None if pos is None else _c(pos), pos is not None)
+        ctx.save_for_backward(x, w)
+        ctx.bias, ctx.pos = bias, pos
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        nb, cout, h, wd = dy.shape
+        dw = grad_buffer(w)
+        ops.conv1x1_bwd_weight(dy, x, dw)
+        dx = ops.conv1x1_bwd_data(dy, w) if ctx.needs_input_grad[0] else None
+        dbias = dpos = None
+        if ctx.bias is not None:
+            dbias = grad_buffer(ctx.bias)
+            ops.reduce_sum(dy, nb, cout, h * wd, dbias)
+        if ctx.pos is not None:
+            dpos = grad_buffer(ctx.pos)
+            ops.reduce_sum(dy, nb, cout * h * wd, 1, dpos)
+        return dx, dw, dbias, dpos
+
+
+def conv1x1(x, w, bias=None, pos=None):
+    return Conv1x1Fn.apply(x, w, bias, pos)
+
+
+class LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x = _c(x)
+        y = ops.linear_fwd(x, w, bias)
+        ctx.save_for_backward(x, w)
+        ctx.bias = bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        dw = grad_buffer(w)
+        ops.linear_bwd_weight(dy, x, dw)
+        dx = ops.linear_bwd_data(dy, w) if ctx.needs_input_grad[0] else None
+        dbias = None
+        if ctx.bias is not None:
+            dbias = grad_buffer(ctx.bias)
+            ops.reduce_sum(dy, dy.shape[0], w.shape[0], 1, dbias)
+        return dx, dw, dbias
+
+
+class DConvFn(Function):
+    """3x3 'same' stride-1 convolution with any group count (direct kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, groups):
+        x = _c(x)
+        y = ops.dconv_fwd(x, w, bias, 3, 1, 1, groups)
+        ctx.save_for_backward(x, w)
+        ctx.groups = groups
+        ctx.bias = bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        dw = grad_buffer(w)
+        ops.dconv_bwd_weight(dy, x, dw, 3, 1, 1, ctx.groups)
+        dx = ops.dconv_bwd_data(dy, w, x.shape[1], 3, 1, ctx.groups) if ctx.needs_input_grad[0] else None
+        dbias = None
+        if ctx.bias is not None:
+            nb, cout, h, wd = dy.shape
+            dbias = grad_buffer(ctx.bias)
+            ops.reduce_sum(dy, nb, cout, h * wd, dbias)
+        return dx, dw, dbias, None
+
+
+class Conv4x4DownFn(Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x = _c(x)
+        ctx.save_for_backward(x, w)
+        return _down_fwd(x, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        dw = grad_buffer(w)
+        _down_wgrad(dy, x, dw)
+        dx = ops.conv4x4s2_up(dy, w) if ctx.needs_input_grad[0] else None
+        return dx, dw
+
+
+class ConvT4x4UpFn(Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x = _c(x)
+        ctx.save_for_backward(x, w)
+        return ops.conv4x4s2_up(x, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        dw = grad_buffer(w)
+        ops.conv4x4s2_wgrad(x, dy, dw)
+        dx = ops.conv4x4s2_down(dy, w) if ctx.needs_input_grad[0] else None
+        return dx, dw
+
+
+class BatchNormActFn(Function):
+    """BatchNorm2d (+ optional fused GELU) as a standalone layer."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, act):
+        x = _c(x)
+        training = _use_batch_stats(bn)
+        st = _bn_stats(x, bn, training)
+        y = ops.bn_act_fwd(x, st, act)
+        ctx.save_for_backward(x, gamma, st.mean, st.invstd, st.scale, st.shift)
+        ctx.training, ctx.act, ctx.beta = training, act, beta
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, *s = ctx.saved_tensors
+        st = _mk_stats(*s)
+        dg, db = grad_buffer(gamma), grad_buffer(ctx.beta)
+        dx = ops.bn_act_bwd(_c(dy), x, gamma, st, dg, db, None, ctx.act, ctx.training,
+                            need_dx=ctx.needs_input_grad[0])
+        return dx, dg, db, None, None
+
+
+class GeluFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        return ops.gelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.gelu_bwd(_c(dy), x)
+
+
+class SigmoidFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.sigmoid_fwd(_c(x))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.sigmoid_bwd(_c(dy), y)
+
+
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add(_c(a), _c(b))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+# ------------------------------------------------------------------- losses --
+class L1LossFn(Function):
+    """weight * mean |recon - x|  (F.l1_loss, experiments/ae_v2/train.py:55)."""
+
+    @staticmethod
+    def forward(ctx, recon, x, weight):
+        recon, x = _c(recon), _c(x)
+        ctx.save_for_backward(recon, x)
+        ctx.weight = float(weight)
+        return ops.l1_fwd(recon, x, ctx.weight)
+
+    @staticmethod
+    def backward(ctx, g):
+        recon, x = ctx.saved_tensors
+        return ops.l1_bwd(recon, x, _c(g), ctx.weight), None, None
+
+
+class SsimFn(Function):
+    """pytorch_msssim.ssim(X, Y, data_range=1): gradient flows to Y (train.py:62)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = _c(x), _c(y)
+        ctx.save_for_backward(x, y)
+        return ops.ssim_fwd(x, y, False)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        return None, ops.ssim_bwd(x, y, _c(g))
+
+
+def l1_loss(recon, x, weight=1.0):
+    return L1LossFn.apply(recon, x, weight)
+
+
+def ssim(x, y):
+    return SsimFn.apply(x, y)

@@ -1,0 +1,95 @@
+"""Layer classes with the reference's constructor signatures and state_dict
+keys (they subclass the torch.nn containers for parameter registration and
+default initialisation only — SURVEY.md Appendix B.9); every forward/backward
+runs on libwfae.so kernels through functional.py.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as tnn
+
+from . import functional as Fn
+from ._lib import WfaeError
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+class Conv2d(tnn.Conv2d):
+    """nn.Conv2d restricted to the three geometries the hot path uses:
+    1x1 (ae_64x8x8_lin.py:15,19,69,79), 4x4 s2 p1 (:31), 3x3 s1 p1 any groups (:17,84)."""
+
+    def forward(self, x):
+        k, s, p = _pair(self.kernel_size), _pair(self.stride), _pair(self.padding)
+        if k == (1, 1) and s == (1, 1) and p == (0, 0) and self.groups == 1:
+            return Fn.Conv1x1Fn.apply(x, self.weight, self.bias, None)
+        if k == (3, 3) and s == (1, 1) and p == (1, 1):
+            return Fn.DConvFn.apply(x, self.weight, self.bias, self.groups)
+        if k == (4, 4) and s == (2, 2) and p == (1, 1) and self.groups == 1 and self.bias is None:
+            return Fn.Conv4x4DownFn.apply(x, self.weight)
+        raise WfaeError(f"Conv2d geometry k={k} s={s} p={p} g={self.groups} bias={self.bias is not None} "
+                        "has no gfx950 kernel in this build")
+
+
+class ConvTranspose2d(tnn.ConvTranspose2d):
+    """nn.ConvTranspose2d(Cin, Cout, 4, stride=2, padding=1, bias=False) (ae_64x8x8_lin.py:42)."""
+
+    def forward(self, x, output_size=None):
+        k, s, p = _pair(self.kernel_size), _pair(self.stride), _pair(self.padding)
+        if k == (4, 4) and s == (2, 2) and p == (1, 1) and self.groups == 1 and self.bias is None \
+                and _pair(self.output_padding) == (0, 0):
+            return Fn.ConvT4x4UpFn.apply(x, self.weight)
+        raise WfaeError("ConvTranspose2d geometry has no gfx950 kernel in this build")
+
+
+class BatchNorm2d(tnn.BatchNorm2d):
+    """nn.BatchNorm2d(eps=1e-5, momentum=0.1).  num_batches_tracked is counted on
+    the host and materialised into the buffer when the state_dict is read."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._nbt_pending = 0
+        if self.momentum is None or not self.affine or not self.track_running_stats:
+            raise WfaeError("BatchNorm2d: only affine, running-stat, fixed-momentum BN is built")
+
+    def flush(self):
+        if self._nbt_pending:
+            self.num_batches_tracked += self._nbt_pending
+            self._nbt_pending = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.flush()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *a, **kw):
+        self._nbt_pending = 0
+        super()._load_from_state_dict(*a, **kw)
+
+    def forward(self, x, act=0):
+        return Fn.BatchNormActFn.apply(x, self.weight, self.bias, self, act)
+
+
+class GELU(tnn.GELU):
+    def forward(self, x):
+        if self.approximate != "none":
+            raise WfaeError("only exact (erf) GELU is built")
+        return Fn.GeluFn.apply(x)
+
+
+class Sigmoid(tnn.Sigmoid):
+    def forward(self, x):
+        return Fn.SigmoidFn.apply(x)
+
+
+class Linear(tnn.Linear):
+    def forward(self, x):
+        shp = x.shape
+        y = Fn.LinearFn.apply(x.reshape(-1, shp[-1]), self.weight, self.bias)
+        return y.view(*shp[:-1], self.out_features)
+
+
+def flush_bn_counters(module: torch.nn.Module):
+    for m in module.modules():
+        if isinstance(m, BatchNorm2d):
+            m.flush()

@@ -1,0 +1,344 @@
+"""Tensor-level launch wrappers over the libwfae.so C ABI (no autograd here).
+
+torch is used for device memory, the current HIP stream and nothing else:
+every arithmetic operation below is a hand-written gfx950 kernel reached
+through ctypes.  All tensors must be CUDA(HIP) fp32 and contiguous (NCHW).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import _lib
+
+_WS_DEFAULT = int(os.environ.get("WFAE_WORKSPACE_MB", "512")) << 20
+_ws = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(min_bytes: int = 0):
+    """Per-(device, stream) scratch buffer handed to kernels that need one."""
+    dev = torch.cuda.current_device()
+    key = (dev, _stream())
+    need = max(_WS_DEFAULT, int(min_bytes))
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(need, dtype=torch.uint8, device=f"cuda:{dev}")
+        _ws[key] = buf
+    return buf
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.WfaeError("wfae kernels need device tensors (the HIP path has no CPU fallback)")
+        if t.dtype != torch.float32:
+            raise _lib.WfaeError(f"wfae kernels are fp32, got {t.dtype}")
+        if not t.is_contiguous():
+            raise _lib.WfaeError("wfae kernels need contiguous NCHW tensors")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+# ----------------------------------------------------------------- 1x1 conv
+def conv1x1_fwd(x, w, bias=None, res=None, res_broadcast=False):
+    _chk(x, w, bias, res)
+    nb, cin, h, wd = x.shape
+    cout = w.shape[0]
+    y = torch.empty((nb, cout, h, wd), dtype=x.dtype, device=x.device)
+    stride = 0 if res_broadcast else cout * h * wd
+    _lib.call("wfae_conv1x1_fwd", _p(x), _p(w), _p(bias), _p(res), stride, _p(y), nb, cin, cout, h * wd, _stream())
+    return y
+
+
+def conv1x1_bwd_data(dy, w):
+    _chk(dy, w)
+    nb, cout, h, wd = dy.shape
+    cin = w.shape[1]
+    dx = torch.empty((nb, cin, h, wd), dtype=dy.dtype, device=dy.device)
+    _lib.call("wfae_conv1x1_bwd_data", _p(dy), _p(w), _p(dx), nb, cin, cout, h * wd, _stream())
+    return dx
+
+
+def conv1x1_bwd_weight(dy, x, dw, accumulate=False):
+    _chk(dy, x, dw)
+    nb, cout, h, wd = dy.shape
+    cin = x.shape[1]
+    ws = workspace()
+    _lib.call("wfae_conv1x1_bwd_weight", _p(dy), _p(x), _p(dw), nb, cin, cout, h * wd, int(accumulate),
+              ws.data_ptr(), ws.numel(), _stream())
+    return dw
+
+
+# ------------------------------------------------------------------- linear
+def linear_fwd(x, w, bias=None):
+    _chk(x, w, bias)
+    b, inf = x.shape
+    out = w.shape[0]
+    y = torch.empty((b, out), dtype=x.dtype, device=x.device)
+    ws = workspace()
+    _lib.call("wfae_linear_fwd", _p(x), _p(w), _p(bias), _p(y), b, inf, out, ws.data_ptr(), ws.numel(), _stream())
+    return y
+
+
+def linear_bwd_data(dy, w):
+    _chk(dy, w)
+    b, out = dy.shape
+    inf = w.shape[1]
+    dx = torch.empty((b, inf), dtype=dy.dtype, device=dy.device)
+    _lib.call("wfae_linear_bwd_data", _p(dy), _p(w), _p(dx), b, inf, out, _stream())
+    return dx
+
+
+def linear_bwd_weight(dy, x, dw, accumulate=False):
+    _chk(dy, x, dw)
+    b, out = dy.shape
+    inf = x.shape[1]
+    _lib.call("wfae_linear_bwd_weight", _p(dy), _p(x), _p(dw), b, inf, out, int(accumulate), _stream())
+    return dw
+
+
+# ------------------------------------------------------ 4x4 stride-2 family
+def conv4x4s2_down(hi, w):
+    """hi (N,Chi,2H,2W), w (Clo,Chi,4,4) -> lo (N,Clo,H,W)"""
+    _chk(hi, w)
+    nb, chi, h2, w2 = hi.shape
+    clo = w.shape[0]
+    hlo, wlo = h2 // 2, w2 // 2
+    lo = torch.empty((nb, clo, hlo, wlo), dtype=hi.dtype, device=hi.device)
+    _lib.call("wfae_conv4x4s2_down", _p(hi), _p(w), _p(lo), nb, chi, clo, hlo, wlo, _stream())
+    return lo
+
+
+def conv4x4s2_up(lo, w):
+    """lo (N,Clo,H,W), w (Clo,Chi,4,4) -> hi (N,Chi,2H,2W)"""
+    _chk(lo, w)
+    nb, clo, hlo, wlo = lo.shape
+    chi = w.shape[1]
+    hi = torch.empty((nb, chi, 2 * hlo, 2 * wlo), dtype=lo.dtype, device=lo.device)
+    ws = workspace(w.numel() * 4)
+    _lib.call("wfae_conv4x4s2_up", _p(lo), _p(w), _p(hi), nb, chi, clo, hlo, wlo, ws.data_ptr(), ws.numel(), _stream())
+    return hi
+
+
+def conv4x4s2_wgrad(lo, hi, dw, accumulate=False):
+    _chk(lo, hi, dw)
+    nb, clo, hlo, wlo = lo.shape
+    chi = hi.shape[1]
+    ws = workspace(dw.numel() * 4 * 2)
+    _lib.call("wfae_conv4x4s2_wgrad", _p(lo), _p(hi), _p(dw), nb, chi, clo, hlo, wlo, int(accumulate),
+              ws.data_ptr(), ws.numel(), _stream())
+    return dw
+
+
+# ------------------------------------------------------------- direct convs
+def dconv_fwd(x, w, bias, ks, stride, pad, groups):
+    _chk(x, w, bias)
+    nb, cin, h, wd = x.shape
+    cout = w.shape[0]
+    ho = (h + 2 * pad - ks) // stride + 1
+    wo = (wd + 2 * pad - ks) // stride + 1
+    y = torch.empty((nb, cout, ho, wo), dtype=x.dtype, device=x.device)
+    _lib.call("wfae_dconv_fwd", _p(x), _p(w), _p(bias), _p(y), nb, cin, cout, h, wd, ks, stride, pad, groups, _stream())
+    return y
+
+
+def dconv_bwd_data(dy, w, cin, ks, pad, groups):
+    _chk(dy, w)
+    nb, cout, h, wd = dy.shape
+    dx = torch.empty((nb, cin, h, wd), dtype=dy.dtype, device=dy.device)
+    _lib.call("wfae_dconv_bwd_data", _p(dy), _p(w), _p(dx), nb, cin, cout, h, wd, ks, pad, groups, _stream())
+    return dx
+
+
+def dconv_bwd_weight(dy, x, dw, ks, stride, pad, groups, accumulate=False):
+    _chk(dy, x, dw)
+    nb, cin, h, wd = x.shape
+    cout = dy.shape[1]
+    ws = workspace()
+    _lib.call("wfae_dconv_bwd_weight", _p(dy), _p(x), _p(dw), nb, cin, cout, h, wd, ks, stride, pad, groups,
+              int(accumulate), ws.data_ptr(), ws.numel(), _stream())
+    return dw
+
+
+# ---------------------------------------------------------------- BatchNorm
+class BnStats:
+    """per-channel vectors produced by the statistics kernels"""
+    __slots__ = ("mean", "invstd", "scale", "shift")
+
+    def __init__(self, c, device):
+        buf = torch.empty((4, c), dtype=torch.float32, device=device)
+        self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
+
+
+def bn_stats_train(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
+    _chk(x, gamma, beta, running_mean, running_var)
+    nb, c, h, wd = x.shape
+    st = BnStats(c, x.device)
+    ws = workspace()
+    _lib.call("wfae_bn_stats_train", _p(x), nb, c, h * wd, _p(gamma), _p(beta), eps, momentum, _p(running_mean),
+              _p(running_var), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift), ws.data_ptr(), ws.numel(),
+              _stream())
+    return st
+
+
+def bn_fold_eval(gamma, beta, running_mean, running_var, eps=1e-5):
+    _chk(gamma, beta, running_mean, running_var)
+    c = gamma.shape[0]
+    st = BnStats(c, gamma.device)
+    _lib.call("wfae_bn_fold_eval", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(st.mean),
+              _p(st.invstd), _p(st.scale), _p(st.shift), c, _stream())
+    return st
+
+
+def bn_act_fwd(x, st, act=1):
+    _chk(x)
+    nb, c, h, wd = x.shape
+    y = torch.empty_like(x)
+    _lib.call("wfae_bn_act_fwd", _p(x), _p(st.scale), _p(st.shift), _p(y), nb, c, h * wd, act, _stream())
+    return y
+
+
+def bn_act_bwd(dy, x, gamma, st, dgamma, dbeta, res=None, act=1, training=True, accumulate=False, need_dx=True):
+    _chk(dy, x, gamma, res, dgamma, dbeta)
+    nb, c, h, wd = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    ws = workspace()
+    _lib.call("wfae_bn_act_bwd", _p(dy), _p(x), _p(gamma), _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd),
+              _p(res), _p(dx), _p(dgamma), _p(dbeta), nb, c, h * wd, act, int(training), int(accumulate),
+              ws.data_ptr(), ws.numel(), _stream())
+    return dx
+
+
+# ------------------------------------------------------------- element-wise
+def _ew(name, a, b=None):
+    _chk(a, b)
+    out = torch.empty_like(a)
+    if b is None:
+        _lib.call(name, _p(a), _p(out), a.numel(), _stream())
+    else:
+        _lib.call(name, _p(a), _p(b), _p(out), a.numel(), _stream())
+    return out
+
+
+def gelu_fwd(x):
+    return _ew("wfae_gelu_fwd", x)
+
+
+def gelu_bwd(dy, x):
+    return _ew("wfae_gelu_bwd", dy, x)
+
+
+def sigmoid_fwd(x):
+    return _ew("wfae_sigmoid_fwd", x)
+
+
+def sigmoid_bwd(dy, y):
+    return _ew("wfae_sigmoid_bwd", dy, y)
+
+
+def add(a, b):
+    return _ew("wfae_add", a, b)
+
+
+def reduce_sum(x, outer, c, inner, out, accumulate=False):
+    _chk(x, out)
+    ws = workspace()
+    _lib.call("wfae_reduce_sum", _p(x), outer, c, inner, _p(out), int(accumulate), ws.data_ptr(), ws.numel(), _stream())
+    return out
+
+
+# --------------------------------------------------------------------- loss
+def sigmoid_l1_fwd(h, x, weight=1.0):
+    _chk(h, x)
+    recon = torch.empty_like(h)
+    loss = torch.empty((), dtype=torch.float32, device=h.device)
+    ws = workspace()
+    _lib.call("wfae_sigmoid_l1_fwd", _p(h), _p(x), _p(recon), _p(loss), weight, h.numel(), ws.data_ptr(), ws.numel(),
+              _stream())
+    return recon, loss
+
+
+def sigmoid_l1_bwd(recon, x, gloss, weight=1.0):
+    _chk(recon, x, gloss)
+    dh = torch.empty_like(recon)
+    _lib.call("wfae_sigmoid_l1_bwd", _p(recon), _p(x), _p(gloss), weight, _p(dh), recon.numel(), _stream())
+    return dh
+
+
+def l1_fwd(recon, x, weight=1.0):
+    _chk(recon, x)
+    loss = torch.empty((), dtype=torch.float32, device=recon.device)
+    ws = workspace()
+    _lib.call("wfae_l1_fwd", _p(recon), _p(x), _p(loss), weight, recon.numel(), ws.data_ptr(), ws.numel(), _stream())
+    return loss
+
+
+def l1_bwd(recon, x, gloss, weight=1.0):
+    _chk(recon, x, gloss)
+    d = torch.empty_like(recon)
+    _lib.call("wfae_l1_bwd", _p(recon), _p(x), _p(gloss), weight, _p(d), recon.numel(), _stream())
+    return d
+
+
+def ssim_fwd(x, y, clamp01=False):
+    _chk(x, y)
+    nb = x.shape[0] * x.shape[1]
+    h, wd = x.shape[-2:]
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    ws = workspace()
+    _lib.call("wfae_ssim_fwd", _p(x), _p(y), _p(out), nb, h, wd, int(clamp01), ws.data_ptr(), ws.numel(), _stream())
+    return out
+
+
+def ssim_bwd(x, y, gout):
+    _chk(x, y, gout)
+    nb = x.shape[0] * x.shape[1]
+    h, wd = x.shape[-2:]
+    dy = torch.empty_like(y)
+    ws = workspace(3 * nb * (h - 10) * (wd - 10) * 4)
+    _lib.call("wfae_ssim_bwd", _p(x), _p(y), _p(gout), _p(dy), nb, h, wd, ws.data_ptr(), ws.numel(), _stream())
+    return dy
+
+
+def psnr(pred, target, clamp01=False):
+    _chk(pred, target)
+    nb = pred.shape[0]
+    hw = pred.numel() // nb
+    out = torch.empty((), dtype=torch.float32, device=pred.device)
+    ws = workspace()
+    _lib.call("wfae_psnr", _p(pred), _p(target), _p(out), nb, hw, int(clamp01), ws.data_ptr(), ws.numel(), _stream())
+    return out
+
+
+# ---------------------------------------------------------------- optimiser
+def adamw_(p, g, m, v, lr, beta1, beta2, eps, wd, bc1, bc2, grad_scale=1.0):
+    _chk(p, g, m, v)
+    _lib.call("wfae_adamw", _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, bc1, bc2, grad_scale,
+              _stream())
+
+
+def sumsq(x):
+    _chk(x)
+    out = torch.empty((), dtype=torch.float64, device=x.device)
+    ws = workspace()
+    _lib.call("wfae_sumsq", _p(x), x.numel(), _p(out), ws.data_ptr(), ws.numel(), _stream())
+    return out
+
+
+def vil_u8_to_f32(src_nhwt, scale=1.0 / 255.0):
+    """uint8 (N,H,W,T) -> fp32 (N,T,H,W) * scale: the loader contract on device."""
+    if src_nhwt.dtype != torch.uint8 or not src_nhwt.is_cuda or not src_nhwt.is_contiguous():
+        raise _lib.WfaeError("vil_u8_to_f32 needs a contiguous uint8 device tensor")
+    n, h, w, t = src_nhwt.shape
+    dst = torch.empty((n, t, h, w), dtype=torch.float32, device=src_nhwt.device)
+    _lib.call("wfae_vil_u8_to_f32", src_nhwt.data_ptr(), _p(dst), n, h, w, t, scale, _stream())
+    return dst

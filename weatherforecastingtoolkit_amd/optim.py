@@ -1,0 +1,171 @@
+"""Fused AdamW over flat parameter / gradient / moment arenas, and the
+LinearLR -> CosineAnnealingLR schedule of the reference in closed form.
+
+Reference semantics: torch.optim.AdamW built by adamw_optimizer
+(pipeline/helpers.py:63-74) and SequentialLR[LinearLR, CosineAnnealingLR]
+built by cosine_warmup_scheduler (pipeline/helpers.py:76-107), stepped once
+per optimiser step (experiments/ae_v2/train.py:254-261).
+
+MI355X design: all parameters of a group live in ONE contiguous fp32 buffer
+(parameters become views), gradients are produced by the backward kernels
+directly inside a second contiguous buffer (functional.grad_buffer), so the
+optimiser step is one kernel launch and the data-parallel gradient exchange is
+an RCCL all-reduce on one buffer (parallel.py).
+"""
+from __future__ import annotations
+
+import bisect
+import math
+
+import torch
+
+from . import ops
+
+
+class FlatArena:
+    """Contiguous storage for a list of parameters, their grads and AdamW moments."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        dev = self.params[0].device
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4  # keep every view 16-byte aligned
+        self.numel = off
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            self.flat_p[o:o + n].view_as(p).copy_(p.data)
+            p.data = self.flat_p[o:o + n].view_as(p)
+            p._wfae_grad_view = self.flat_g[o:o + n].view_as(p)
+
+    def grads_in_arena(self):
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != p._wfae_grad_view.data_ptr():
+                return False
+        return True
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (eps 1e-8, decoupled weight decay, no amsgrad),
+    one wfae_adamw launch per parameter group when all gradients sit in the arena."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, flatten=True):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.grad_scale = 1.0  # set to 1/world_size by the data-parallel wrapper
+        self._arenas = []
+        for g in self.param_groups:
+            ps = [p for p in g["params"] if p.requires_grad]
+            g["step"] = 0
+            if flatten and ps and ps[0].is_cuda:
+                arena = FlatArena(ps)
+                arena.m = torch.zeros_like(arena.flat_p)
+                arena.v = torch.zeros_like(arena.flat_p)
+            else:
+                arena = None
+            self._arenas.append(arena)
+
+    @property
+    def arenas(self):
+        return [a for a in self._arenas if a is not None]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for g, arena in zip(self.param_groups, self._arenas):
+            g["step"] += 1
+            t = g["step"]
+            b1, b2 = g["betas"]
+            bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+            args = (g["lr"], b1, b2, g["eps"], g["weight_decay"], bc1, bc2, self.grad_scale)
+            if arena is not None and arena.grads_in_arena():
+                ops.adamw_(arena.flat_p, arena.flat_g, arena.m, arena.v, *args)
+                continue
+            for i, p in enumerate(g["params"]):
+                if p.grad is None:
+                    continue
+                if arena is not None:
+                    o, n = arena.offsets[i], p.numel()
+                    m, v = arena.m[o:o + n], arena.v[o:o + n]
+                    pd = arena.flat_p[o:o + n]
+                else:
+                    st = self.state[p]
+                    if not st:
+                        st["m"], st["v"] = torch.zeros_like(p).view(-1), torch.zeros_like(p).view(-1)
+                    m, v, pd = st["m"], st["v"], p.data.view(-1)
+                ops.adamw_(pd, p.grad.contiguous().view(-1), m, v, *args)
+        return loss
+
+
+# ------------------------------------------------------------------ schedule
+class CosineWarmupLR:
+    """Closed form of SequentialLR([LinearLR(start_factor=start/peak, total_iters=warmup),
+    CosineAnnealingLR(T_max=total-warmup, eta_min=final)], milestones=[warmup]).
+
+    Reproduces torch's behaviour for NON-integer `warmup_steps` too
+    (experiments/ae_v2/train.py:258 passes warmup_ratio*total_steps unrounded):
+    the cosine phase is then entered through torch's chained form starting from
+    whatever the linear ramp reached at the last integer step below the milestone."""
+
+    def __init__(self, opt, start_lr, final_lr, peak_lr, total_steps, warmup_steps):
+        self.opt = opt
+        self.start_lr, self.final_lr, self.peak_lr = float(start_lr), float(final_lr), float(peak_lr)
+        self.total_steps, self.warmup_steps = total_steps, warmup_steps
+        self.last_epoch = 0
+        for g in opt.param_groups:
+            g["initial_lr"] = self.peak_lr
+        self._apply()
+
+    def lr_at(self, e):
+        return cosine_warmup_lr(e, self.start_lr, self.peak_lr, self.final_lr, self.total_steps, self.warmup_steps)
+
+    def _apply(self):
+        lr = self.lr_at(self.last_epoch)
+        for g in self.opt.param_groups:
+            g["lr"] = lr
+        self._last_lr = [lr for _ in self.opt.param_groups]
+
+    def step(self):
+        self.last_epoch += 1
+        self._apply()
+
+    def get_last_lr(self):
+        return self._last_lr
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch}
+
+    def load_state_dict(self, sd):
+        self.last_epoch = sd["last_epoch"]
+        self._apply()
+
+
+def cosine_warmup_lr(e, start_lr, peak_lr, final_lr, total_steps, warmup_steps):
+    sf = start_lr / peak_lr
+
+    def linear(k):
+        if warmup_steps <= 0:
+            return peak_lr
+        return peak_lr * (sf + (1.0 - sf) * min(k, warmup_steps) / warmup_steps)
+
+    if bisect.bisect_right([warmup_steps], e) == 0:
+        return linear(e)
+    t_max = total_steps - warmup_steps
+    if float(warmup_steps).is_integer():
+        # milestone hit exactly: SequentialLR calls cosine.step(0) -> closed form from peak_lr
+        t = e - int(warmup_steps)
+        return final_lr + (peak_lr - final_lr) * (1.0 + math.cos(math.pi * t / t_max)) / 2.0
+    # milestone skipped: the cosine scheduler is entered through its chained
+    # (recursive) form with last_epoch = 0 at e = floor(warmup)+1, starting from the
+    # LR the linear ramp left behind; the product of its per-step ratios telescopes to
+    #   (1 + cos(pi t / T)) / (1 + cos(pi (-1) / T)).
+    first = math.floor(warmup_steps) + 1
+    t, lr0 = e - first, linear(first - 1)
+    return final_lr + (lr0 - final_lr) * (1.0 + math.cos(math.pi * t / t_max)) / (1.0 + math.cos(math.pi / t_max))

@@ -1,0 +1,197 @@
+"""bench.py — SEVIR 384x384 frames/sec of the conv-AE train step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + L1 loss + backward + (gradient all-reduce) + AdamW + LR
+schedule of ae_64x8x8_lin.PosAwareAE_TF(img_size=384) on a batch of 32
+synthetic SEVIR-shaped frames per GPU (BASELINE.json configs[1]; weak scaling:
+global batch 32*N).  Frames are generated on the device before the timed
+region.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      the dominant kernel family of the step, timed live with events
+                on the launch stream around each of its launches inside the
+                timed region; achieved = algorithmic FLOPs / that time.
+  step_roofline whole-step fractions per SURVEY.md §8(d):
+                fp32_fraction = 938.8 GFLOP/frame * fps / 157.3 TFLOP/s,
+                hbm_fraction  = 7.365 GB/frame * fps / 8 TB/s.
+  cpu_baseline  the oracle (CPU restatement of the reference path, kind "port")
+                timed on this box's host cores on a bounded sample: one full
+                train step at 384x384, batch 1 (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOPS_PER_FRAME_384 = 938.8e9   # fwd+bwd, SURVEY.md §8(d)
+BYTES_PER_FRAME_384 = 7.365e9   # fused-minimum HBM traffic, SURVEY.md §8(d)
+PEAK_FP32 = 157.3e12            # MI355X_MICROARCH.md: fp32 vector = fp32 matrix
+PEAK_HBM = 8.0e12
+
+KERNEL_OF = {
+    "wfae_conv4x4s2_up": "gemm_kernel<B_UP> (ConvTranspose2d fwd / Conv2d dgrad, fp32 MFMA implicit GEMM)",
+    "wfae_conv4x4s2_down": "gemm_kernel<B_DOWN> (Conv2d fwd / ConvTranspose2d dgrad, fp32 MFMA implicit GEMM)",
+    "wfae_conv4x4s2_wgrad": "gemm_kernel<B_WGRAD> (4x4 s2 weight gradient, fp32 MFMA implicit GEMM, split-K)",
+    "wfae_conv1x1_fwd": "gemm_kernel<A_KCONTIG,B_NCONTIG> (1x1 conv fwd, fp32 MFMA)",
+    "wfae_conv1x1_bwd_data": "gemm_kernel<A_MCONTIG,B_NCONTIG> (1x1 conv dgrad, fp32 MFMA)",
+    "wfae_conv1x1_bwd_weight": "gemm_kernel<A_KCONTIG,B_KCONTIG> (1x1 conv wgrad, fp32 MFMA, split-K)",
+}
+
+
+def cpu_baseline(img_size=384, batch=1):
+    """Time the oracle's full train step on the host cores (bounded sample)."""
+    import torch
+    from oracle import ae_oracle as orc
+    from weatherforecastingtoolkit_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for k, shp, kind in synth.ae_state_dict_spec(img_size):
+        if kind == "bn_n":
+            sd[k] = torch.zeros((), dtype=torch.int64)
+        elif kind in ("bn_w", "bn_rv"):
+            sd[k] = torch.ones(shp)
+        elif kind in ("bn_b", "bn_rm"):
+            sd[k] = torch.zeros(shp)
+        elif kind == "normal":
+            sd[k] = torch.randn(shp, generator=g)
+        else:
+            fan = shp[1] * (shp[2] * shp[3] if len(shp) == 4 else 1) if len(shp) > 1 else kind[1]
+            b = 1.0 / fan ** 0.5
+            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * b
+        if sd[k].dtype.is_floating_point and "running_" not in k:
+            sd[k].requires_grad_(True)
+    x = torch.from_numpy(synth.uniform_frames(batch, img_size, seed=99))
+    opt = orc.make_optimizer([p for _, p in orc.trainable(sd)], lr=5e-5, weight_decay=1e-4)
+    t0 = time.perf_counter()
+    orc.train_step(x, sd, opt)
+    dt = time.perf_counter() - t0
+    return {"value": batch / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ae_oracle.py train step (fwd+L1+bwd+AdamW), {img_size}x{img_size}, batch {batch}, "
+                      f"1 step, torch CPU fp32, {cores} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="frames per GPU")
+    ap.add_argument("--img-size", type=int, default=384)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from weatherforecastingtoolkit_amd import functional as Fn, ops, parallel
+    from weatherforecastingtoolkit_amd.optim import CosineWarmupLR, FusedAdamW
+    from weatherforecastingtoolkit_amd.pipeline.models.ae_64x8x8_lin import PosAwareAE_TF
+
+    rank, world, local = parallel.init_from_env("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    torch.manual_seed(0)  # identical random-init weights on every rank (then broadcast anyway)
+    net = PosAwareAE_TF(img_size=args.img_size).to(dev).train()
+    opt = FusedAdamW(net.parameters(), lr=5e-5, betas=(0.9, 0.999), weight_decay=1e-4)
+    total_steps = max(args.steps + args.warmup, 10)
+    sched = CosineWarmupLR(opt, 5e-6, 5e-7, 5e-5, total_steps, 0.1 * total_steps)
+    dp = parallel.DataParallelTrainer(net, opt)
+
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    B, S = args.batch, args.img_size
+    x = (torch.randint(0, 256, (B, 1, S, S), generator=gen, device=dev, dtype=torch.int32).float() / 255.0).contiguous()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        recon, _ = net(x)
+        loss = Fn.l1_loss(recon, x)
+        loss.backward()
+        dp.reduce_gradients()
+        opt.step()
+        sched.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    timing = (not args.no_kernel_timing)
+    if timing:
+        ops.profile_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_stop() if timing else {}
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        fps = world * B * args.steps / dt
+        scale = (S / 384.0) ** 2
+        out = {
+            "metric": "SEVIR 384x384 frames/sec (AE train step)",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"experiments/ae_v2 conv AE (ae_64x8x8_lin.PosAwareAE_TF, img_size={S}), "
+                                   f"1x{S}x{S} synthetic SEVIR frames, batch {B}/GPU, fp32, "
+                                   "fwd + L1 + bwd + AdamW + cosine-warmup LR",
+                       "batch_per_gpu": B, "global_batch": B * world, "img_size": S,
+                       "parallelism": f"dp{world}", "params": sum(p.numel() for p in net.parameters())},
+            "final_loss": final_loss,
+            "step_roofline": {"fp32_fraction": FLOPS_PER_FRAME_384 * scale * fps / world / PEAK_FP32,
+                              "hbm_fraction": BYTES_PER_FRAME_384 * scale * fps / world / PEAK_HBM,
+                              "binding": "fp32 MFMA/VALU (AI ~127 FLOP/B, SURVEY.md §8d)"},
+        }
+        if prof:
+            tot_ms = sum(v[1] for v in prof.values())
+            fam = sorted(prof.items(), key=lambda kv: -kv[1][1])
+            name, (calls, ms, fl, by) = fam[0]
+            if fl > 0:
+                ach, peak, unit, bound = fl / (ms * 1e-3) / 1e12, PEAK_FP32 / 1e12, "TFLOP/s", "mfma"
+            else:
+                ach, peak, unit, bound = by / (ms * 1e-3) / 1e9, PEAK_HBM / 1e9, "GB/s", "hbm"
+            out["roofline"] = {"kernel": KERNEL_OF.get(name, name), "entry_point": name, "bound": bound,
+                               "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+                               "launches": calls, "avg_launch_ms": ms / calls,
+                               "share_of_kernel_time": ms / tot_ms}
+            out["kernel_breakdown"] = [
+                {"entry_point": k, "calls_per_step": v[0] / args.steps, "ms_per_step": v[1] / args.steps,
+                 "tflops": (v[2] / (v[1] * 1e-3) / 1e12) if v[2] else None,
+                 "gbps": v[3] / (v[1] * 1e-3) / 1e9} for k, v in fam[:12]]
+        if world == 1 and not args.no_cpu_baseline:
+            del net, opt, dp
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(args.img_size, 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,22 +1,15 @@
 import os
 import sys
 
-import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-GOLDEN = os.path.join(ROOT, "tests", "golden")
-
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-
-
-def golden(name):
-    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
 
 @pytest.fixture(scope="session")
@@ -25,15 +18,3 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
-
-
-def relerr(a, b):
-    """max |a-b| / (max |b| + tiny), both numpy or torch (moved to cpu)."""
-    import torch
-    if isinstance(a, torch.Tensor):
-        a = a.detach().double().cpu().numpy()
-    if isinstance(b, torch.Tensor):
-        b = b.detach().double().cpu().numpy()
-    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
-    assert a.shape == b.shape, (a.shape, b.shape)
-    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))

@@ -12,7 +12,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import golden, relerr
+from tests._util import golden, relerr
 
 pytestmark = pytest.mark.gpu
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, relerr
+from tests._util import golden, relerr
 
 pytestmark = pytest.mark.gpu
 

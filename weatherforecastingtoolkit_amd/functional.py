@@ -30,7 +30,9 @@ BN_EPS = 1e-5
 def grad_buffer(p):
     v = getattr(p, "_wfae_grad_view", None)
     if v is not None and p.grad is None:
-        return v
+        # a fresh alias: autograd adopts the tensor as p.grad without a copy only
+        # when nobody else references the same TensorImpl
+        return v.view(v.shape)
     return torch.empty_like(p)
 
 

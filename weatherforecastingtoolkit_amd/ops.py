@@ -20,6 +20,38 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional per-launch timing with events on the launch stream (bench.py's
+# roofline read-out): name -> [(start_evt, end_evt, algorithmic flops, algorithmic bytes)]
+_prof = None
+
+
+def profile_start():
+    global _prof
+    _prof = {}
+
+
+def profile_stop():
+    """-> {name: (calls, total_ms, flops, bytes)}; synchronises the device."""
+    global _prof
+    rec, _prof = _prof, None
+    torch.cuda.synchronize()
+    out = {}
+    for k, lst in (rec or {}).items():
+        ms = sum(a.elapsed_time(b) for a, b, _, _ in lst)
+        out[k] = (len(lst), ms, sum(f for _, _, f, _ in lst), sum(b for _, _, _, b in lst))
+    return out
+
+
+def _call(name, flops, nbytes, *args):
+    if _prof is None:
+        return _lib.call(name, *args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.call(name, *args)
+    e1.record()
+    _prof.setdefault(name, []).append((e0, e1, flops, nbytes))
+
+
 def workspace(min_bytes: int = 0):
     """Per-(device, stream) scratch buffer handed to kernels that need one."""
     dev = torch.cuda.current_device()
@@ -55,7 +87,7 @@ def conv1x1_fwd(x, w, bias=None, res=None, res_broadcast=False):
     cout = w.shape[0]
     y = torch.empty((nb, cout, h, wd), dtype=x.dtype, device=x.device)
     stride = 0 if res_broadcast else cout * h * wd
-    _lib.call("wfae_conv1x1_fwd", _p(x), _p(w), _p(bias), _p(res), stride, _p(y), nb, cin, cout, h * wd, _stream())
+    _call("wfae_conv1x1_fwd", 2 * nb * h * wd * cin * cout, 4 * (nb * h * wd * (cin + cout) + cin * cout) + (0 if res is None else 4 * nb * h * wd * cout), _p(x), _p(w), _p(bias), _p(res), stride, _p(y), nb, cin, cout, h * wd, _stream())
     return y
 
 
@@ -64,7 +96,7 @@ def conv1x1_bwd_data(dy, w):
     nb, cout, h, wd = dy.shape
     cin = w.shape[1]
     dx = torch.empty((nb, cin, h, wd), dtype=dy.dtype, device=dy.device)
-    _lib.call("wfae_conv1x1_bwd_data", _p(dy), _p(w), _p(dx), nb, cin, cout, h * wd, _stream())
+    _call("wfae_conv1x1_bwd_data", 2 * nb * h * wd * cin * cout, 4 * (nb * h * wd * (cin + cout) + cin * cout), _p(dy), _p(w), _p(dx), nb, cin, cout, h * wd, _stream())
     return dx
 
 
@@ -73,7 +105,7 @@ def conv1x1_bwd_weight(dy, x, dw, accumulate=False):
     nb, cout, h, wd = dy.shape
     cin = x.shape[1]
     ws = workspace()
-    _lib.call("wfae_conv1x1_bwd_weight", _p(dy), _p(x), _p(dw), nb, cin, cout, h * wd, int(accumulate),
+    _call("wfae_conv1x1_bwd_weight", 2 * nb * h * wd * cin * cout, 4 * (nb * h * wd * (cin + cout) + cin * cout), _p(dy), _p(x), _p(dw), nb, cin, cout, h * wd, int(accumulate),
               ws.data_ptr(), ws.numel(), _stream())
     return dw
 
@@ -85,7 +117,7 @@ def linear_fwd(x, w, bias=None):
     out = w.shape[0]
     y = torch.empty((b, out), dtype=x.dtype, device=x.device)
     ws = workspace()
-    _lib.call("wfae_linear_fwd", _p(x), _p(w), _p(bias), _p(y), b, inf, out, ws.data_ptr(), ws.numel(), _stream())
+    _call("wfae_linear_fwd", 2 * b * inf * out, 4 * (inf * out + b * (inf + out)), _p(x), _p(w), _p(bias), _p(y), b, inf, out, ws.data_ptr(), ws.numel(), _stream())
     return y
 
 
@@ -94,7 +126,7 @@ def linear_bwd_data(dy, w):
     b, out = dy.shape
     inf = w.shape[1]
     dx = torch.empty((b, inf), dtype=dy.dtype, device=dy.device)
-    _lib.call("wfae_linear_bwd_data", _p(dy), _p(w), _p(dx), b, inf, out, _stream())
+    _call("wfae_linear_bwd_data", 2 * b * inf * out, 4 * (inf * out + b * (inf + out)), _p(dy), _p(w), _p(dx), b, inf, out, _stream())
     return dx
 
 
@@ -102,7 +134,7 @@ def linear_bwd_weight(dy, x, dw, accumulate=False):
     _chk(dy, x, dw)
     b, out = dy.shape
     inf = x.shape[1]
-    _lib.call("wfae_linear_bwd_weight", _p(dy), _p(x), _p(dw), b, inf, out, int(accumulate), _stream())
+    _call("wfae_linear_bwd_weight", 2 * b * inf * out, 4 * (inf * out + b * (inf + out)), _p(dy), _p(x), _p(dw), b, inf, out, int(accumulate), _stream())
     return dw
 
 
@@ -114,7 +146,7 @@ def conv4x4s2_down(hi, w):
     clo = w.shape[0]
     hlo, wlo = h2 // 2, w2 // 2
     lo = torch.empty((nb, clo, hlo, wlo), dtype=hi.dtype, device=hi.device)
-    _lib.call("wfae_conv4x4s2_down", _p(hi), _p(w), _p(lo), nb, chi, clo, hlo, wlo, _stream())
+    _call("wfae_conv4x4s2_down", 32 * nb * hlo * wlo * clo * chi, 4 * (nb * hlo * wlo * (clo + 4 * chi) + 16 * clo * chi), _p(hi), _p(w), _p(lo), nb, chi, clo, hlo, wlo, _stream())
     return lo
 
 
@@ -125,7 +157,7 @@ def conv4x4s2_up(lo, w):
     chi = w.shape[1]
     hi = torch.empty((nb, chi, 2 * hlo, 2 * wlo), dtype=lo.dtype, device=lo.device)
     ws = workspace(w.numel() * 4)
-    _lib.call("wfae_conv4x4s2_up", _p(lo), _p(w), _p(hi), nb, chi, clo, hlo, wlo, ws.data_ptr(), ws.numel(), _stream())
+    _call("wfae_conv4x4s2_up", 32 * nb * hlo * wlo * clo * chi, 4 * (nb * hlo * wlo * (clo + 4 * chi) + 16 * clo * chi), _p(lo), _p(w), _p(hi), nb, chi, clo, hlo, wlo, ws.data_ptr(), ws.numel(), _stream())
     return hi
 
 
@@ -134,7 +166,7 @@ def conv4x4s2_wgrad(lo, hi, dw, accumulate=False):
     nb, clo, hlo, wlo = lo.shape
     chi = hi.shape[1]
     ws = workspace(dw.numel() * 4 * 2)
-    _lib.call("wfae_conv4x4s2_wgrad", _p(lo), _p(hi), _p(dw), nb, chi, clo, hlo, wlo, int(accumulate),
+    _call("wfae_conv4x4s2_wgrad", 32 * nb * hlo * wlo * clo * chi, 4 * (nb * hlo * wlo * (clo + 4 * chi) + 16 * clo * chi), _p(lo), _p(hi), _p(dw), nb, chi, clo, hlo, wlo, int(accumulate),
               ws.data_ptr(), ws.numel(), _stream())
     return dw
 
@@ -147,7 +179,7 @@ def dconv_fwd(x, w, bias, ks, stride, pad, groups):
     ho = (h + 2 * pad - ks) // stride + 1
     wo = (wd + 2 * pad - ks) // stride + 1
     y = torch.empty((nb, cout, ho, wo), dtype=x.dtype, device=x.device)
-    _lib.call("wfae_dconv_fwd", _p(x), _p(w), _p(bias), _p(y), nb, cin, cout, h, wd, ks, stride, pad, groups, _stream())
+    _call("wfae_dconv_fwd", 2 * nb * ho * wo * cout * (cin // groups) * ks * ks, 4 * (nb * (cin * h * wd + cout * ho * wo) + w.numel()), _p(x), _p(w), _p(bias), _p(y), nb, cin, cout, h, wd, ks, stride, pad, groups, _stream())
     return y
 
 
@@ -155,7 +187,7 @@ def dconv_bwd_data(dy, w, cin, ks, pad, groups):
     _chk(dy, w)
     nb, cout, h, wd = dy.shape
     dx = torch.empty((nb, cin, h, wd), dtype=dy.dtype, device=dy.device)
-    _lib.call("wfae_dconv_bwd_data", _p(dy), _p(w), _p(dx), nb, cin, cout, h, wd, ks, pad, groups, _stream())
+    _call("wfae_dconv_bwd_data", 2 * nb * h * wd * cout * (cin // groups) * ks * ks, 4 * (nb * h * wd * (cin + cout) + w.numel()), _p(dy), _p(w), _p(dx), nb, cin, cout, h, wd, ks, pad, groups, _stream())
     return dx
 
 
@@ -164,7 +196,7 @@ def dconv_bwd_weight(dy, x, dw, ks, stride, pad, groups, accumulate=False):
     nb, cin, h, wd = x.shape
     cout = dy.shape[1]
     ws = workspace()
-    _lib.call("wfae_dconv_bwd_weight", _p(dy), _p(x), _p(dw), nb, cin, cout, h, wd, ks, stride, pad, groups,
+    _call("wfae_dconv_bwd_weight", 2 * dy.numel() * (cin // groups) * ks * ks, 4 * (x.numel() + dy.numel() + dw.numel()), _p(dy), _p(x), _p(dw), nb, cin, cout, h, wd, ks, stride, pad, groups,
               int(accumulate), ws.data_ptr(), ws.numel(), _stream())
     return dw
 
@@ -184,7 +216,7 @@ def bn_stats_train(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum
     nb, c, h, wd = x.shape
     st = BnStats(c, x.device)
     ws = workspace()
-    _lib.call("wfae_bn_stats_train", _p(x), nb, c, h * wd, _p(gamma), _p(beta), eps, momentum, _p(running_mean),
+    _call("wfae_bn_stats_train", 0, 4 * x.numel(), _p(x), nb, c, h * wd, _p(gamma), _p(beta), eps, momentum, _p(running_mean),
               _p(running_var), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift), ws.data_ptr(), ws.numel(),
               _stream())
     return st
@@ -194,7 +226,7 @@ def bn_fold_eval(gamma, beta, running_mean, running_var, eps=1e-5):
     _chk(gamma, beta, running_mean, running_var)
     c = gamma.shape[0]
     st = BnStats(c, gamma.device)
-    _lib.call("wfae_bn_fold_eval", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(st.mean),
+    _call("wfae_bn_fold_eval", 0, 0, _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(st.mean),
               _p(st.invstd), _p(st.scale), _p(st.shift), c, _stream())
     return st
 
@@ -203,7 +235,7 @@ def bn_act_fwd(x, st, act=1):
     _chk(x)
     nb, c, h, wd = x.shape
     y = torch.empty_like(x)
-    _lib.call("wfae_bn_act_fwd", _p(x), _p(st.scale), _p(st.shift), _p(y), nb, c, h * wd, act, _stream())
+    _call("wfae_bn_act_fwd", 0, 8 * x.numel(), _p(x), _p(st.scale), _p(st.shift), _p(y), nb, c, h * wd, act, _stream())
     return y
 
 
@@ -212,7 +244,7 @@ def bn_act_bwd(dy, x, gamma, st, dgamma, dbeta, res=None, act=1, training=True, 
     nb, c, h, wd = x.shape
     dx = torch.empty_like(x) if need_dx else None
     ws = workspace()
-    _lib.call("wfae_bn_act_bwd", _p(dy), _p(x), _p(gamma), _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd),
+    _call("wfae_bn_act_bwd", 0, 4 * x.numel() * (6 if res is not None else 5), _p(dy), _p(x), _p(gamma), _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd),
               _p(res), _p(dx), _p(dgamma), _p(dbeta), nb, c, h * wd, act, int(training), int(accumulate),
               ws.data_ptr(), ws.numel(), _stream())
     return dx
@@ -223,9 +255,9 @@ def _ew(name, a, b=None):
     _chk(a, b)
     out = torch.empty_like(a)
     if b is None:
-        _lib.call(name, _p(a), _p(out), a.numel(), _stream())
+        _call(name, 0, 8 * a.numel(), _p(a), _p(out), a.numel(), _stream())
     else:
-        _lib.call(name, _p(a), _p(b), _p(out), a.numel(), _stream())
+        _call(name, 0, 12 * a.numel(), _p(a), _p(b), _p(out), a.numel(), _stream())
     return out
 
 
@@ -252,7 +284,7 @@ def add(a, b):
 def reduce_sum(x, outer, c, inner, out, accumulate=False):
     _chk(x, out)
     ws = workspace()
-    _lib.call("wfae_reduce_sum", _p(x), outer, c, inner, _p(out), int(accumulate), ws.data_ptr(), ws.numel(), _stream())
+    _call("wfae_reduce_sum", 0, 4 * x.numel(), _p(x), outer, c, inner, _p(out), int(accumulate), ws.data_ptr(), ws.numel(), _stream())
     return out
 
 
@@ -262,7 +294,7 @@ def sigmoid_l1_fwd(h, x, weight=1.0):
     recon = torch.empty_like(h)
     loss = torch.empty((), dtype=torch.float32, device=h.device)
     ws = workspace()
-    _lib.call("wfae_sigmoid_l1_fwd", _p(h), _p(x), _p(recon), _p(loss), weight, h.numel(), ws.data_ptr(), ws.numel(),
+    _call("wfae_sigmoid_l1_fwd", 0, 12 * h.numel(), _p(h), _p(x), _p(recon), _p(loss), weight, h.numel(), ws.data_ptr(), ws.numel(),
               _stream())
     return recon, loss
 
@@ -270,7 +302,7 @@ def sigmoid_l1_fwd(h, x, weight=1.0):
 def sigmoid_l1_bwd(recon, x, gloss, weight=1.0):
     _chk(recon, x, gloss)
     dh = torch.empty_like(recon)
-    _lib.call("wfae_sigmoid_l1_bwd", _p(recon), _p(x), _p(gloss), weight, _p(dh), recon.numel(), _stream())
+    _call("wfae_sigmoid_l1_bwd", 0, 12 * recon.numel(), _p(recon), _p(x), _p(gloss), weight, _p(dh), recon.numel(), _stream())
     return dh
 
 
@@ -278,14 +310,14 @@ def l1_fwd(recon, x, weight=1.0):
     _chk(recon, x)
     loss = torch.empty((), dtype=torch.float32, device=recon.device)
     ws = workspace()
-    _lib.call("wfae_l1_fwd", _p(recon), _p(x), _p(loss), weight, recon.numel(), ws.data_ptr(), ws.numel(), _stream())
+    _call("wfae_l1_fwd", 0, 8 * recon.numel(), _p(recon), _p(x), _p(loss), weight, recon.numel(), ws.data_ptr(), ws.numel(), _stream())
     return loss
 
 
 def l1_bwd(recon, x, gloss, weight=1.0):
     _chk(recon, x, gloss)
     d = torch.empty_like(recon)
-    _lib.call("wfae_l1_bwd", _p(recon), _p(x), _p(gloss), weight, _p(d), recon.numel(), _stream())
+    _call("wfae_l1_bwd", 0, 12 * recon.numel(), _p(recon), _p(x), _p(gloss), weight, _p(d), recon.numel(), _stream())
     return d
 
 
@@ -295,7 +327,7 @@ def ssim_fwd(x, y, clamp01=False):
     h, wd = x.shape[-2:]
     out = torch.empty((), dtype=torch.float32, device=x.device)
     ws = workspace()
-    _lib.call("wfae_ssim_fwd", _p(x), _p(y), _p(out), nb, h, wd, int(clamp01), ws.data_ptr(), ws.numel(), _stream())
+    _call("wfae_ssim_fwd", 0, 8 * x.numel(), _p(x), _p(y), _p(out), nb, h, wd, int(clamp01), ws.data_ptr(), ws.numel(), _stream())
     return out
 
 
@@ -305,7 +337,7 @@ def ssim_bwd(x, y, gout):
     h, wd = x.shape[-2:]
     dy = torch.empty_like(y)
     ws = workspace(3 * nb * (h - 10) * (wd - 10) * 4)
-    _lib.call("wfae_ssim_bwd", _p(x), _p(y), _p(gout), _p(dy), nb, h, wd, ws.data_ptr(), ws.numel(), _stream())
+    _call("wfae_ssim_bwd", 0, 12 * x.numel(), _p(x), _p(y), _p(gout), _p(dy), nb, h, wd, ws.data_ptr(), ws.numel(), _stream())
     return dy
 
 
@@ -315,14 +347,14 @@ def psnr(pred, target, clamp01=False):
     hw = pred.numel() // nb
     out = torch.empty((), dtype=torch.float32, device=pred.device)
     ws = workspace()
-    _lib.call("wfae_psnr", _p(pred), _p(target), _p(out), nb, hw, int(clamp01), ws.data_ptr(), ws.numel(), _stream())
+    _call("wfae_psnr", 0, 8 * pred.numel(), _p(pred), _p(target), _p(out), nb, hw, int(clamp01), ws.data_ptr(), ws.numel(), _stream())
     return out
 
 
 # ---------------------------------------------------------------- optimiser
 def adamw_(p, g, m, v, lr, beta1, beta2, eps, wd, bc1, bc2, grad_scale=1.0):
     _chk(p, g, m, v)
-    _lib.call("wfae_adamw", _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, bc1, bc2, grad_scale,
+    _call("wfae_adamw", 0, 28 * p.numel(), _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, bc1, bc2, grad_scale,
               _stream())
 
 
@@ -330,7 +362,7 @@ def sumsq(x):
     _chk(x)
     out = torch.empty((), dtype=torch.float64, device=x.device)
     ws = workspace()
-    _lib.call("wfae_sumsq", _p(x), x.numel(), _p(out), ws.data_ptr(), ws.numel(), _stream())
+    _call("wfae_sumsq", 0, 4 * x.numel(), _p(x), x.numel(), _p(out), ws.data_ptr(), ws.numel(), _stream())
     return out
 
 
@@ -340,5 +372,5 @@ def vil_u8_to_f32(src_nhwt, scale=1.0 / 255.0):
         raise _lib.WfaeError("vil_u8_to_f32 needs a contiguous uint8 device tensor")
     n, h, w, t = src_nhwt.shape
     dst = torch.empty((n, t, h, w), dtype=torch.float32, device=src_nhwt.device)
-    _lib.call("wfae_vil_u8_to_f32", src_nhwt.data_ptr(), _p(dst), n, h, w, t, scale, _stream())
+    _call("wfae_vil_u8_to_f32", 0, 5 * dst.numel(), src_nhwt.data_ptr(), _p(dst), n, h, w, t, scale, _stream())
     return dst

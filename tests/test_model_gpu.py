@@ -76,6 +76,16 @@ def test_full_model_golden(dev, gname):
     idx = torch.from_numpy(g["lattice"]).to(dev)
     names = [n for n, _ in net.named_parameters()]
     assert names == [str(n) for n in g["grad_names"]]
+    # eval-mode forward (BatchNorm running statistics) on identical weights vs the oracle
+    from oracle import ae_oracle as orc
+    from weatherforecastingtoolkit_amd import synth
+    osd = orc.to_torch_sd(synth.synth_state_dict(synth.ae_state_dict_spec(size), seed=0), requires_grad=False)
+    with torch.no_grad():
+        orecon, oz = orc.forward(x.cpu(), osd, training=False)
+        net.eval()
+        er0, ez0 = net(x)
+        net.train()
+    assert relerr(er0, orecon) < 1e-4 and relerr(ez0, oz) < 1e-4
     for s in range(int(g["steps"])):
         opt.zero_grad(set_to_none=True)
         recon, z = net(x)
@@ -106,8 +116,13 @@ def test_full_model_golden(dev, gname):
     net.eval()
     with torch.no_grad():
         er, ez = net(x)
-    assert relerr(er[:, 0][:, idx][:, :, idx], g["eval_recon_lattice"]) < 1e-4
-    assert relerr(ez, g["eval_z"]) < 1e-4
+    # After AdamW steps the weights of two correct fp32 implementations differ by O(lr) on
+    # elements whose gradient is at rounding-noise level (Adam normalises |g| away): perturbing
+    # the REFERENCE's own gradients by 1e-5*max|g| moves its eval-mode z by 3.4e-3 after 3
+    # steps ("Parity"), so this trajectory check is necessarily looser than the
+    # same-weights check above.
+    assert relerr(er[:, 0][:, idx][:, :, idx], g["eval_recon_lattice"]) < 1e-3
+    assert relerr(ez, g["eval_z"]) < 2e-2
 
 
 def test_leaf_modules_standalone(dev):

@@ -73,6 +73,9 @@ def load(path: str = LIB_PATH):
     global _lib, _decls
     if _lib is not None:
         return _lib
+    # torch's bundled HIP runtime must be in the process first: libwfae.so then binds
+    # to that same libamdhip64 (one runtime, one set of streams) instead of a second copy.
+    import torch  # noqa: F401
     if not os.path.exists(path):
         raise WfaeError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -1,0 +1,120 @@
+"""Per-layer kernel micro-benchmark at the real shapes of the 384x384, B=32 train step.
+Times each libwfae.so entry point with events on the launch stream (interleaved
+rounds, median) and prints ms / TFLOP/s / GB/s per shape.
+
+    python tools/kbench.py [--only conv4,conv1,dconv,bn] [--batch 32] [--size 384] [--rounds 5]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from weatherforecastingtoolkit_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, rounds):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def rnd(*shape):
+    return torch.rand(shape, device=dev) - 0.5
+
+
+def report(tag, ms, flops, nbytes):
+    print(f"{tag:58s} {ms:9.3f} ms  {flops / ms / 1e9:8.1f} TF/s  {nbytes / ms / 1e6:8.0f} GB/s", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="conv4,conv1,dconv,bn")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=384)
+    ap.add_argument("--rounds", type=int, default=5)
+    a = ap.parse_args()
+    only = set(a.only.split(","))
+    B, S, R = a.batch, a.size, a.rounds
+    tot = {}
+
+    def acc(k, ms, mult=1):
+        tot[k] = tot.get(k, 0.0) + ms * mult
+
+    if "conv4" in only:
+        for chi, clo, hlo in [(256, 512, S // 4), (512, 1024, S // 8), (1024, 1024, S // 16),
+                              (512, 1024, S // 8), (256, 512, S // 4), (128, 256, S // 2)]:
+            hi, lo, w = rnd(B, chi, 2 * hlo, 2 * hlo), rnd(B, clo, hlo, hlo), rnd(clo, chi, 4, 4)
+            dw = torch.empty_like(w)
+            fl = 32 * B * hlo * hlo * clo * chi
+            by = 4 * (B * hlo * hlo * (clo + 4 * chi) + 16 * clo * chi)
+            for nm, fn in [("down", lambda: ops.conv4x4s2_down(hi, w)), ("up", lambda: ops.conv4x4s2_up(lo, w)),
+                           ("wgrad", lambda: ops.conv4x4s2_wgrad(lo, hi, dw))]:
+                ms = timeit(fn, R)
+                report(f"conv4x4 {nm:5s} hi {chi}@{2 * hlo} lo {clo}@{hlo}", ms, fl, by)
+                acc("conv4_" + nm, ms)
+            del hi, lo, w, dw
+    stages = [(256, S // 2), (512, S // 4), (1024, S // 8), (1024, S // 16), (1024, S // 8), (512, S // 4),
+              (256, S // 2), (128, S)]
+    if "conv1" in only:
+        for c, h in stages:
+            mid = c // 4
+            for cin, cout, res in [(c, mid, False), (mid, c, True)]:
+                x, w, dy = rnd(B, cin, h, h), rnd(cout, cin, 1, 1), rnd(B, cout, h, h)
+                r = rnd(B, cout, h, h) if res else None
+                dw = torch.empty_like(w)
+                fl = 2 * B * h * h * cin * cout
+                by = 4 * (B * h * h * (cin + cout) + cin * cout)
+                for nm, fn, extra in [("fwd", lambda: ops.conv1x1_fwd(x, w, None, r), 4 * B * h * h * cout if res else 0),
+                                      ("dgrad", lambda: ops.conv1x1_bwd_data(dy, w), 0),
+                                      ("wgrad", lambda: ops.conv1x1_bwd_weight(dy, x, dw), 0)]:
+                    ms = timeit(fn, R)
+                    report(f"conv1x1 {nm:5s} {cin}->{cout} @{h}{' +res' if res and nm == 'fwd' else ''}", ms, fl, by + extra)
+                    acc("conv1_" + nm, ms, 4)
+                del x, w, dy, r, dw
+    if "dconv" in only:
+        for c, h in stages:
+            mid = c // 4
+            x, w, dy = rnd(B, mid, h, h), rnd(mid, mid // 8, 3, 3), rnd(B, mid, h, h)
+            dw = torch.empty_like(w)
+            fl = 2 * B * h * h * mid * (mid // 8) * 9
+            by = 4 * 2 * B * h * h * mid
+            for nm, fn in [("fwd", lambda: ops.dconv_fwd(x, w, None, 3, 1, 1, 8)),
+                           ("dgrad", lambda: ops.dconv_bwd_data(dy, w, mid, 3, 1, 8)),
+                           ("wgrad", lambda: ops.dconv_bwd_weight(dy, x, dw, 3, 1, 1, 8))]:
+                ms = timeit(fn, R)
+                report(f"gconv3x3 {nm:5s} {mid}ch g8 @{h}", ms, fl, by)
+                acc("dconv_" + nm, ms, 4)
+            del x, w, dy, dw
+    if "bn" in only:
+        for c, h in stages:
+            for ch in (c, c // 4):
+                x, dy = rnd(B, ch, h, h), rnd(B, ch, h, h)
+                g, b_, rm, rv = torch.ones(ch, device=dev), torch.zeros(ch, device=dev), torch.zeros(ch, device=dev), torch.ones(ch, device=dev)
+                dg, db = torch.empty(ch, device=dev), torch.empty(ch, device=dev)
+                n = x.numel()
+                st = ops.bn_stats_train(x, g, b_, rm, rv)
+                mult = 4 if ch == c else 8
+                ms = timeit(lambda: ops.bn_stats_train(x, g, b_, rm, rv), R); report(f"bn_stats {ch}@{h}", ms, 0, 4 * n); acc("bn_stats", ms, mult)
+                ms = timeit(lambda: ops.bn_act_fwd(x, st, 1), R); report(f"bn_act_fwd {ch}@{h}", ms, 0, 8 * n); acc("bn_fwd", ms, mult)
+                ms = timeit(lambda: ops.bn_act_bwd(dy, x, g, st, dg, db, None, 1, True), R); report(f"bn_act_bwd {ch}@{h}", ms, 0, 20 * n); acc("bn_bwd", ms, mult)
+                del x, dy
+    print("---- per-step totals (ms), weighted by layer multiplicity ----")
+    for k, v in tot.items():
+        print(f"{k:14s} {v:9.2f}")
+
+
+if __name__ == "__main__":
+    main()

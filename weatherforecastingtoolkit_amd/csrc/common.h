@@ -67,11 +67,15 @@ __device__ __forceinline__ float gelu_f(float u) {
 }
 __device__ __forceinline__ float gelu_grad_f(float u) {
   const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * u * u);
   return cdf + u * pdf;
 }
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// out = (beta ? out : 0) + sum over `splits` partial slabs of MN floats (+ bias_n[i % N]); fixed order.
+int slab_reduce(const float* slab, float* out, const float* bias_n, long MN, int N, int splits, int beta,
+                hipStream_t st, int transpose_m = 0);
 
 }  // namespace wfae

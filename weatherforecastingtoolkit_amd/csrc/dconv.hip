@@ -230,16 +230,6 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(DWgradP p) {
   }
 }
 
-__global__ void parts_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long n,
-                                    int parts, int beta) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int z = 0; z < parts; ++z) s += part[(long)z * n + i];
-  if (beta) s += out[i];
-  out[i] = s;
-}
-
 inline int pow2_floor(int v) {
   int r = 1;
   while (r * 2 <= v) r *= 2;
@@ -326,7 +316,7 @@ int wfae_dconv_bwd_weight(const float* dy, const float* x, float* dw, int NB, in
   const int gy = p.n_gset * p.n_ochunk * p.n_ichunk;
   const long total_tiles = (long)NB * p.tiles_x * p.tiles_y;
   const size_t out_elems = (size_t)Cout * IG * KK;
-  long parts = 2048 / gy;
+  long parts = 1024 / gy;
   if (parts < 1) parts = 1;
   if (parts > total_tiles) parts = total_tiles;
   while (parts > 1 && (size_t)parts * out_elems * sizeof(float) > ws_bytes) --parts;
@@ -355,9 +345,7 @@ int wfae_dconv_bwd_weight(const float* dy, const float* x, float* dw, int NB, in
 #undef WFAE_WG
   int rc = check_launch("dconv_wgrad");
   if (rc) return rc;
-  hipLaunchKernelGGL(parts_reduce_kernel, dim3(cdiv((long)out_elems, 256)), dim3(256), 0, st, (const float*)ws,
-                     dw, (long)out_elems, (int)parts, accumulate);
-  return check_launch("dconv_wgrad_reduce");
+  return slab_reduce((const float*)ws, dw, nullptr, (long)out_elems, 1, (int)parts, accumulate, st);
 }
 
 }  // extern "C"

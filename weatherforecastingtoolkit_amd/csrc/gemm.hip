@@ -54,12 +54,16 @@ struct GemmP {
   int c_ld;
   long res_img;
   int beta;          // 1: C += result
-  int a_vec, b_vec;  // 16-byte vector loads are legal for this operand
+  int a_vec, b_vec, c_vec;  // 16-byte vector accesses are legal for this operand / the result
   // 4x4 s2 geometry (gather kinds): lo side Hlo x Wlo, hi side 2Hlo x 2Wlo
   int Chi, Clo, Hlo, Wlo;
 };
 
-template <int BM, int WMW, int WNW, int AK, int BKD, int EK>
+// VEC: every operand/result row is 16-byte aligned and a multiple of 4 floats long, so all
+// global traffic is dwordx4.  Loaders are BRANCH-FREE: out-of-range elements load from a clamped
+// (always valid) address and are zeroed by a select, so the compiler issues every global load of
+// a stage back-to-back and waits once, after the MFMAs of the current stage.
+template <int BM, int WMW, int WNW, int AK, int BKD, int EK, bool VEC>
 __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   static_assert(WMW * WNW == 4, "4 waves");
   constexpr int TM = BM / (WMW * 32);
@@ -67,8 +71,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   static_assert(TM >= 1 && TN >= 1, "tile");
   constexpr int LDA_S = BM + 4;
   constexpr int LDB_S = BN + 4;
-  __shared__ __attribute__((aligned(16))) float As[2][BK][LDA_S];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB_S];
+  constexpr int A_FLOATS = 2 * BK * LDA_S, B_FLOATS = 2 * BK * LDB_S;
+  __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + B_FLOATS];
+  float(*As)[BK][LDA_S] = reinterpret_cast<float(*)[BK][LDA_S]>(smem);
+  float(*Bs)[BK][LDB_S] = reinterpret_cast<float(*)[BK][LDB_S]>(smem + A_FLOATS);
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -92,7 +98,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   const float* __restrict__ Bp = p.B;
 
   // ------------------------------------------------ per-thread loader state
-  constexpr int A_IT = (BM * BK / 4 + NT - 1) / NT;
+  constexpr int A_CNT = BM * BK / 4;
+  constexpr int A_IT = (A_CNT + NT - 1) / NT;
   constexpr int B_IT = (BN * BK / 4) / NT;  // 2
   float4 ra[A_IT];
   float4 rb[B_IT];
@@ -101,11 +108,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   const int H = 2 * p.Hlo, W = 2 * p.Wlo;
   const int HWlo = p.Hlo * p.Wlo;
 
-  // B_NCONTIG: n is fixed per thread
-  long bn_base = 0;
+  long bn_base = 0;  // B_NCONTIG: n is fixed per thread
   bool bn_ok = false;
-  // gather kinds
-  const int g_nl = t & (BN - 1);
+  const int g_nl = t & (BN - 1);  // gather kinds
   const int g_kh = t >> 7;
   long g_base = 0;
   unsigned g_rmask = 0, g_cmask = 0;
@@ -115,105 +120,100 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   if constexpr (BKD == B_NCONTIG) {
     const int n = n0 + (t & 31) * 4;
     bn_ok = n < p.N;
-    if (bn_ok) {
-      const int img = n / p.b_hw;
-      bn_base = (long)img * p.b_img + (n - img * p.b_hw);
-    }
+    const int nn = bn_ok ? n : 0;
+    const int img = nn / p.b_hw;
+    bn_base = (long)img * p.b_img + (nn - img * p.b_hw);
   } else if constexpr (BKD == B_DOWN) {
     const int n = n0 + g_nl;
     g_ok = n < p.N;
-    if (g_ok) {
-      const int img = n / HWlo;
-      const int r = n - img * HWlo;
-      const int oy = r / p.Wlo, ox = r - oy * p.Wlo;
-      const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
-      g_base = (long)img * p.Chi * H * W + (long)iy0 * W + ix0;
+    const int nn = g_ok ? n : 0;
+    const int img = nn / HWlo;
+    const int r = nn - img * HWlo;
+    const int oy = r / p.Wlo, ox = r - oy * p.Wlo;
+    const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+    g_base = (long)img * p.Chi * H * W + (long)iy0 * W + ix0;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int iy = iy0 + g_kh * 2 + i;
-        if (iy >= 0 && iy < H) g_rmask |= 1u << i;
-      }
+    for (int i = 0; i < 2; ++i) {
+      const int iy = iy0 + g_kh * 2 + i;
+      if (g_ok && iy >= 0 && iy < H) g_rmask |= 1u << i;
+    }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ix = ix0 + i;
-        if (ix >= 0 && ix < W) g_cmask |= 1u << i;
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int ix = ix0 + i;
+      if (ix >= 0 && ix < W) g_cmask |= 1u << i;
     }
   } else if constexpr (BKD == B_UP) {
     const int n = n0 + g_nl;
     g_ok = n < p.N;
-    if (g_ok) {
-      const int img = n / HWlo;
-      const int r = n - img * HWlo;
-      const int a = r / p.Wlo, b = r - a * p.Wlo;
-      g_base = (long)img * p.Clo * HWlo + (long)(a + py) * p.Wlo + (b + px);
+    const int nn = g_ok ? n : 0;
+    const int img = nn / HWlo;
+    const int r = nn - img * HWlo;
+    const int a = r / p.Wlo, b = r - a * p.Wlo;
+    g_base = (long)img * p.Clo * HWlo + (long)(a + py) * p.Wlo + (b + px);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = a + py - i, col = b + px - i;
-        if (row >= 0 && row < p.Hlo) g_rmask |= 1u << i;
-        if (col >= 0 && col < p.Wlo) g_cmask |= 1u << i;
-      }
+    for (int i = 0; i < 2; ++i) {
+      const int row = a + py - i, col = b + px - i;
+      if (g_ok && row >= 0 && row < p.Hlo) g_rmask |= 1u << i;
+      if (col >= 0 && col < p.Wlo) g_cmask |= 1u << i;
     }
   } else if constexpr (BKD == B_WGRAD) {
     const int n = n0 + g_nl;
     g_ok = n < p.N;
-    g_hi = n >> 4;
-    g_ky = (n >> 2) & 3;
-    g_kx = n & 3;
+    const int nn = g_ok ? n : 0;
+    g_hi = nn >> 4;
+    g_ky = (nn >> 2) & 3;
+    g_kx = nn & 3;
   }
+
+  auto ld4 = [&](const float* base, long off, bool ok) -> float4 {
+    float4 v = *reinterpret_cast<const float4*>(base + (ok ? off : 0));
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
+  };
+  auto ld1 = [&](const float* base, long off, bool ok) -> float {
+    const float v = base[ok ? off : 0];
+    return ok ? v : 0.f;
+  };
 
   auto load_a = [&](int k0) {
     if constexpr (AK == A_KCONTIG) {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
         const int idx = t + i * NT;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < BM * BK / 4) {
-          const int m = m0 + (idx >> 2);
-          const int k = k0 + (idx & 3) * 4;
-          if (m < p.M && k < k_end) {
-            if (p.a_vec && k + 3 < k_end) {
-              const int img = k / p.a_hw;
-              v = *reinterpret_cast<const float4*>(Ap + (long)img * p.a_img + (long)m * p.a_ld +
-                                                   (k - img * p.a_hw));
-            } else {
-              float e[4] = {0.f, 0.f, 0.f, 0.f};
+        const int m = m0 + (idx >> 2);
+        const int k = k0 + (idx & 3) * 4;
+        const bool ok = (A_IT * NT == A_CNT || idx < A_CNT) && m < p.M && k < k_end;
+        if constexpr (VEC) {
+          const int kk = ok ? k : 0;
+          const int img = kk / p.a_hw;
+          ra[i] = ld4(Ap, (long)img * p.a_img + (long)m * p.a_ld + (kk - img * p.a_hw), ok);
+        } else {
+          float e[4];
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const int kk = k + j;
-                if (kk < k_end) {
-                  const int img = kk / p.a_hw;
-                  e[j] = Ap[(long)img * p.a_img + (long)m * p.a_ld + (kk - img * p.a_hw)];
-                }
-              }
-              v = make_float4(e[0], e[1], e[2], e[3]);
-            }
+          for (int j = 0; j < 4; ++j) {
+            const bool okj = ok && (k + j) < k_end;
+            const int kk = okj ? k + j : 0;
+            const int img = kk / p.a_hw;
+            e[j] = ld1(Ap, (long)img * p.a_img + (long)m * p.a_ld + (kk - img * p.a_hw), okj);
           }
+          ra[i] = make_float4(e[0], e[1], e[2], e[3]);
         }
-        ra[i] = v;
       }
     } else {  // A_MCONTIG
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
         const int idx = t + i * NT;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < BM * BK / 4) {
-          const int kr = idx / (BM / 4);
-          const int m = m0 + (idx % (BM / 4)) * 4;
-          const int k = k0 + kr;
-          if (k < k_end && m < p.M) {
-            const float* src = Ap + (long)k * p.a_ld + m;
-            if (p.a_vec && m + 3 < p.M) {
-              v = *reinterpret_cast<const float4*>(src);
-            } else {
-              v.x = src[0];
-              if (m + 1 < p.M) v.y = src[1];
-              if (m + 2 < p.M) v.z = src[2];
-              if (m + 3 < p.M) v.w = src[3];
-            }
-          }
+        const int kr = idx / (BM / 4);
+        const int m = m0 + (idx % (BM / 4)) * 4;
+        const int k = k0 + kr;
+        const bool ok = (A_IT * NT == A_CNT || idx < A_CNT) && k < k_end && m < p.M;
+        const long off = (long)k * p.a_ld + m;
+        if constexpr (VEC) {
+          ra[i] = ld4(Ap, off, ok);
+        } else {
+          ra[i] = make_float4(ld1(Ap, off, ok), ld1(Ap, off + 1, ok && m + 1 < p.M),
+                              ld1(Ap, off + 2, ok && m + 2 < p.M), ld1(Ap, off + 3, ok && m + 3 < p.M));
         }
-        ra[i] = v;
       }
     }
   };
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
         const int idx = t + i * NT;
-        if (idx < BM * BK / 4) {
+        if (A_IT * NT == A_CNT || idx < A_CNT) {
           const int ml = idx >> 2, kq = (idx & 3) * 4;
           As[buf][kq + 0][ml] = ra[i].x;
           As[buf][kq + 1][ml] = ra[i].y;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
         const int idx = t + i * NT;
-        if (idx < BM * BK / 4) {
+        if (A_IT * NT == A_CNT || idx < A_CNT) {
           const int kr = idx / (BM / 4), ml = (idx % (BM / 4)) * 4;
           *reinterpret_cast<float4*>(&As[buf][kr][ml]) = ra[i];
         }
@@ -248,25 +248,21 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         const int k = k0 + (t >> 5) + i * 8;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bn_ok && k < k_end) {
-          if (p.b_vec) {
-            v = *reinterpret_cast<const float4*>(Bp + bn_base + (long)k * p.b_ld);
-          } else {
-            const int n = n0 + (t & 31) * 4;
-            float e[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool ok = bn_ok && k < k_end;
+        if constexpr (VEC) {
+          rb[i] = ld4(Bp, bn_base + (long)k * p.b_ld, ok);
+        } else {
+          const int n = n0 + (t & 31) * 4;
+          float e[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int nn = n + j;
-              if (nn < p.N) {
-                const int img = nn / p.b_hw;
-                e[j] = Bp[(long)img * p.b_img + (long)k * p.b_ld + (nn - img * p.b_hw)];
-              }
-            }
-            v = make_float4(e[0], e[1], e[2], e[3]);
+          for (int j = 0; j < 4; ++j) {
+            const bool okj = ok && (n + j) < p.N;
+            const int nn = okj ? n + j : 0;
+            const int img = nn / p.b_hw;
+            e[j] = ld1(Bp, (long)img * p.b_img + (long)k * p.b_ld + (nn - img * p.b_hw), okj);
           }
+          rb[i] = make_float4(e[0], e[1], e[2], e[3]);
         }
-        rb[i] = v;
       }
     } else if constexpr (BKD == B_KCONTIG) {
 #pragma unroll
@@ -274,89 +270,78 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
         const int idx = t + i * NT;
         const int n = n0 + (idx >> 2);
         const int k = k0 + (idx & 3) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < p.N && k < k_end) {
-          if (p.b_vec && k + 3 < k_end) {
-            const int img = k / p.b_hw;
-            v = *reinterpret_cast<const float4*>(Bp + (long)img * p.b_img + (long)n * p.b_ld +
-                                                 (k - img * p.b_hw));
-          } else {
-            float e[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool ok = n < p.N && k < k_end;
+        if constexpr (VEC) {
+          const int kk = ok ? k : 0;
+          const int img = kk / p.b_hw;
+          rb[i] = ld4(Bp, (long)img * p.b_img + (long)n * p.b_ld + (kk - img * p.b_hw), ok);
+        } else {
+          float e[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int kk = k + j;
-              if (kk < k_end) {
-                const int img = kk / p.b_hw;
-                e[j] = Bp[(long)img * p.b_img + (long)n * p.b_ld + (kk - img * p.b_hw)];
-              }
-            }
-            v = make_float4(e[0], e[1], e[2], e[3]);
+          for (int j = 0; j < 4; ++j) {
+            const bool okj = ok && (k + j) < k_end;
+            const int kk = okj ? k + j : 0;
+            const int img = kk / p.b_hw;
+            e[j] = ld1(Bp, (long)img * p.b_img + (long)n * p.b_ld + (kk - img * p.b_hw), okj);
           }
+          rb[i] = make_float4(e[0], e[1], e[2], e[3]);
         }
-        rb[i] = v;
       }
     } else if constexpr (BKD == B_DOWN) {
       // k = hi*16 + ky*4 + kx ; one hi channel per stage
       const int hi = k0 >> 4;
-      const float* src = Bp + g_base + (long)hi * H * W + (long)(g_kh * 2) * W;
-      const bool ok = g_ok && hi < p.Chi;
+      const long base = g_base + (long)hi * H * W + (long)(g_kh * 2) * W;
+      const bool okc = hi < p.Chi;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v = 0.f;
-          if (ok && ((g_rmask >> i) & 1u) && ((g_cmask >> j) & 1u)) v = src[i * W + j];
-          rg[i * 4 + j] = v;
-        }
+        for (int j = 0; j < 4; ++j)
+          rg[i * 4 + j] = ld1(Bp, base + i * W + j, okc && ((g_rmask >> i) & 1u) && ((g_cmask >> j) & 1u));
     } else if constexpr (BKD == B_UP) {
       // k = lo*4 + ty*2 + tx ; four lo channels per stage, this thread two of them
       const int lo0 = (k0 >> 2) + g_kh * 2;
 #pragma unroll
       for (int l = 0; l < 2; ++l) {
         const int lo = lo0 + l;
-        const float* src = Bp + g_base + (long)lo * HWlo;
-        const bool ok = g_ok && lo < p.Clo;
+        const long base = g_base + (long)lo * HWlo;
+        const bool okc = lo < p.Clo;
 #pragma unroll
         for (int ty = 0; ty < 2; ++ty)
 #pragma unroll
-          for (int tx = 0; tx < 2; ++tx) {
-            float v = 0.f;
-            if (ok && ((g_rmask >> ty) & 1u) && ((g_cmask >> tx) & 1u)) v = src[-ty * p.Wlo - tx];
-            rg[l * 4 + ty * 2 + tx] = v;
-          }
+          for (int tx = 0; tx < 2; ++tx)
+            rg[l * 4 + ty * 2 + tx] =
+                ld1(Bp, base - ty * p.Wlo - tx, okc && ((g_rmask >> ty) & 1u) && ((g_cmask >> tx) & 1u));
       }
     } else {  // B_WGRAD: k = (img, oy, ox) pixel index, n = (hi, ky, kx)
       const int kb = k0 + g_kh * 8;
       if ((p.Wlo & 7) == 0) {
         // 8 consecutive pixels share (img, oy)
-        const int img = kb / HWlo;
-        const int r = kb - img * HWlo;
+        const bool okk = g_ok && kb < k_end;
+        const int kc = okk ? kb : 0;
+        const int img = kc / HWlo;
+        const int r = kc - img * HWlo;
         const int oy = r / p.Wlo, ox0 = r - oy * p.Wlo;
         const int iy = 2 * oy - 1 + g_ky;
-        const bool ok = g_ok && kb < k_end && iy >= 0 && iy < H;
+        const bool ok = okk && iy >= 0 && iy < H;
         const int ixb = 2 * ox0 - 1 + g_kx;
-        const float* src = Bp + ((long)img * p.Chi + g_hi) * H * W + (long)iy * W + ixb;
+        const long base = ((long)img * p.Chi + g_hi) * H * W + (long)iy * W + ixb;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int ix = ixb + 2 * j;
-          float v = 0.f;
-          if (ok && ix >= 0 && ix < W) v = src[2 * j];
-          rg[j] = v;
+          rg[j] = ld1(Bp, base + 2 * j, ok && ix >= 0 && ix < W);
         }
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int k = kb + j;
-          float v = 0.f;
-          if (g_ok && k < k_end) {
-            const int img = k / HWlo;
-            const int r = k - img * HWlo;
-            const int oy = r / p.Wlo, ox = r - oy * p.Wlo;
-            const int iy = 2 * oy - 1 + g_ky, ix = 2 * ox - 1 + g_kx;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-              v = Bp[((long)img * p.Chi + g_hi) * H * W + (long)iy * W + ix];
-          }
-          rg[j] = v;
+          const bool okk = g_ok && k < k_end;
+          const int kc = okk ? k : 0;
+          const int img = kc / HWlo;
+          const int r = kc - img * HWlo;
+          const int oy = r / p.Wlo, ox = r - oy * p.Wlo;
+          const int iy = 2 * oy - 1 + g_ky, ix = 2 * ox - 1 + g_kx;
+          rg[j] = ld1(Bp, ((long)img * p.Chi + g_hi) * H * W + (long)iy * W + ix,
+                      okk && iy >= 0 && iy < H && ix >= 0 && ix < W);
         }
       }
     }
@@ -432,58 +417,164 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 
   // ---------------------------------------------------------------- epilogue
   // C/D map of 32x32 MFMA: col(n) = lane & 31, row(m) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn0 + j * 32 + l31;
-    if (n >= p.N) continue;
-    float* cb;
+  if constexpr (VEC && EK != E_UP) {
+    // Stage 16-row slices of the wave tile through LDS (the operand buffers are free after the
+    // final barrier) and write whole 16-byte pieces: 4x fewer, 4x wider stores / residual loads.
+    constexpr int COLS = TN * 32;
+    constexpr int F4R = COLS / 4;        // float4 per row
+    constexpr int RPI = 64 / F4R;        // rows per wave-instruction
+    float* sw = smem + wave * (16 * COLS);
+    const int c4 = lane % F4R, rsub = lane / F4R;
+    const int n = n0 + wn0 + c4 * 4;
+    const bool nok = n < p.N;
+    float* cb = p.C;
     const float* rbp = nullptr;
     long mstride;
     if constexpr (EK == E_BATCHED) {
-      const int img = n / p.c_hw;
-      const int pn = n - img * p.c_hw;
-      cb = p.C + (long)img * p.c_img + pn;
+      const int nn = nok ? n : 0;
+      const int img = nn / p.c_hw;
+      const int pn = nn - img * p.c_hw;
+      cb += (long)img * p.c_img + pn;
       if (p.res) rbp = p.res + (long)img * p.res_img + pn;
       mstride = p.c_ld;
-    } else if constexpr (EK == E_SLAB) {
-      cb = p.C + (long)z * p.M * p.N + n;
+    } else {
+      cb += (long)z * p.M * p.N + n;
       mstride = p.N;
-    } else {  // E_UP
-      const int img = n / HWlo;
-      const int r = n - img * HWlo;
-      const int a = r / p.Wlo, b = r - a * p.Wlo;
-      cb = p.C + (long)img * p.Chi * H * W + (long)(2 * a + py) * W + (2 * b + px);
-      mstride = (long)H * W;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < p.M) {
-          float v = acc[i][j][r];
-          if constexpr (EK == E_BATCHED) {
-            if (p.bias) v += p.bias[m];
-            if (rbp) v += rbp[(long)m * mstride];
-            if (p.beta) v += cb[(long)m * mstride];
+      for (int q = 0; q < 2; ++q) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r8 = 0; r8 < 8; ++r8) {
+            const int r = q * 8 + r8;
+            const int row = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lh;
+            sw[row * COLS + j * 32 + l31] = acc[i][j][r];
           }
-          cb[(long)m * mstride] = v;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 16 / RPI; ++it) {
+          const int row = it * RPI + rsub;
+          float4 v = *reinterpret_cast<const float4*>(&sw[row * COLS + c4 * 4]);
+          const int m = m0 + wm0 + i * 32 + q * 16 + row;
+          if (nok && m < p.M) {
+            float* dst = cb + (long)m * mstride;
+            if constexpr (EK == E_BATCHED) {
+              if (p.bias) {
+                const float bv = p.bias[m];
+                v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+              }
+              if (rbp) {
+                const float4 rv = *reinterpret_cast<const float4*>(rbp + (long)m * mstride);
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+              }
+              if (p.beta) {
+                const float4 ov = *reinterpret_cast<const float4*>(dst);
+                v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
+              }
+            }
+            *reinterpret_cast<float4*>(dst) = v;
+          }
         }
       }
+  } else {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn0 + j * 32 + l31;
+      if (n >= p.N) continue;
+      float* cb;
+      const float* rbp = nullptr;
+      long mstride;
+      if constexpr (EK == E_BATCHED) {
+        const int img = n / p.c_hw;
+        const int pn = n - img * p.c_hw;
+        cb = p.C + (long)img * p.c_img + pn;
+        if (p.res) rbp = p.res + (long)img * p.res_img + pn;
+        mstride = p.c_ld;
+      } else if constexpr (EK == E_SLAB) {
+        cb = p.C + (long)z * p.M * p.N + n;
+        mstride = p.N;
+      } else {  // E_UP
+        const int img = n / HWlo;
+        const int r = n - img * HWlo;
+        const int a = r / p.Wlo, b = r - a * p.Wlo;
+        cb = p.C + (long)img * p.Chi * H * W + (long)(2 * a + py) * W + (2 * b + px);
+        mstride = (long)H * W;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < p.M) {
+            float v = acc[i][j][r];
+            if constexpr (EK == E_BATCHED) {
+              if (p.bias) v += p.bias[m];
+              if (rbp) v += rbp[(long)m * mstride];
+              if (p.beta) v += cb[(long)m * mstride];
+            }
+            cb[(long)m * mstride] = v;
+          }
+        }
+    }
   }
 }
 
 // out[i] = (beta ? out[i] : 0) + sum_z slab[z][i] (+ bias_n[i % N])   (fixed order => deterministic)
+// transpose_m > 0: the slab is [M = transpose_m][N] and `out` is [N][M]
+__device__ __forceinline__ long out_index(long i, int N, int transpose_m) {
+  if (transpose_m <= 0) return i;
+  const long m = i / N, n = i - m * N;
+  return n * transpose_m + m;
+}
+
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                      const float* __restrict__ bias_n, long MN, int N, int splits,
-                                     int beta) {
+                                     int beta, int transpose_m) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= MN) return;
   float s = 0.f;
   for (int z = 0; z < splits; ++z) s += slab[(long)z * MN + i];
   if (bias_n) s += bias_n[i % N];
-  if (beta) s += out[i];
-  out[i] = s;
+  const long o = out_index(i, N, transpose_m);
+  if (beta) s += out[o];
+  out[o] = s;
+}
+
+// Many slabs, few outputs: 64 outputs x 16 z-lanes per block, each z-lane sums every 16th
+// slab (4 independent accumulators), then a fixed-order LDS combine.
+__global__ __launch_bounds__(1024) void splitk_reduce_wide_kernel(const float* __restrict__ slab,
+                                                                  float* __restrict__ out,
+                                                                  const float* __restrict__ bias_n, long MN,
+                                                                  int N, int splits, int beta, int transpose_m) {
+  __shared__ float sm[16][65];
+  const int il = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + il;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < MN) {
+    int z = zl;
+    for (; z + 48 < splits; z += 64) {
+      s0 += slab[(long)z * MN + i];
+      s1 += slab[(long)(z + 16) * MN + i];
+      s2 += slab[(long)(z + 32) * MN + i];
+      s3 += slab[(long)(z + 48) * MN + i];
+    }
+    for (; z < splits; z += 16) s0 += slab[(long)z * MN + i];
+  }
+  sm[zl][il] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (zl == 0 && i < MN) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += sm[k][il];
+    if (bias_n) s += bias_n[i % N];
+    const long o = out_index(i, N, transpose_m);
+    if (beta) s += out[o];
+    out[o] = s;
+  }
 }
 
 // Wp[phase][lo*4 + ty*2 + tx][hi] = W[lo][hi][1-py+2ty][1-px+2tx]
@@ -504,21 +595,29 @@ __global__ void pack_up_weights_kernel(const float* __restrict__ w, float* __res
   wp[i] = w[((long)lo * Chi + hi) * 16 + ky * 4 + kx];
 }
 
-template <int AK, int BKD, int EK>
-int launch_gemm(const GemmP& p, int zdim, hipStream_t st, const char* what) {
+template <int AK, int BKD, int EK, bool VEC>
+int launch_gemm_v(const GemmP& p, int zdim, hipStream_t st, const char* what) {
   const int ntiles = cdiv(p.N, BN);
   dim3 block(NT);
   if (p.M > 64) {
     dim3 grid(cdiv(p.M, 128) * ntiles, 1, zdim);
-    hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, VEC>), grid, block, 0, st, p);
   } else if (p.M > 32) {
     dim3 grid(cdiv(p.M, 64) * ntiles, 1, zdim);
-    hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK, VEC>), grid, block, 0, st, p);
   } else {
     dim3 grid(ntiles, 1, zdim);
-    hipLaunchKernelGGL((gemm_kernel<32, 1, 4, AK, BKD, EK>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<32, 1, 4, AK, BKD, EK, VEC>), grid, block, 0, st, p);
   }
   return check_launch(what);
+}
+
+// p.a_vec / p.b_vec / p.c_vec say whether 16-byte accesses are legal for that operand; the
+// all-vector kernel needs all three (gather operands are scalar by nature and always "legal").
+template <int AK, int BKD, int EK>
+int launch_gemm(const GemmP& p, int zdim, hipStream_t st, const char* what) {
+  if (p.a_vec && p.b_vec && p.c_vec) return launch_gemm_v<AK, BKD, EK, true>(p, zdim, st, what);
+  return launch_gemm_v<AK, BKD, EK, false>(p, zdim, st, what);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -527,7 +626,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 inline int pick_splits(int M, int N, int K, size_t ws_bytes, int* k_per_split) {
   const long tiles = (long)cdiv(M, M > 64 ? 128 : (M > 32 ? 64 : 32)) * cdiv(N, BN);
   const int stages = cdiv(K, BK);
-  long want = (2048 + tiles - 1) / tiles;
+  long want = (1024 + tiles - 1) / tiles;
   if (want < 1) want = 1;
   if (want > stages) want = stages;
   const size_t slab = (size_t)M * N * sizeof(float);
@@ -537,11 +636,26 @@ inline int pick_splits(int M, int N, int K, size_t ws_bytes, int* k_per_split) {
   return cdiv(K, per);
 }
 
+}  // namespace
+
+namespace wfae {
+int slab_reduce(const float* slab, float* out, const float* bias_n, long MN, int N, int splits, int beta,
+                hipStream_t st, int transpose_m) {
+  if (splits >= 16) {
+    hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3(cdiv(MN, 64)), dim3(1024), 0, st, slab, out, bias_n, MN, N,
+                       splits, beta, transpose_m);
+  } else {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(MN, 256)), dim3(256), 0, st, slab, out, bias_n, MN, N,
+                       splits, beta, transpose_m);
+  }
+  return check_launch("slab_reduce");
+}
+}  // namespace wfae
+
+namespace {
 int splitk_finish(const float* slab, float* out, const float* bias_n, long MN, int N, int splits,
-                  int beta, hipStream_t st) {
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(MN, 256)), dim3(256), 0, st, slab, out, bias_n,
-                     MN, N, splits, beta);
-  return check_launch("splitk_reduce");
+                  int beta, hipStream_t st, int transpose_m = 0) {
+  return wfae::slab_reduce(slab, out, bias_n, MN, N, splits, beta, st, transpose_m);
 }
 
 }  // namespace
@@ -562,6 +676,7 @@ int wfae_conv1x1_fwd(const float* x, const float* w, const float* bias, const fl
   p.c_hw = HW; p.c_img = (long)Cout * HW; p.c_ld = HW; p.res_img = res_img_stride;
   p.a_vec = (Cin % 4 == 0) && aligned16(w);
   p.b_vec = (HW % 4 == 0) && aligned16(x);
+  p.c_vec = (HW % 4 == 0) && aligned16(y) && (!res || (aligned16(res) && res_img_stride % 4 == 0));
   return launch_gemm<A_KCONTIG, B_NCONTIG, E_BATCHED>(p, 1, (hipStream_t)stream, "conv1x1_fwd");
 }
 
@@ -578,6 +693,7 @@ int wfae_conv1x1_bwd_data(const float* dy, const float* w, float* dx, int NB, in
   p.c_hw = HW; p.c_img = (long)Cin * HW; p.c_ld = HW;
   p.a_vec = (Cin % 4 == 0) && aligned16(w);
   p.b_vec = (HW % 4 == 0) && aligned16(dy);
+  p.c_vec = (HW % 4 == 0) && aligned16(dx);
   return launch_gemm<A_MCONTIG, B_NCONTIG, E_BATCHED>(p, 1, (hipStream_t)stream, "conv1x1_bwd_data");
 }
 
@@ -589,16 +705,25 @@ int wfae_conv1x1_bwd_weight(const float* dy, const float* x, float* dw, int NB, 
   const size_t slab = (size_t)Cout * Cin * sizeof(float);
   WFAE_REQUIRE(ws && ws_bytes >= slab, WFAE_ERR_WORKSPACE, "conv1x1_bwd_weight: workspace %zu < %zu", ws_bytes, slab);
   GemmP p = {};
-  p.A = dy; p.B = x; p.C = (float*)ws;
-  p.M = Cout; p.N = Cin; p.K = NB * HW;
-  p.a_hw = HW; p.a_img = (long)Cout * HW; p.a_ld = HW;
-  p.b_hw = HW; p.b_img = (long)Cin * HW; p.b_ld = HW;
-  p.a_vec = (HW % 4 == 0) && aligned16(dy);
-  p.b_vec = (HW % 4 == 0) && aligned16(x);
+  p.K = NB * HW;
+  // The N tile is 128 wide: when Cin is the small side (< 128 and < Cout) compute dW^T = X dY^T
+  // (M = Cin, N = Cout) so no MFMA work is spent on padding; the slab reduce writes it back transposed.
+  const bool swap = Cin < Cout && Cin < 128;
+  const float* a = swap ? x : dy;
+  const float* b = swap ? dy : x;
+  const int Ma = swap ? Cin : Cout, Nb = swap ? Cout : Cin;
+  p.A = a; p.B = b; p.C = (float*)ws;
+  p.M = Ma; p.N = Nb;
+  p.a_hw = HW; p.a_img = (long)Ma * HW; p.a_ld = HW;
+  p.b_hw = HW; p.b_img = (long)Nb * HW; p.b_ld = HW;
+  p.a_vec = (HW % 4 == 0) && aligned16(a);
+  p.b_vec = (HW % 4 == 0) && aligned16(b);
+  p.c_vec = (Nb % 4 == 0) && aligned16(ws);
   const int splits = pick_splits(p.M, p.N, p.K, ws_bytes, &p.k_per_split);
   int rc = launch_gemm<A_KCONTIG, B_KCONTIG, E_SLAB>(p, splits, (hipStream_t)stream, "conv1x1_bwd_weight");
   if (rc) return rc;
-  return splitk_finish((float*)ws, dw, nullptr, (long)Cout * Cin, Cin, splits, accumulate, (hipStream_t)stream);
+  return splitk_finish((float*)ws, dw, nullptr, (long)Cout * Cin, Nb, splits, accumulate, (hipStream_t)stream,
+                       swap ? Ma : 0);
 }
 
 int wfae_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In,
@@ -614,6 +739,7 @@ int wfae_linear_fwd(const float* x, const float* w, const float* bias, float* y,
   p.b_hw = In; p.b_img = 0; p.b_ld = In;
   p.a_vec = (In % 4 == 0) && aligned16(x);
   p.b_vec = (In % 4 == 0) && aligned16(w);
+  p.c_vec = (Out % 4 == 0) && aligned16(ws);
   const int splits = pick_splits(p.M, p.N, p.K, ws_bytes, &p.k_per_split);
   int rc = launch_gemm<A_KCONTIG, B_KCONTIG, E_SLAB>(p, splits, (hipStream_t)stream, "linear_fwd");
   if (rc) return rc;
@@ -632,6 +758,7 @@ int wfae_linear_bwd_data(const float* dy, const float* w, float* dx, int B, int 
   p.c_hw = In; p.c_img = 0; p.c_ld = In;
   p.a_vec = (Out % 4 == 0) && aligned16(dy);
   p.b_vec = (In % 4 == 0) && aligned16(w);
+  p.c_vec = (In % 4 == 0) && aligned16(dx);
   return launch_gemm<A_KCONTIG, B_NCONTIG, E_BATCHED>(p, 1, (hipStream_t)stream, "linear_bwd_data");
 }
 
@@ -648,6 +775,7 @@ int wfae_linear_bwd_weight(const float* dy, const float* x, float* dw, int B, in
   p.beta = accumulate ? 1 : 0;
   p.a_vec = (Out % 4 == 0) && aligned16(dy);
   p.b_vec = (In % 4 == 0) && aligned16(x);
+  p.c_vec = (In % 4 == 0) && aligned16(dw);
   return launch_gemm<A_MCONTIG, B_NCONTIG, E_BATCHED>(p, 1, (hipStream_t)stream, "linear_bwd_weight");
 }
 
@@ -663,6 +791,8 @@ int wfae_conv4x4s2_down(const float* hi, const float* w, float* lo, int NB, int 
   p.a_hw = p.K; p.a_img = 0; p.a_ld = p.K;
   p.c_hw = Hlo * Wlo; p.c_img = (long)Clo * Hlo * Wlo; p.c_ld = Hlo * Wlo;
   p.a_vec = aligned16(w);
+  p.b_vec = 1;
+  p.c_vec = ((Hlo * Wlo) % 4 == 0) && aligned16(lo);
   p.Chi = Chi; p.Clo = Clo; p.Hlo = Hlo; p.Wlo = Wlo;
   return launch_gemm<A_KCONTIG, B_DOWN, E_BATCHED>(p, 1, (hipStream_t)stream, "conv4x4s2_down");
 }
@@ -684,6 +814,8 @@ int wfae_conv4x4s2_up(const float* lo, const float* w, float* hi, int NB, int Ch
   p.M = Chi; p.N = NB * Hlo * Wlo; p.K = Clo * 4; p.k_per_split = p.K;
   p.a_ld = Chi;
   p.a_vec = (Chi % 4 == 0) && aligned16(ws);
+  p.b_vec = 1;
+  p.c_vec = 1;
   p.Chi = Chi; p.Clo = Clo; p.Hlo = Hlo; p.Wlo = Wlo;
   return launch_gemm<A_MCONTIG, B_UP, E_UP>(p, 4, st, "conv4x4s2_up");
 }
@@ -702,6 +834,8 @@ int wfae_conv4x4s2_wgrad(const float* lo, const float* hi, float* dw, int NB, in
   p.M = Clo; p.N = Chi * 16; p.K = NB * HWlo;
   p.a_hw = HWlo; p.a_img = (long)Clo * HWlo; p.a_ld = HWlo;
   p.a_vec = (HWlo % 4 == 0) && aligned16(lo);
+  p.b_vec = 1;
+  p.c_vec = aligned16(ws);
   p.Chi = Chi; p.Clo = Clo; p.Hlo = Hlo; p.Wlo = Wlo;
   const int splits = pick_splits(p.M, p.N, p.K, ws_bytes, &p.k_per_split);
   int rc = launch_gemm<A_KCONTIG, B_WGRAD, E_SLAB>(p, splits, (hipStream_t)stream, "conv4x4s2_wgrad");

@@ -19,7 +19,7 @@ Extra objects in the line:
                 hbm_fraction  = 7.365 GB/frame * fps / 8 TB/s.
   cpu_baseline  the oracle (CPU restatement of the reference path, kind "port")
                 timed on this box's host cores on a bounded sample: one full
-                train step at 384x384, batch 1 (rank 0, N=1 only).
+                train step at 384x384, batch 4 = BASELINE configs[0] (rank 0, N=1 only).
 """
 from __future__ import annotations
 
@@ -181,8 +181,14 @@ def main():
                 ach, peak, unit, bound = fl / (ms * 1e-3) / 1e12, PEAK_FP32 / 1e12, "TFLOP/s", "mfma"
             else:
                 ach, peak, unit, bound = by / (ms * 1e-3) / 1e9, PEAK_HBM / 1e9, "GB/s", "hbm"
+            traffic = None
+            try:  # HBM bytes per launch from the committed PMC run of this same command (profiles/)
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    traffic = json.load(f).get(name, {}).get("hbm_bytes_per_launch")
+            except OSError:
+                pass
             out["roofline"] = {"kernel": KERNEL_OF.get(name, name), "entry_point": name, "bound": bound,
-                               "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+                               "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic,
                                "launches": calls, "avg_launch_ms": ms / calls,
                                "share_of_kernel_time": ms / tot_ms}
             out["kernel_breakdown"] = [
@@ -192,7 +198,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             del net, opt, dp
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(args.img_size, 1)
+            out["cpu_baseline"] = cpu_baseline(args.img_size, 4)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -111,6 +111,15 @@ int wfae_dconv_bwd_weight(const float* dy, const float* x, float* dw, int NB, in
                           int H, int W, int KS, int stride, int pad, int groups, int accumulate,
                           void* ws, size_t ws_bytes, wfae_stream_t stream);
 
+/* grouped 3x3 pad-1 stride-1 convolution with Cin == Cout == C and C/groups in {4,8,16,32}
+ * (the Bottleneck middle conv, ae_64x8x8_lin.py:17), register-blocked kernels.
+ * fwd: transposed=0 -> y = conv(x, w); transposed=1 -> data gradient dx = conv^T(dy, w) (pass dy as x).
+ * bwd_weight: dw[(g,oc),ci,ky,kx] as a per-group fp32-MFMA implicit GEMM over the pixels. */
+int wfae_gconv3x3_fwd(const float* x, const float* w, float* y, int NB, int C, int H, int W, int groups,
+                      int transposed, void* ws, size_t ws_bytes, wfae_stream_t stream);
+int wfae_gconv3x3_bwd_weight(const float* dy, const float* x, float* dw, int NB, int C, int H, int W,
+                             int groups, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
+
 /* ---- BatchNorm2d (+GELU) --------------------------------------------------
  * nn.BatchNorm2d(eps=1e-5, momentum=0.1) followed by nn.GELU()
  * (ae_64x8x8_lin.py:14,16,18,32,43).

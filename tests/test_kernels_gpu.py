@@ -119,6 +119,24 @@ def test_dconv3x3(ops, dev, nb, cin, cout, h, w, groups):
     assert relerr(dw, wr.grad) < TOL
 
 
+@pytest.mark.parametrize("nb,c,h,w", [(2, 32, 16, 16), (1, 64, 24, 40), (2, 128, 24, 24), (2, 256, 8, 8), (1, 256, 24, 24),
+                                      (3, 32, 7, 9), (1, 64, 33, 35)])
+def test_gconv3x3_blocked(ops, dev, nb, c, h, w):
+    """register-blocked grouped 3x3 (4/8/16/32 channels per group): fwd, dgrad, MFMA wgrad"""
+    groups = 8
+    x, wt, dy = rnd((nb, c, h, w), 1), rnd((c, c // groups, 3, 3), 2, -0.3, 0.3), rnd((nb, c, h, w), 3)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, padding=1, groups=groups)
+    ref.backward(dy)
+    assert relerr(ops.gconv3x3_fwd(x.to(dev), wt.to(dev), groups, False), ref) < TOL
+    assert relerr(ops.gconv3x3_fwd(dy.to(dev), wt.to(dev), groups, True), xr.grad) < TOL
+    dw = torch.empty_like(wt, device=dev)
+    ops.gconv3x3_bwd_weight(dy.to(dev), x.to(dev), dw, groups)
+    assert relerr(dw, wr.grad) < TOL
+    ops.gconv3x3_bwd_weight(dy.to(dev), x.to(dev), dw, groups, accumulate=True)
+    assert relerr(dw, 2 * wr.grad) < TOL
+
+
 @pytest.mark.parametrize("nb,cout,h,w", [(2, 16, 16, 24), (1, 256, 64, 64), (3, 32, 20, 12)])
 def test_dconv4x4s2_cin1(ops, dev, nb, cout, h, w):
     x, wt, dy = rnd((nb, 1, h, w), 1, 0, 1), rnd((cout, 1, 4, 4), 2, -0.3, 0.3), rnd((nb, cout, h // 2, w // 2), 3)

@@ -91,9 +91,9 @@ def main():
             dw = torch.empty_like(w)
             fl = 2 * B * h * h * mid * (mid // 8) * 9
             by = 4 * 2 * B * h * h * mid
-            for nm, fn in [("fwd", lambda: ops.dconv_fwd(x, w, None, 3, 1, 1, 8)),
-                           ("dgrad", lambda: ops.dconv_bwd_data(dy, w, mid, 3, 1, 8)),
-                           ("wgrad", lambda: ops.dconv_bwd_weight(dy, x, dw, 3, 1, 1, 8))]:
+            for nm, fn in [("fwd", lambda: ops.gconv3x3_fwd(x, w, 8, False)),
+                           ("dgrad", lambda: ops.gconv3x3_fwd(dy, w, 8, True)),
+                           ("wgrad", lambda: ops.gconv3x3_bwd_weight(dy, x, dw, 8))]:
                 ms = timeit(fn, R)
                 report(f"gconv3x3 {nm:5s} {mid}ch g8 @{h}", ms, fl, by)
                 acc("dconv_" + nm, ms, 4)

@@ -78,4 +78,8 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 int slab_reduce(const float* slab, float* out, const float* bias_n, long MN, int N, int splits, int beta,
                 hipStream_t st, int transpose_m = 0);
 
+// pixel-parallel VALU weight gradient of the grouped 3x3 conv (dconv.hip); WFAE_ERR_UNSUPPORTED if the shape is not covered
+int gconv3_wgrad_valu(const float* dy, const float* x, float* dw, int NB, int C, int H, int W, int groups,
+                      int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+
 }  // namespace wfae

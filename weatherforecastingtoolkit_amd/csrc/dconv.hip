@@ -349,3 +349,258 @@ int wfae_dconv_bwd_weight(const float* dy, const float* x, float* dw, int NB, in
 }
 
 }  // extern "C"
+
+// =====================================================================================
+// Grouped 3x3 'same' convolution of Bottleneck (ae_64x8x8_lin.py:17), register-blocked:
+// each thread owns PY x 2 output pixels and ALL CPG output channels of its group, the
+// input patch (+halo) of 8 channels at a time is staged in LDS with coalesced row reads,
+// weights are pre-packed [g][ci][tap][oc] so the CPG weights of one (ci,tap) are one wide
+// scalar load.  The same kernel computes the data gradient from transposed/flipped packing.
+// =====================================================================================
+namespace {
+
+template <int CPG, int PY>
+__global__ __launch_bounds__(256) void gconv3_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                     float* __restrict__ y, int C, int H, int W, int tiles_x) {
+  constexpr int TH = 16 * PY, TW = 32;
+  constexpr int CIB = CPG < 8 ? CPG : 8;
+  constexpr int IH = TH + 2, IWU = TW + 2, IW = 36;
+  __shared__ __attribute__((aligned(16))) float xs[CIB][IH][IW];
+  const int t = threadIdx.x;
+  const int tx = t & 15, ty = t >> 4;
+  const int oy0 = (blockIdx.x / tiles_x) * TH, ox0 = (blockIdx.x % tiles_x) * TW;
+  const int g = blockIdx.y, n = blockIdx.z;
+  const float* xg = x + ((long)n * C + (long)g * CPG) * H * W;
+
+  float acc[PY][2][CPG];
+#pragma unroll
+  for (int a = 0; a < PY; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int o = 0; o < CPG; ++o) acc[a][b][o] = 0.f;
+
+  for (int ci0 = 0; ci0 < CPG; ci0 += CIB) {
+    __syncthreads();
+    for (int idx = t; idx < CIB * IH * IWU; idx += 256) {
+      const int c = idx / (IH * IWU);
+      const int r = idx - c * (IH * IWU);
+      const int ry = r / IWU, rx = r - ry * IWU;
+      const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
+      float v = 0.f;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = xg[((long)(ci0 + c) * H + iy) * W + ix];
+      xs[c][ry][rx] = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < CIB; ++c) {
+      float in[PY + 2][4];
+#pragma unroll
+      for (int r = 0; r < PY + 2; ++r) {
+        const float2 a = *reinterpret_cast<const float2*>(&xs[c][ty * PY + r][2 * tx]);
+        const float2 b = *reinterpret_cast<const float2*>(&xs[c][ty * PY + r][2 * tx + 2]);
+        in[r][0] = a.x; in[r][1] = a.y; in[r][2] = b.x; in[r][3] = b.y;
+      }
+      const float* __restrict__ wc = wp + ((long)(g * CPG + ci0 + c) * 9) * CPG;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int o = 0; o < CPG; ++o) {
+            const float w = wc[(ky * 3 + kx) * CPG + o];
+#pragma unroll
+            for (int a = 0; a < PY; ++a)
+#pragma unroll
+              for (int b = 0; b < 2; ++b) acc[a][b][o] = fmaf(in[a + ky][b + kx], w, acc[a][b][o]);
+          }
+    }
+  }
+  const int ox = ox0 + 2 * tx;
+#pragma unroll
+  for (int a = 0; a < PY; ++a) {
+    const int oy = oy0 + ty * PY + a;
+    if (oy < H && ox < W) {
+      float* yp = y + (((long)n * C + (long)g * CPG) * H + oy) * W + ox;
+#pragma unroll
+      for (int o = 0; o < CPG; ++o) {
+        if (ox + 1 < W && (W & 1) == 0)
+          *reinterpret_cast<float2*>(yp + (long)o * H * W) = make_float2(acc[a][0][o], acc[a][1][o]);
+        else {
+          yp[(long)o * H * W] = acc[a][0][o];
+          if (ox + 1 < W) yp[(long)o * H * W + 1] = acc[a][1][o];
+        }
+      }
+    }
+  }
+}
+
+// wp[((g*CPG + i)*9 + tap)*CPG + o]:  forward  i = ci, o = oc : w[g*CPG+o][i][tap]
+//                                     transposed (dgrad) i = oc_orig, o = ci_orig : w[g*CPG+i][o][8-tap]
+__global__ void gconv3_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int CPG,
+                                   int transposed) {
+  const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i0 >= C * CPG * 9) return;
+  const int o = i0 % CPG;
+  int r = i0 / CPG;
+  const int tap = r % 9;
+  r /= 9;
+  const int i = r % CPG, g = r / CPG;
+  wp[i0] = transposed ? w[((long)(g * CPG + i) * CPG + o) * 9 + (8 - tap)]
+                      : w[((long)(g * CPG + o) * CPG + i) * 9 + tap];
+}
+
+template <int CPG, int PY>
+int launch_gconv3(const float* x, const float* wp, float* y, int NB, int C, int H, int W, hipStream_t st) {
+  const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 16 * PY);
+  hipLaunchKernelGGL((gconv3_kernel<CPG, PY>), dim3(tiles_x * tiles_y, C / CPG, NB), dim3(256), 0, st, x, wp, y, C, H,
+                     W, tiles_x);
+  return check_launch("gconv3");
+}
+
+}  // namespace
+
+extern "C" int wfae_gconv3x3_fwd(const float* x, const float* w, float* y, int NB, int C, int H, int W, int groups,
+                                 int transposed, void* ws, size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(x && w && y, WFAE_ERR_NULL_POINTER, "gconv3x3_fwd: null pointer");
+  WFAE_REQUIRE(NB > 0 && NB <= 65535 && C > 0 && H > 0 && W > 0 && groups > 0 && C % groups == 0, WFAE_ERR_BAD_SHAPE,
+               "gconv3x3_fwd: bad shape");
+  const int cpg = C / groups;
+  WFAE_REQUIRE(cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32, WFAE_ERR_UNSUPPORTED,
+               "gconv3x3_fwd: %d channels per group (4/8/16/32 built; use wfae_dconv_fwd otherwise)", cpg);
+  const size_t need = (size_t)C * cpg * 9 * sizeof(float);
+  WFAE_REQUIRE(ws && ws_bytes >= need, WFAE_ERR_WORKSPACE, "gconv3x3_fwd: workspace %zu < %zu", ws_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gconv3_pack_kernel, dim3(cdiv((long)C * cpg * 9, 256)), dim3(256), 0, st, w, (float*)ws, C, cpg,
+                     transposed);
+  int rc = check_launch("gconv3_pack");
+  if (rc) return rc;
+  const float* wp = (const float*)ws;
+  switch (cpg) {
+    case 4: return launch_gconv3<4, 2>(x, wp, y, NB, C, H, W, st);
+    case 8: return launch_gconv3<8, 2>(x, wp, y, NB, C, H, W, st);
+    case 16: return launch_gconv3<16, 2>(x, wp, y, NB, C, H, W, st);
+    default: return launch_gconv3<32, 1>(x, wp, y, NB, C, H, W, st);
+  }
+}
+
+// =====================================================================================
+// Grouped 3x3 weight gradient for 4 / 8 / 16 channels per group: pixel-parallel.
+// Every lane owns one pixel column of the tile and accumulates the full OCW x CPG x 9 = 144
+// partial products of its wave's (group, output-channel chunk) in registers while the wave walks
+// the rows of the tile (x patch + halo in LDS, dy read coalesced from HBM); the 64 lanes are
+// combined once per block with wavefront shuffles and written as one partial slab row.
+// =====================================================================================
+namespace {
+
+template <int CPG, int OCW>
+__global__ __launch_bounds__(256, 2) void gconv3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              float* __restrict__ part, int NB, int C, int H, int W,
+                                                              int tiles_x, int tiles_y, int parts) {
+  static_assert(OCW * CPG * 9 == 144, "144 accumulators per lane");
+  constexpr int TH = 8, TW = 64, IH = TH + 2, IWU = TW + 2, IW = 68;
+  constexpr int Q = CPG / OCW;                 // work units per group
+  constexpr int GPB = Q >= 4 ? 1 : 4 / Q;      // groups per block (4 waves = 4 units)
+  constexpr int XCH = GPB * CPG;               // input channels staged per block
+  __shared__ float xs[XCH][IH][IW];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int u = blockIdx.y * 4 + wave;         // (group, oc chunk)
+  const int g = u / Q, q = u - g * Q;
+  const int g0 = (blockIdx.y * 4) / Q;         // first group of this block
+  const int cl = (g - g0) * CPG;               // channel offset of this wave's group inside xs
+  const int oc0 = g * CPG + q * OCW;
+
+  float acc[OCW][CPG][9];
+#pragma unroll
+  for (int o = 0; o < OCW; ++o)
+#pragma unroll
+    for (int c = 0; c < CPG; ++c)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc[o][c][k] = 0.f;
+
+  const int per_img = tiles_x * tiles_y;
+  const int total = NB * per_img;
+  for (int tile = blockIdx.x; tile < total; tile += parts) {
+    const int n = tile / per_img;
+    const int tr = tile - n * per_img;
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+    __syncthreads();
+    const float* xg = x + ((long)n * C + (long)g0 * CPG) * H * W;
+    for (int idx = t; idx < XCH * IH * IWU; idx += 256) {
+      const int c = idx / (IH * IWU);
+      const int r = idx - c * (IH * IWU);
+      const int ry = r / IWU, rx = r - ry * IWU;
+      const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
+      float v = 0.f;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = xg[((long)c * H + iy) * W + ix];
+      xs[c][ry][rx] = v;
+    }
+    __syncthreads();
+    const int ox = ox0 + lane;
+    const float* dyp = dy + ((long)n * C + oc0) * H * W + ox;
+#pragma unroll 1
+    for (int r = 0; r < TH; ++r) {
+      const int oy = oy0 + r;
+      const bool ok = oy < H && ox < W;
+      float d[OCW];
+#pragma unroll
+      for (int o = 0; o < OCW; ++o) d[o] = ok ? dyp[((long)o * H + oy) * W] : 0.f;
+#pragma unroll
+      for (int c = 0; c < CPG; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float xv = xs[cl + c][r + ky][lane + kx];
+#pragma unroll
+            for (int o = 0; o < OCW; ++o) acc[o][c][ky * 3 + kx] = fmaf(d[o], xv, acc[o][c][ky * 3 + kx]);
+          }
+    }
+  }
+  float* dst = part + (long)blockIdx.x * C * CPG * 9 + (long)oc0 * CPG * 9;
+#pragma unroll
+  for (int o = 0; o < OCW; ++o)
+#pragma unroll
+    for (int c = 0; c < CPG; ++c)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float v = wave_sum(acc[o][c][k]);
+        if (lane == 0) dst[(o * CPG + c) * 9 + k] = v;
+      }
+}
+
+}  // namespace
+
+namespace wfae {
+// weight gradient of the grouped 3x3 conv for cpg in {4, 8, 16}; returns WFAE_ERR_UNSUPPORTED otherwise
+int gconv3_wgrad_valu(const float* dy, const float* x, float* dw, int NB, int C, int H, int W, int groups,
+                      int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int cpg = C / groups;
+  if (!(cpg == 4 || cpg == 8 || cpg == 16)) return WFAE_ERR_UNSUPPORTED;
+  const int ocw = 144 / (cpg * 9);
+  const int units = groups * (cpg / ocw);
+  if (units % 4 != 0) return WFAE_ERR_UNSUPPORTED;
+  if (cpg == 4 && groups % 4 != 0) return WFAE_ERR_UNSUPPORTED;
+  const int gy = units / 4;
+  const int tiles_x = cdiv(W, 64), tiles_y = cdiv(H, 8);
+  const long total = (long)NB * tiles_x * tiles_y;
+  const size_t out_elems = (size_t)C * cpg * 9;
+  long parts = 768 / gy;
+  if (parts < 1) parts = 1;
+  if (parts > total) parts = total;
+  while (parts > 1 && (size_t)parts * out_elems * sizeof(float) > ws_bytes) --parts;
+  if (!ws || (size_t)parts * out_elems * sizeof(float) > ws_bytes)
+    return fail(WFAE_ERR_WORKSPACE, "gconv3x3_bwd_weight: workspace %zu too small", ws_bytes);
+  dim3 grid((unsigned)parts, gy), block(256);
+  float* part = (float*)ws;
+  if (cpg == 4)
+    hipLaunchKernelGGL((gconv3_wgrad_kernel<4, 4>), grid, block, 0, st, dy, x, part, NB, C, H, W, tiles_x, tiles_y, (int)parts);
+  else if (cpg == 8)
+    hipLaunchKernelGGL((gconv3_wgrad_kernel<8, 2>), grid, block, 0, st, dy, x, part, NB, C, H, W, tiles_x, tiles_y, (int)parts);
+  else
+    hipLaunchKernelGGL((gconv3_wgrad_kernel<16, 1>), grid, block, 0, st, dy, x, part, NB, C, H, W, tiles_x, tiles_y, (int)parts);
+  int rc = check_launch("gconv3_wgrad");
+  if (rc) return rc;
+  return slab_reduce(part, dw, nullptr, (long)out_elems, 1, (int)parts, accumulate, st);
+}
+}  // namespace wfae

@@ -118,6 +118,28 @@ class UpUnitFn(Function):
         return dx, dw, dg, db, None
 
 
+# grouped 3x3 conv of the Bottleneck: register-blocked kernels when channels/group is 4/8/16/32
+def _g3_fwd(x, w, groups):
+    if ops.gconv3x3_supported(x.shape[1], groups) and w.shape[0] == x.shape[1]:
+        return ops.gconv3x3_fwd(x, w, groups, False)
+    return ops.dconv_fwd(x, w, None, 3, 1, 1, groups)
+
+
+def _g3_dgrad(dy, w, cin, groups):
+    if ops.gconv3x3_supported(cin, groups) and w.shape[0] == cin:
+        return ops.gconv3x3_fwd(dy, w, groups, True)
+    return ops.dconv_bwd_data(dy, w, cin, 3, 1, groups)
+
+
+def _g3_wgrad(dy, x, dw, groups):
+    c = x.shape[1]
+    # measured (tools/kbench.py): pixel-parallel VALU kernel wins at 4 and 8 channels/group, the per-group
+    # MFMA implicit GEMM at 32, the output-stationary direct kernel at 16
+    if c % groups == 0 and c // groups in (4, 8, 32) and dw.shape[0] == c and groups > 1:
+        return ops.gconv3x3_bwd_weight(dy, x, dw, groups)
+    return ops.dconv_bwd_weight(dy, x, dw, 3, 1, 1, groups)
+
+
 # -------------------------------------------------------------- Bottleneck --
 def _mk_stats(mean, invstd, scale, shift):
     st = ops.BnStats.__new__(ops.BnStats)
@@ -137,7 +159,7 @@ class BottleneckFn(Function):
         t1 = ops.conv1x1_fwd(a1, w1)
         st2 = _bn_stats(t1, bn2, training)
         a2 = ops.bn_act_fwd(t1, st2, 1)
-        t2 = ops.dconv_fwd(a2, wg, None, 3, 1, 1, groups)
+        t2 = _g3_fwd(a2, wg, groups)
         st3 = _bn_stats(t2, bn3, training)
         a3 = ops.bn_act_fwd(t2, st3, 1)
         y = ops.conv1x1_fwd(a3, w3, None, x)
@@ -164,8 +186,8 @@ class BottleneckFn(Function):
         dt2 = ops.bn_act_bwd(da3, t2, g3, st3, dg3, db3, None, 1, tr)
         del da3
         dwg = grad_buffer(wg)
-        ops.dconv_bwd_weight(dt2, a2, dwg, 3, 1, 1, ctx.groups)
-        da2 = ops.dconv_bwd_data(dt2, wg, mid, 3, 1, ctx.groups)
+        _g3_wgrad(dt2, a2, dwg, ctx.groups)
+        da2 = _g3_dgrad(dt2, wg, mid, ctx.groups)
         del dt2
         dg2, db2 = grad_buffer(g2), grad_buffer(ctx.betas[1])
         dt1 = ops.bn_act_bwd(da2, t1, g2, st2, dg2, db2, None, 1, tr)

@@ -201,6 +201,31 @@ def dconv_bwd_weight(dy, x, dw, ks, stride, pad, groups, accumulate=False):
     return dw
 
 
+def gconv3x3_supported(c, groups):
+    return c % groups == 0 and (c // groups) in (4, 8, 16, 32)
+
+
+def gconv3x3_fwd(x, w, groups, transposed=False):
+    """grouped 3x3 'same' conv with Cin == Cout (Bottleneck middle conv); transposed=True gives the data gradient."""
+    _chk(x, w)
+    nb, c, h, wd = x.shape
+    y = torch.empty_like(x)
+    ws = workspace()
+    cpg = c // groups
+    _call("wfae_gconv3x3_fwd", 2 * x.numel() * cpg * 9, 8 * x.numel(), _p(x), _p(w), _p(y), nb, c, h, wd, groups,
+          int(transposed), ws.data_ptr(), ws.numel(), _stream())
+    return y
+
+
+def gconv3x3_bwd_weight(dy, x, dw, groups, accumulate=False):
+    _chk(dy, x, dw)
+    nb, c, h, wd = x.shape
+    ws = workspace()
+    _call("wfae_gconv3x3_bwd_weight", 2 * x.numel() * (c // groups) * 9, 8 * x.numel(), _p(dy), _p(x), _p(dw), nb, c,
+          h, wd, groups, int(accumulate), ws.data_ptr(), ws.numel(), _stream())
+    return dw
+
+
 # ---------------------------------------------------------------- BatchNorm
 class BnStats:
     """per-channel vectors produced by the statistics kernels"""

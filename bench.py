@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--img-size", type=int, default=384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run weight gradients on the main stream")
     args = ap.parse_args()
 
     import torch
@@ -111,6 +112,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    Fn.set_wgrad_overlap(not args.no_overlap)
     torch.manual_seed(0)  # identical random-init weights on every rank (then broadcast anyway)
     net = PosAwareAE_TF(img_size=args.img_size).to(dev).train()
     opt = FusedAdamW(net.parameters(), lr=5e-5, betas=(0.9, 0.999), weight_decay=1e-4)

@@ -158,3 +158,27 @@ def test_leaf_modules_standalone(dev):
         assert relerr(xd.grad, xr.grad) < 5e-5, type(mine).__name__
         for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
             assert relerr(p.grad, q.grad) < 5e-5, (type(mine).__name__, n)
+
+
+def test_wgrad_side_stream_overlap_matches(dev):
+    """weight gradients on the side stream (bench/train setting) == main-stream gradients, bit for bit"""
+    from weatherforecastingtoolkit_amd import functional as Fn
+    from weatherforecastingtoolkit_amd.optim import FusedAdamW
+    net = _build(128, dev)
+    g = golden("g3_full128_b4_blobs")
+    x = _frames(g).to(dev)
+    opt = FusedAdamW(net.parameters(), lr=5e-5, weight_decay=1e-4)
+    grads = []
+    for overlap in (False, True, True):
+        Fn.set_wgrad_overlap(overlap)
+        try:
+            opt.zero_grad(set_to_none=True)
+            recon, _ = net(x)
+            Fn.l1_loss(recon, x).backward()
+            Fn.join_side_stream()
+            torch.cuda.synchronize()
+            assert opt.arenas[0].grads_in_arena()
+            grads.append(opt.arenas[0].flat_g.clone())
+        finally:
+            Fn.set_wgrad_overlap(False)
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])

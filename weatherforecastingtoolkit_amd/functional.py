@@ -27,6 +27,49 @@ from . import ops
 BN_EPS = 1e-5
 
 
+# ---------------------------------------------------------------------------------------------
+# Weight-gradient kernels do not feed the backward chain (dgrad -> BN bwd -> dgrad ...), so they
+# can run on a second HIP stream: the MFMA-bound wgrad GEMMs then overlap the HBM-bound
+# BatchNorm / element-wise backward kernels of the critical path.  Opt-in (bench / train script):
+# whoever reads .grad afterwards must call join_side_stream() first (FusedAdamW.step,
+# DataParallelTrainer.reduce_gradients and helpers.grad_norm do).
+# ---------------------------------------------------------------------------------------------
+_overlap = False
+_side = {}
+
+
+def set_wgrad_overlap(flag: bool):
+    global _overlap
+    _overlap = bool(flag)
+
+
+def _side_stream():
+    dev = torch.cuda.current_device()
+    s = _side.get(dev)
+    if s is None:
+        s = _side[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
+def join_side_stream():
+    if _side:
+        dev = torch.cuda.current_device()
+        if dev in _side:
+            torch.cuda.current_stream().wait_stream(_side[dev])
+
+
+def _wgrad(fn, *tensors):
+    """run fn() (a weight-gradient launch reading `tensors`) on the side stream when overlap is on"""
+    if not _overlap:
+        return fn()
+    side = _side_stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    for t in tensors:
+        t.record_stream(side)
+
+
 def grad_buffer(p):
     v = getattr(p, "_wfae_grad_view", None)
     if v is not None and p.grad is None:
@@ -87,7 +130,7 @@ class DownUnitFn(Function):
         dg, db = grad_buffer(gamma), grad_buffer(ctx.beta)
         dt = ops.bn_act_bwd(_c(da), t, gamma, st, dg, db, None, 1, ctx.training)
         dw = grad_buffer(w)
-        _down_wgrad(dt, x, dw)
+        _wgrad(lambda: _down_wgrad(dt, x, dw), dt, x)
         dx = ops.conv4x4s2_up(dt, w) if ctx.needs_input_grad[0] else None
         return dx, dw, dg, db, None
 
@@ -113,7 +156,7 @@ class UpUnitFn(Function):
         dg, db = grad_buffer(gamma), grad_buffer(ctx.beta)
         dt = ops.bn_act_bwd(_c(da), t, gamma, st, dg, db, None, 1, ctx.training)
         dw = grad_buffer(w)
-        ops.conv4x4s2_wgrad(x, dt, dw)  # lo = x, hi = dt
+        _wgrad(lambda: ops.conv4x4s2_wgrad(x, dt, dw), x, dt)  # lo = x, hi = dt
         dx = ops.conv4x4s2_down(dt, w) if ctx.needs_input_grad[0] else None
         return dx, dw, dg, db, None
 
@@ -180,20 +223,20 @@ class BottleneckFn(Function):
         dy = _c(dy)
         mid = w1.shape[0]
         dw3 = grad_buffer(w3)
-        ops.conv1x1_bwd_weight(dy, a3, dw3)
+        _wgrad(lambda: ops.conv1x1_bwd_weight(dy, a3, dw3), dy, a3)
         da3 = ops.conv1x1_bwd_data(dy, w3)
         dg3, db3 = grad_buffer(g3), grad_buffer(ctx.betas[2])
         dt2 = ops.bn_act_bwd(da3, t2, g3, st3, dg3, db3, None, 1, tr)
         del da3
         dwg = grad_buffer(wg)
-        _g3_wgrad(dt2, a2, dwg, ctx.groups)
+        _wgrad(lambda: _g3_wgrad(dt2, a2, dwg, ctx.groups), dt2, a2)
         da2 = _g3_dgrad(dt2, wg, mid, ctx.groups)
         del dt2
         dg2, db2 = grad_buffer(g2), grad_buffer(ctx.betas[1])
         dt1 = ops.bn_act_bwd(da2, t1, g2, st2, dg2, db2, None, 1, tr)
         del da2
         dw1 = grad_buffer(w1)
-        ops.conv1x1_bwd_weight(dt1, a1, dw1)
+        _wgrad(lambda: ops.conv1x1_bwd_weight(dt1, a1, dw1), dt1, a1)
         da1 = ops.conv1x1_bwd_data(dt1, w1)
         del dt1
         dg1, db1 = grad_buffer(g1), grad_buffer(ctx.betas[0])

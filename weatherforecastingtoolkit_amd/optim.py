@@ -79,6 +79,8 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        from .functional import join_side_stream
+        join_side_stream()  # weight gradients may have been produced on the side stream
         for g, arena in zip(self.param_groups, self._arenas):
             g["step"] += 1
             t = g["step"]

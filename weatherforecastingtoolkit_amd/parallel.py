@@ -81,6 +81,8 @@ class DataParallelTrainer:
                 dist.broadcast(b, src=0)
 
     def reduce_gradients(self):
+        from .functional import join_side_stream
+        join_side_stream()
         for a in self.opt.arenas:
             if not a.grads_in_arena():
                 raise RuntimeError("data-parallel step needs every gradient inside the flat arena")

@@ -42,6 +42,8 @@ def grad_norm(optimizer_or_params, norm_type=2):
     """TrackGradNormCallback arithmetic (reference :250-256) without 323 host syncs: one
     sum-of-squares kernel per gradient arena (or per tensor), one .item()."""
     assert norm_type == 2
+    from ..functional import join_side_stream
+    join_side_stream()
     total = 0.0
     arenas = getattr(optimizer_or_params, "arenas", None)
     if arenas:

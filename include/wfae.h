@@ -184,6 +184,29 @@ int wfae_ssim_bwd(const float* x, const float* y, const float* gout, float* dy, 
 int wfae_psnr(const float* pred, const float* target, float* out, int NB, int HW, int clamp01,
               void* ws, size_t ws_bytes, wfae_stream_t stream);
 
+/* ---- latent transformer of the `_tf` variant (pipeline/models/ae_64x8x8_tf.py:77-80,107-109):
+ * nn.TransformerEncoderLayer(d_model=64, nhead=8, dim_feedforward=2048, dropout=0.1), post-norm, ReLU,
+ * batch_first=False.  The Linear layers use wfae_linear_*.
+ * layernorm: y = LN(x + res) (res may be null); mean/rstd per row are saved for backward; bwd returns the
+ *   gradient w.r.t. (x + res) plus dgamma/dbeta.
+ * mha_seqfirst: qkv rows are (s, n) pairs (row = s*N + n) with columns [q | k | v], E = H*D each; attention over
+ *   the S axis per (n, head), softmax(q k^T / sqrt(D)), dropout on the probabilities from a counter-based
+ *   generator keyed by `seed` (the same seed regenerates the mask in backward).  S <= 64, D in {8, 16}.
+ * dropout: y = x * mask / (1 - p), mask from (seed, element index); applying it to dy with the same seed is
+ *   the backward. */
+int wfae_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                       float* mean, float* rstd, int rows, int E, float eps, wfae_stream_t stream);
+int wfae_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma, const float* mean,
+                       const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int E, int accumulate,
+                       void* ws, size_t ws_bytes, wfae_stream_t stream);
+int wfae_mha_seqfirst_fwd(const float* qkv, float* out, float* probs, int S, int N, int H, int D, float p_drop,
+                          uint64_t seed, wfae_stream_t stream);
+int wfae_mha_seqfirst_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, int S, int N, int H,
+                          int D, float p_drop, uint64_t seed, wfae_stream_t stream);
+int wfae_relu_fwd(const float* x, float* y, int64_t n, wfae_stream_t stream);
+int wfae_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, wfae_stream_t stream);
+int wfae_dropout(const float* x, float* y, int64_t n, float p_drop, uint64_t seed, wfae_stream_t stream);
+
 /* ---- AdamW (torch.optim.AdamW via pipeline/helpers.py:63-74) ---------------
  * p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
  * p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps),  g pre-multiplied by grad_scale

@@ -275,6 +275,52 @@ def g_full(name, img_size, batch, steps, frames="uniform"):
     save(name, **out)
 
 
+# ------------------------------------------------------------------ G5 ---
+def g5_tf():
+    """the `_tf` variant that experiments/ae_v2/train.py:18 imports: eval-mode forward (dropout off)
+    and a train-mode step with every dropout probability set to 0 (dropout RNG cannot be matched)."""
+    import pipeline.models.ae_64x8x8_tf as reftf
+    spec = synth.ae_tf_state_dict_spec(128)
+    np_sd = synth.synth_state_dict(spec, seed=0)
+    net = reftf.PosAwareAE_TF()
+    assert list(net.state_dict().keys()) == [k for k, _, _ in spec]
+    net.load_state_dict({k: (T(v) if v.ndim else torch.tensor(0)) for k, v in np_sd.items()}, strict=True)
+    x = T(synth.uniform_frames(3, 128, seed=1234))
+    out = {}
+    idx = np.linspace(0, 127, LATTICE).round().astype(np.int64)
+    out["lattice"] = idx
+    net.eval()
+    with torch.no_grad():
+        er, ez = net(x)
+    out["eval_recon_lattice"] = er[:, 0][:, idx][:, :, idx].numpy()
+    out["eval_z"] = ez.numpy()
+    # seq-first quirk (SURVEY.md 7.2 item 7): sample 0's output depends on sample 1's latent
+    with torch.no_grad():
+        er1, _ = net(torch.cat([x[:1], x[2:3], x[2:3]]))
+    out["eval_recon0_other_batch"] = er1[0, 0][idx][:, idx].numpy()
+    net.train()
+    for m in net.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, nn.MultiheadAttention):
+            m.dropout = 0.0
+    recon, z = net(x)
+    loss = F.l1_loss(recon, x)
+    loss.backward()
+    out["recon_lattice"] = recon.detach()[:, 0][:, idx][:, :, idx].numpy()
+    out["z"] = z.detach().numpy()
+    out["loss"] = np.float64(loss.item())
+    names, norms = [], []
+    for n, p in net.named_parameters():
+        names.append(n)
+        norms.append(-1.0 if p.grad is None else p.grad.double().norm().item())
+    out["grad_names"], out["grad_norms"] = np.array(names), np.array(norms)
+    out["g_tf0_inproj"] = net.tf.layers[0].self_attn.in_proj_weight.grad.numpy()
+    out["g_tf7_lin2"] = net.tf.layers[7].linear2.weight.grad.numpy()[:, :64]
+    out["g_tf3_norm1"] = net.tf.layers[3].norm1.weight.grad.numpy()
+    save("g5_tf128_b3", **out)
+
+
 # ------------------------------------------------------------------ G7 ---
 def g7_metrics():
     """SSIM/PSNR from the restatement (UNPINNED: pytorch_msssim/torchmetrics absent)."""
@@ -329,6 +375,8 @@ def main():
         g_full("g3_full128_b4_blobs", 128, 4, 1, "blobs")
     if want("g4"):
         g_full("g4_full384_b1", 384, 1, 1, "blobs")
+    if want("g5"):
+        g5_tf()
     if want("g7"):
         g7_metrics()
     if want("g8"):

@@ -182,3 +182,97 @@ def test_wgrad_side_stream_overlap_matches(dev):
         finally:
             Fn.set_wgrad_overlap(False)
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+
+
+def test_tf_variant_golden(dev):
+    """next-1 row: ae_64x8x8_tf.PosAwareAE_TF (latent transformer, attention across the batch) vs the reference."""
+    from weatherforecastingtoolkit_amd import functional as Fn, synth
+    from weatherforecastingtoolkit_amd.pipeline.models.ae_64x8x8_tf import PosAwareAE_TF
+    import torch.nn as tnn
+    g = golden("g5_tf128_b3")
+    np_sd = synth.synth_state_dict(synth.ae_tf_state_dict_spec(128), seed=0)
+    net = PosAwareAE_TF().to(dev)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in np_sd.items()}, strict=True)
+    x = torch.from_numpy(synth.uniform_frames(3, 128, seed=1234)).to(dev)
+    idx = torch.from_numpy(g["lattice"]).to(dev)
+    net.eval()
+    with torch.no_grad():
+        er, ez = net(x)
+        er1, _ = net(torch.cat([x[:1], x[2:3], x[2:3]]))
+    assert relerr(er[:, 0][:, idx][:, :, idx], g["eval_recon_lattice"]) < 1e-4
+    assert relerr(ez, g["eval_z"]) < 1e-4
+    assert relerr(er1[0, 0][idx][:, idx], g["eval_recon0_other_batch"]) < 1e-4   # the batch-coupling quirk is reproduced
+    net.train()
+    for m in net.modules():
+        if isinstance(m, tnn.Dropout):
+            m.p = 0.0
+        if isinstance(m, tnn.MultiheadAttention):
+            m.dropout = 0.0
+    recon, z = net(x)
+    loss = Fn.l1_loss(recon, x)
+    loss.backward()
+    assert relerr(recon.detach()[:, 0][:, idx][:, :, idx], g["recon_lattice"]) < 1e-4
+    assert relerr(z, g["z"]) < 1e-4
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * float(g["loss"])
+    names = [n for n, _ in net.named_parameters()]
+    assert names == [str(n) for n in g["grad_names"]]
+    for (n, p), ref in zip(net.named_parameters(), g["grad_norms"]):
+        if ref < 0:
+            assert p.grad is None, n          # tf_encoder.* template: never used
+        else:
+            assert abs(p.grad.double().norm().item() - ref) <= 3e-3 * ref + 1e-12, n
+    assert relerr(net.tf.layers[0].self_attn.in_proj_weight.grad, g["g_tf0_inproj"]) < 2e-3
+    assert relerr(net.tf.layers[7].linear2.weight.grad[:, :64], g["g_tf7_lin2"]) < 2e-3
+    assert relerr(net.tf.layers[3].norm1.weight.grad, g["g_tf3_norm1"]) < 2e-3
+
+
+def test_tf_dropout_and_optimizer_runs(dev):
+    """train mode with the reference's dropout 0.1 (own counter-based RNG) + AdamW skipping the unused template"""
+    from weatherforecastingtoolkit_amd import functional as Fn
+    from weatherforecastingtoolkit_amd.optim import FusedAdamW
+    from weatherforecastingtoolkit_amd.pipeline.models.ae_64x8x8_tf import PosAwareAE_TF
+    torch.manual_seed(0)
+    net = PosAwareAE_TF().to(dev).train()
+    opt = FusedAdamW(net.parameters(), lr=5e-5, weight_decay=1e-4)
+    x = torch.rand(2, 1, 128, 128, device=dev)
+    before = net.tf_encoder.linear1.weight.detach().clone()
+    w0 = net.tf.layers[0].linear1.weight.detach().clone()
+    losses = []
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        recon, _ = net(x)
+        loss = Fn.l1_loss(recon, x)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses))
+    assert torch.equal(before, net.tf_encoder.linear1.weight)       # no grad -> untouched, like torch.optim
+    assert not torch.equal(w0, net.tf.layers[0].linear1.weight)
+    runs, stray = opt.arenas[0].runs()
+    assert len(runs) == 2 and not stray
+
+
+def test_transformer_layer_vs_torch(dev):
+    """one seq-first TransformerEncoderLayer, fwd + bwd, against torch's own implementation on CPU"""
+    import torch.nn as tnn
+    from weatherforecastingtoolkit_amd import nn as wnn
+    torch.manual_seed(1)
+    ref = tnn.TransformerEncoderLayer(d_model=64, nhead=8, dim_feedforward=256, dropout=0.0)
+    mine = wnn.TransformerEncoderLayer(d_model=64, nhead=8, dim_feedforward=256, dropout=0.0)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev).train()
+    ref.train()
+    for s_len in (1, 5, 32):
+        x = torch.randn(s_len, 64, 64)
+        xr, xd = x.clone().requires_grad_(True), x.to(dev).requires_grad_(True)
+        yr = ref(xr)
+        gy = torch.randn_like(yr)
+        yr.backward(gy)
+        yd = mine(xd)
+        yd.backward(gy.to(dev))
+        assert relerr(yd, yr) < 2e-5
+        assert relerr(xd.grad, xr.grad) < 1e-4
+        for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+            assert relerr(p.grad, q.grad) < 2e-4, n
+            p.grad = None
+            q.grad = None

@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_PKG, "libwfae.so")
 _CT = {
     "int": ctypes.c_int,
     "int64_t": ctypes.c_int64,
+    "uint64_t": ctypes.c_uint64,
     "size_t": ctypes.c_size_t,
     "float": ctypes.c_float,
     "wfae_stream_t": ctypes.c_void_p,

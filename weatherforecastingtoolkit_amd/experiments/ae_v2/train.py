@@ -29,7 +29,7 @@ from ... import parallel, synth
 from ...nn import flush_bn_counters
 from ...pipeline import helpers
 from ...pipeline.datasets.sevire.sevir import SEVIRFrameLoader
-from ...pipeline.models.ae_64x8x8_lin import PosAwareAE_TF
+from ...pipeline.models import ae_64x8x8_lin, ae_64x8x8_tf
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -61,6 +61,8 @@ def main(argv=None):
     ap.add_argument("--resume", type=bool, default=False)
     ap.add_argument("--config", default=os.path.join(HERE, "config.yaml"))
     ap.add_argument("--max-steps", type=int, default=-1, help="stop early (smoke runs)")
+    ap.add_argument("--model", choices=("tf", "lin"), default="tf",
+                    help="tf = ae_64x8x8_tf (what the reference ae_v2/train.py:18 imports), lin = ae_64x8x8_lin (ae_v2_2)")
     args, unknown = ap.parse_known_args(argv)
     cfg = C.load(args.config)
     cli = C.from_dotlist(unknown)
@@ -83,7 +85,9 @@ def main(argv=None):
     disc_start = int(cfg.lpips.disc_start * total_steps)                      # reference :318
 
     torch.manual_seed(0)
-    net = PosAwareAE_TF(img_size=size).to(dev).train()
+    model_mod = ae_64x8x8_tf if args.model == "tf" else ae_64x8x8_lin
+    net = model_mod.PosAwareAE_TF(img_size=size).to(dev).train()
+    Fn.set_wgrad_overlap(True)
     loss_fn = Loss(disc_start, cfg.lpips.disc_weight, cfg.lpips.perceptual_weight, cfg.lpips.recon_weight)
     opt = helpers.adamw_optimizer(net, cfg.optim.lr, cfg.optim.weight_decay, cfg.optim.beta1, cfg.optim.beta2)
     sched = helpers.cosine_warmup_scheduler(opt, cfg.cosine_warmup.start_lr, cfg.cosine_warmup.final_lr,

@@ -421,6 +421,83 @@ class AddFn(Function):
         return dy, dy
 
 
+# ------------------------------------------------------- latent transformer --
+class AddLayerNormFn(Function):
+    """LayerNorm(x + res): the post-norm residual of nn.TransformerEncoderLayer."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps):
+        x, res = _c(x), _c(res)
+        y, mean, rstd = ops.layernorm_fwd(x, res, gamma, beta, eps)
+        ctx.save_for_backward(x, res, gamma, mean, rstd)
+        ctx.beta = beta
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, res, gamma, mean, rstd = ctx.saved_tensors
+        dg, db = grad_buffer(gamma), grad_buffer(ctx.beta)
+        dh = ops.layernorm_bwd(_c(dy), x, res, gamma, mean, rstd, dg, db)
+        return dh, dh, dg, db, None
+
+
+class MhaSeqFirstFn(Function):
+    @staticmethod
+    def forward(ctx, qkv, s, n, h, p_drop, seed):
+        qkv = _c(qkv)
+        d = qkv.shape[1] // (3 * h)
+        out, probs = ops.mha_fwd(qkv, s, n, h, d, p_drop, seed)
+        ctx.save_for_backward(qkv, probs)
+        ctx.cfg = (s, n, h, d, p_drop, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, probs = ctx.saved_tensors
+        return ops.mha_bwd(qkv, probs, _c(dout), *ctx.cfg), None, None, None, None, None
+
+
+class ReluFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.relu_fwd(_c(x))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.relu_bwd(_c(dy), y)
+
+
+class DropoutFn(Function):
+    """y = x * mask / (1-p); the mask is a pure function of (seed, element index), so backward
+    applies the same kernel to dy."""
+
+    @staticmethod
+    def forward(ctx, x, p_drop, seed):
+        ctx.cfg = (p_drop, seed)
+        return ops.dropout(_c(x), p_drop, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(_c(dy), *ctx.cfg), None, None
+
+
+_seed_counter = [0]
+
+
+def next_seed():
+    _seed_counter[0] += 1
+    return (torch.initial_seed() * 1000003 + _seed_counter[0]) & 0x7FFFFFFFFFFFFFFF
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, float(p), next_seed())
+
+
 # ------------------------------------------------------------------- losses --
 class L1LossFn(Function):
     """weight * mean |recon - x|  (F.l1_loss, experiments/ae_v2/train.py:55)."""

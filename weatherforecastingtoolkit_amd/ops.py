@@ -376,6 +376,66 @@ def psnr(pred, target, clamp01=False):
     return out
 
 
+# ------------------------------------------------------- latent transformer
+def layernorm_fwd(x, res, gamma, beta, eps=1e-5):
+    _chk(x, res, gamma, beta)
+    rows, e = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _call("wfae_layernorm_fwd", 0, 12 * x.numel(), _p(x), _p(res), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows,
+          e, eps, _stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, res, gamma, mean, rstd, dgamma, dbeta, accumulate=False):
+    _chk(dy, x, res, gamma, mean, rstd, dgamma, dbeta)
+    rows, e = x.shape
+    dx = torch.empty_like(x)
+    ws = workspace()
+    _call("wfae_layernorm_bwd", 0, 16 * x.numel(), _p(dy), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(dx),
+          _p(dgamma), _p(dbeta), rows, e, int(accumulate), ws.data_ptr(), ws.numel(), _stream())
+    return dx
+
+
+def mha_fwd(qkv, s, n, h, d, p_drop=0.0, seed=0):
+    _chk(qkv)
+    out = torch.empty((s * n, h * d), dtype=torch.float32, device=qkv.device)
+    probs = torch.empty((n, h, s, s), dtype=torch.float32, device=qkv.device)
+    _call("wfae_mha_seqfirst_fwd", 4 * n * h * s * s * d, 4 * (qkv.numel() + out.numel()), _p(qkv), _p(out), _p(probs),
+          s, n, h, d, p_drop, seed, _stream())
+    return out, probs
+
+
+def mha_bwd(qkv, probs, dout, s, n, h, d, p_drop=0.0, seed=0):
+    _chk(qkv, probs, dout)
+    dqkv = torch.empty_like(qkv)
+    _call("wfae_mha_seqfirst_bwd", 8 * n * h * s * s * d, 8 * qkv.numel(), _p(qkv), _p(probs), _p(dout), _p(dqkv), s, n,
+          h, d, p_drop, seed, _stream())
+    return dqkv
+
+
+def relu_fwd(x):
+    _chk(x)
+    y = torch.empty_like(x)
+    _call("wfae_relu_fwd", 0, 8 * x.numel(), _p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+def relu_bwd(dy, y):
+    _chk(dy, y)
+    dx = torch.empty_like(dy)
+    _call("wfae_relu_bwd", 0, 12 * y.numel(), _p(dy), _p(y), _p(dx), y.numel(), _stream())
+    return dx
+
+
+def dropout(x, p_drop, seed):
+    _chk(x)
+    y = torch.empty_like(x)
+    _call("wfae_dropout", 0, 8 * x.numel(), _p(x), _p(y), x.numel(), p_drop, seed, _stream())
+    return y
+
+
 # ---------------------------------------------------------------- optimiser
 def adamw_(p, g, m, v, lr, beta1, beta2, eps, wd, bc1, bc2, grad_scale=1.0):
     _chk(p, g, m, v)

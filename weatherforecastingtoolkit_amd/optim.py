@@ -43,10 +43,34 @@ class FlatArena:
             p._wfae_grad_view = self.flat_g[o:o + n].view_as(p)
 
     def grads_in_arena(self):
+        """every parameter has a gradient and it lives inside the arena"""
         for p in self.params:
             if p.grad is None or p.grad.data_ptr() != p._wfae_grad_view.data_ptr():
                 return False
         return True
+
+    def runs(self):
+        """Maximal runs [(start, end)] (element offsets) of consecutive parameters whose gradient lives in
+        the arena, plus the list of parameter indices that have a gradient elsewhere.  Parameters without
+        a gradient (e.g. the never-used `tf_encoder.*` template of the _tf model) are skipped, like
+        torch.optim does."""
+        runs, stray, start, end = [], [], None, None
+        for i, p in enumerate(self.params):
+            o, n = self.offsets[i], p.numel()
+            inside = p.grad is not None and p.grad.data_ptr() == p._wfae_grad_view.data_ptr()
+            if inside:
+                if start is None:
+                    start = o
+                end = o + n
+            else:
+                if start is not None:
+                    runs.append((start, end))
+                    start = None
+                if p.grad is not None:
+                    stray.append(i)
+        if start is not None:
+            runs.append((start, end))
+        return runs, stray
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -87,17 +111,20 @@ class FusedAdamW(torch.optim.Optimizer):
             b1, b2 = g["betas"]
             bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
             args = (g["lr"], b1, b2, g["eps"], g["weight_decay"], bc1, bc2, self.grad_scale)
-            if arena is not None and arena.grads_in_arena():
-                ops.adamw_(arena.flat_p, arena.flat_g, arena.m, arena.v, *args)
+            if arena is not None:
+                runs, stray = arena.runs()
+                for a, b in runs:  # one launch per contiguous run (one run when every parameter has a grad)
+                    ops.adamw_(arena.flat_p[a:b], arena.flat_g[a:b], arena.m[a:b], arena.v[a:b], *args)
+                for i in stray:
+                    p = arena.params[i]
+                    o, n = arena.offsets[i], p.numel()
+                    ops.adamw_(arena.flat_p[o:o + n], p.grad.contiguous().view(-1), arena.m[o:o + n],
+                               arena.v[o:o + n], *args)
                 continue
             for i, p in enumerate(g["params"]):
                 if p.grad is None:
                     continue
-                if arena is not None:
-                    o, n = arena.offsets[i], p.numel()
-                    m, v = arena.m[o:o + n], arena.v[o:o + n]
-                    pd = arena.flat_p[o:o + n]
-                else:
+                if True:
                     st = self.state[p]
                     if not st:
                         st["m"], st["v"] = torch.zeros_like(p).view(-1), torch.zeros_like(p).view(-1)

@@ -84,6 +84,9 @@ class DataParallelTrainer:
         from .functional import join_side_stream
         join_side_stream()
         for a in self.opt.arenas:
-            if not a.grads_in_arena():
+            runs, stray = a.runs()
+            if stray:
                 raise RuntimeError("data-parallel step needs every gradient inside the flat arena")
+            # parameters without a gradient (never-used template layers) contribute their zero-initialised
+            # arena slots: the same on every rank, like DDP with find_unused_parameters
             self.sync.allreduce_(a.flat_g)

@@ -131,6 +131,34 @@ def ae_state_dict_spec(img_size: int = 128, in_channels: int = 1, latent_channel
     return spec + d
 
 
+def _tf_layer_entries(prefix: str, d: int = 64, ff: int = 2048):
+    return [
+        (prefix + ".self_attn.in_proj_weight", (3 * d, d), "linear"),
+        (prefix + ".self_attn.in_proj_bias", (3 * d,), ("bias", d)),
+        (prefix + ".self_attn.out_proj.weight", (d, d), "linear"),
+        (prefix + ".self_attn.out_proj.bias", (d,), ("bias", d)),
+        (prefix + ".linear1.weight", (ff, d), "linear"),
+        (prefix + ".linear1.bias", (ff,), ("bias", d)),
+        (prefix + ".linear2.weight", (d, ff), "linear"),
+        (prefix + ".linear2.bias", (d,), ("bias", ff)),
+        (prefix + ".norm1.weight", (d,), "bn_w"),
+        (prefix + ".norm1.bias", (d,), "bn_b"),
+        (prefix + ".norm2.weight", (d,), "bn_w"),
+        (prefix + ".norm2.bias", (d,), "bn_b"),
+    ]
+
+
+def ae_tf_state_dict_spec(img_size: int = 128, num_layers: int = 8):
+    """state_dict of pipeline/models/ae_64x8x8_tf.py::PosAwareAE_TF (743 entries): the `_lin` layout
+    with `tf_encoder.*` and `tf.layers.{i}.*` registered between from_latent and dec."""
+    base = ae_state_dict_spec(img_size)
+    cut = next(i for i, (k, _, _) in enumerate(base) if k == "dec.0.weight")
+    tf = _tf_layer_entries("tf_encoder")
+    for i in range(num_layers):
+        tf += _tf_layer_entries(f"tf.layers.{i}")
+    return base[:cut] + tf + base[cut:]
+
+
 def synth_tensor(seed: int, key: str, shape, kind) -> np.ndarray:
     if isinstance(kind, tuple) and kind[0] == "bias":
         b = 1.0 / np.sqrt(kind[1])

@@ -11,9 +11,11 @@ global batch 32*N).  Frames are generated on the device before the timed
 region.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      the dominant kernel family of the step, timed live with events
-                on the launch stream around each of its launches inside the
-                timed region; achieved = algorithmic FLOPs / that time.
+  roofline      the dominant kernel family of the step, timed live with an event
+                pair on the launch stream around each of its launches (a second
+                pass of the same K steps right after the timed region, streams
+                serialised so concurrent launches do not inflate each other);
+                achieved = algorithmic FLOPs / that time.
   step_roofline whole-step fractions per SURVEY.md §8(d):
                 fp32_fraction = 938.8 GFLOP/frame * fps / 157.3 TFLOP/s,
                 hbm_fraction  = 7.365 GB/frame * fps / 8 TB/s.
@@ -142,15 +144,24 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    timing = (not args.no_kernel_timing)
-    if timing:
-        ops.profile_start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    prof = ops.profile_stop() if timing else {}
+    # Per-kernel read-out for the roofline object: the same step, K more times, with an event pair
+    # around every launch on its launch stream.  Streams are serialised for this pass (weight
+    # gradients back on the main stream) so a launch's duration is not inflated by a concurrent one.
+    prof = {}
+    if not args.no_kernel_timing:
+        Fn.set_wgrad_overlap(False)
+        step()
+        fence()
+        ops.profile_start()
+        for _ in range(args.steps):
+            step()
+        prof = ops.profile_stop()
+        Fn.set_wgrad_overlap(not args.no_overlap)
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

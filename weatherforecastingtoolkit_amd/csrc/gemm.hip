@@ -307,78 +307,94 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
     }
   }
 
+  // Full K stages need no predicates at all: rows m >= M of A and columns n >= N of B are loaded from a
+  // clamped valid address and may hold anything — they only reach accumulator rows / columns that the
+  // epilogue never stores.  Only the halo taps of the conv gathers must be exact zeros; that is one
+  // v_and with a loop-invariant mask word per element when the registers go to LDS.  A partial last
+  // stage (K % 16 != 0) is handled after the loop by the predicated generic loaders.
+  unsigned lg_mask[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) lg_mask[j] = ((lg_static >> j) & 1u) ? 0xFFFFFFFFu : 0u;
+  const bool a_batched = p.a_img != 0, b_batched = p.b_img != 0;
+  if constexpr (VEC) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i)
+      if (!la_st[i]) la_off[i] = 0;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i)
+      if constexpr (BKD == B_NCONTIG || BKD == B_KCONTIG)
+        if (!lb_st[i]) lb_off[i] = 0;
+  }
+
   auto load_a_lean = [&]() {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const bool ok = la_st[i] && la_k[i] < k_end;
-      ra[i] = *reinterpret_cast<const float4*>(Ap + (ok ? la_off[i] : 0));
-      a_okbits = (a_okbits & ~(1u << i)) | ((unsigned)ok << i);
-      la_k[i] += BK;
+      ra[i] = *reinterpret_cast<const float4*>(Ap + la_off[i]);
       if constexpr (AK == A_KCONTIG) {
         la_off[i] += BK;
-        la_pk[i] += BK;
-        if (la_pk[i] >= p.a_hw) {
-          la_pk[i] -= p.a_hw;
-          la_off[i] += p.a_img - p.a_hw;
+        if (a_batched) {  // wave-uniform: plain weight matrices skip the image-wrap arithmetic
+          la_pk[i] += BK;
+          if (la_pk[i] >= p.a_hw) {
+            la_pk[i] -= p.a_hw;
+            la_off[i] += p.a_img - p.a_hw;
+          }
         }
       } else {
         la_off[i] += (long)BK * p.a_ld;
       }
     }
+    a_okbits = 0xFFFFFFFFu;
   };
 
   auto load_b_lean = [&]() {
     if constexpr (BKD == B_NCONTIG || BKD == B_KCONTIG) {
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
-        const bool ok = lb_st[i] && lb_k[i] < k_end;
-        rb[i] = *reinterpret_cast<const float4*>(Bp + (ok ? lb_off[i] : 0));
-        b_okbits = (b_okbits & ~(1u << i)) | ((unsigned)ok << i);
-        lb_k[i] += BK;
+        rb[i] = *reinterpret_cast<const float4*>(Bp + lb_off[i]);
         if constexpr (BKD == B_NCONTIG) {
           lb_off[i] += (long)BK * p.b_ld;
         } else {
           lb_off[i] += BK;
-          lb_pk[i] += BK;
-          if (lb_pk[i] >= p.b_hw) {
-            lb_pk[i] -= p.b_hw;
-            lb_off[i] += p.b_img - p.b_hw;
+          if (b_batched) {
+            lb_pk[i] += BK;
+            if (lb_pk[i] >= p.b_hw) {
+              lb_pk[i] -= p.b_hw;
+              lb_off[i] += p.b_img - p.b_hw;
+            }
           }
         }
       }
+      b_okbits = 0xFFFFFFFFu;
     } else if constexpr (BKD == B_DOWN) {
       const float* __restrict__ bp = Bp + lg_off;
 #pragma unroll
       for (int j = 0; j < 8; ++j) rg[j] = bp[lg_rel[j]];
-      g_okbits = lg_static;
       lg_off += (long)H * W;
     } else if constexpr (BKD == B_UP) {
       const float* __restrict__ bp = Bp + lg_off;
 #pragma unroll
       for (int j = 0; j < 8; ++j) rg[j] = bp[lg_rel[j]];
-      g_okbits = lg_static;
       lg_off += (long)4 * HWlo;
     } else {  // B_WGRAD / B_WGRAD3: 8 consecutive output pixels of one row (Wlo % 8 == 0)
       constexpr int ST = BKD == B_WGRAD ? 2 : 1;
       const int Hh = ST * p.Hlo, Ww = ST * p.Wlo;
-      const bool okk = g_ok && lg_k < k_end;
-      const bool okrow = okk && c_iy >= 0 && c_iy < Hh;
+      const bool okrow = c_iy >= 0 && c_iy < Hh;
       const int iyc = min(max(c_iy, 0), Hh - 1);
       const int ixb = ST * c_x - 1 + g_kx;
-      unsigned bits = okrow ? 0xFFu : 0u;
-      if (ixb < 0) bits &= ~1u;
-      if (ixb + 7 * ST >= Ww) bits &= ~0x80u;
+      const unsigned m0w = (okrow && ixb >= 0) ? 0xFFFFFFFFu : 0u;
+      const unsigned mmw = okrow ? 0xFFFFFFFFu : 0u;
+      const unsigned m7w = (okrow && ixb + 7 * ST < Ww) ? 0xFFFFFFFFu : 0u;
       // 32-bit element offset (host guarantees the tensor has < 2^31 elements)
-      const int rowoff = okk ? ((c_img * p.Chi + g_hi) * Hh + iyc) * Ww : 0;
-      const float* __restrict__ bp = Bp + rowoff;
-      const int x0 = okk ? ixb : 0;
-      rg[0] = bp[max(x0, 0)];
+      const float* __restrict__ bp = Bp + ((c_img * p.Chi + g_hi) * Hh + iyc) * Ww;
+      rg[0] = bp[max(ixb, 0)];
 #pragma unroll
-      for (int j = 1; j < 7; ++j) rg[j] = bp[x0 + ST * j];
-      rg[7] = bp[min(x0 + 7 * ST, Ww - 1)];
-      g_okbits = bits;
+      for (int j = 1; j < 7; ++j) rg[j] = bp[ixb + ST * j];
+      rg[7] = bp[min(ixb + 7 * ST, Ww - 1)];
+      lg_mask[0] = m0w;
+#pragma unroll
+      for (int j = 1; j < 7; ++j) lg_mask[j] = mmw;
+      lg_mask[7] = m7w;
       // advance the cursor by one stage (BK = 16 pixels; rows are at least 8 pixels wide)
-      lg_k += BK;
       c_x += BK;
 #pragma unroll
       for (int w = 0; w < 2; ++w)
@@ -440,27 +456,23 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
     }
   };
 
+  bool lean_regs = VEC;  // which loader filled the staging registers (the K-tail stage uses the predicated generic loaders)
   auto store_a = [&](int buf) {
-    if constexpr (AK == A_KCONTIG) {
 #pragma unroll
-      for (int i = 0; i < A_IT; ++i) {
-        const int idx = t + i * NT;
-        if (A_IT * NT == A_CNT || idx < A_CNT) {
+    for (int i = 0; i < A_IT; ++i) {
+      const int idx = t + i * NT;
+      if (A_IT * NT == A_CNT || idx < A_CNT) {
+        float4 v = ra[i];
+        if (!lean_regs) v = sel4(v, a_okbits, i);  // wave-uniform branch: full stages carry no predicate
+        if constexpr (AK == A_KCONTIG) {
           const int ml = idx >> 2, kq = (idx & 3) * 4;
-          const float4 v = sel4(ra[i], a_okbits, i);
           As[buf][kq + 0][ml] = v.x;
           As[buf][kq + 1][ml] = v.y;
           As[buf][kq + 2][ml] = v.z;
           As[buf][kq + 3][ml] = v.w;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) {
-        const int idx = t + i * NT;
-        if (A_IT * NT == A_CNT || idx < A_CNT) {
+        } else {
           const int kr = idx / (BM / 4), ml = (idx % (BM / 4)) * 4;
-          *reinterpret_cast<float4*>(&As[buf][kr][ml]) = sel4(ra[i], a_okbits, i);
+          *reinterpret_cast<float4*>(&As[buf][kr][ml]) = v;
         }
       }
     }
@@ -620,22 +632,32 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   auto store_b = [&](int buf) {
     if constexpr (BKD == B_NCONTIG) {
 #pragma unroll
-      for (int i = 0; i < B_IT; ++i)
-        *reinterpret_cast<float4*>(&Bs[buf][(t >> 5) + i * 8][(t & 31) * 4]) = sel4(rb[i], b_okbits, i);
+      for (int i = 0; i < B_IT; ++i) {
+        float4 v = rb[i];
+        if (!lean_regs) v = sel4(v, b_okbits, i);
+        *reinterpret_cast<float4*>(&Bs[buf][(t >> 5) + i * 8][(t & 31) * 4]) = v;
+      }
     } else if constexpr (BKD == B_KCONTIG) {
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         const int idx = t + i * NT;
         const int nl = idx >> 2, kq = (idx & 3) * 4;
-        const float4 v = sel4(rb[i], b_okbits, i);
+        float4 v = rb[i];
+        if (!lean_regs) v = sel4(v, b_okbits, i);
         Bs[buf][kq + 0][nl] = v.x;
         Bs[buf][kq + 1][nl] = v.y;
         Bs[buf][kq + 2][nl] = v.z;
         Bs[buf][kq + 3][nl] = v.w;
       }
     } else {
+      if (lean_regs) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) Bs[buf][g_kh * 8 + j][g_nl] = ((g_okbits >> j) & 1u) ? rg[j] : 0.f;
+        for (int j = 0; j < 8; ++j)
+          Bs[buf][g_kh * 8 + j][g_nl] = __uint_as_float(__float_as_uint(rg[j]) & lg_mask[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Bs[buf][g_kh * 8 + j][g_nl] = ((g_okbits >> j) & 1u) ? rg[j] : 0.f;
+      }
     }
   };
 
@@ -653,31 +675,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   const int l31 = lane & 31, lh = lane >> 5;
   const int l15 = lane & 15, lq = lane >> 4;
 
-  const int nstages = (k_end - k_begin + BK - 1) / BK;
-  if (nstages > 0) {
-    if constexpr (VEC) {
-      load_a_lean();
-      load_b_lean();
-    } else {
-      load_a(k_begin);
-      load_b(k_begin);
-    }
-    store_a(0);
-    store_b(0);
-  }
-  __syncthreads();
-  for (int s = 0; s < nstages; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nstages) {
-      if constexpr (VEC) {
-        load_a_lean();
-        load_b_lean();
-      } else {
-        load_a(k_begin + (s + 1) * BK);
-        load_b(k_begin + (s + 1) * BK);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch's consumers below the MFMAs
+  auto compute = [&](int buf) {
     if constexpr (MF == 32) {
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 2) {
@@ -707,6 +705,37 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
+  };
+
+  // Stages [0, nlean) are complete (16 k each) and use the lean loaders; a partial last stage and the
+  // scalar (non-VEC) kernels use the predicated generic loaders.
+  const int nstages = (k_end - k_begin + BK - 1) / BK;
+  const int nlean = VEC ? (k_end - k_begin) / BK : 0;
+  auto load_stage = [&](int s) {
+    bool lean = false;
+    if constexpr (VEC) lean = s < nlean;
+    if (lean) {
+      if constexpr (VEC) {
+        load_a_lean();
+        load_b_lean();
+      }
+    } else {
+      load_a(k_begin + s * BK);
+      load_b(k_begin + s * BK);
+    }
+    lean_regs = lean;
+  };
+  if (nstages > 0) {
+    load_stage(0);
+    store_a(0);
+    store_b(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < nstages; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nstages) load_stage(s + 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch's consumers below the MFMAs
+    compute(buf);
     __builtin_amdgcn_sched_barrier(0);
     if (s + 1 < nstages) {
       store_a(buf ^ 1);

@@ -51,11 +51,22 @@ def _side_stream():
     return s
 
 
+# Tensors read by side-stream kernels are kept alive (Python references) until the main stream has
+# waited for the side stream; only then may the caching allocator hand their memory to later
+# main-stream kernels.  (tensor.record_stream() would also be correct but makes the allocator poll
+# per-block events and, with the host running several steps ahead, fall back to fresh hipMallocs.)
+_keep = []
+_keep_bytes = [0]
+_KEEP_LIMIT = 24 << 30
+
+
 def join_side_stream():
     if _side:
         dev = torch.cuda.current_device()
         if dev in _side:
             torch.cuda.current_stream().wait_stream(_side[dev])
+    _keep.clear()
+    _keep_bytes[0] = 0
 
 
 def _wgrad(fn, *tensors):
@@ -66,8 +77,10 @@ def _wgrad(fn, *tensors):
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         fn()
-    for t in tensors:
-        t.record_stream(side)
+    _keep.extend(tensors)
+    _keep_bytes[0] += sum(t.numel() * 4 for t in tensors)
+    if _keep_bytes[0] > _KEEP_LIMIT:
+        join_side_stream()
 
 
 def grad_buffer(p):

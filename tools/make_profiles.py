@@ -1,0 +1,60 @@
+"""Turn the raw rocprofv3 outputs merged back under gpurun_out/ into the committed summaries in profiles/.
+
+    python tools/make_profiles.py <tag>      (e.g. r01_v4)
+expects gpurun_out/prof (kernel stats), gpurun_out/pmc_fetch, gpurun_out/pmc_write, gpurun_out/bench.log
+"""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+
+tag = sys.argv[1]
+
+
+def one(pat):
+    g = sorted(glob.glob(pat))
+    assert g, pat
+    return g[-1]
+
+
+shutil.copy(one("gpurun_out/prof/*/*kernel_stats.csv"), f"profiles/{tag}_bench_b32_384_kernel_stats.csv")
+shutil.copy("gpurun_out/bench.log", f"profiles/{tag}_bench_b32_384.json")
+
+
+def agg(path, cname):
+    d = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == cname:
+            d[r["Kernel_Name"]][0] += 1
+            d[r["Kernel_Name"]][1] += float(r["Counter_Value"])
+    return d
+
+
+F = agg(one("gpurun_out/pmc_fetch/*/*counter_collection.csv"), "FETCH_SIZE")
+W = agg(one("gpurun_out/pmc_write/*/*counter_collection.csv"), "WRITE_SIZE")
+with open(f"profiles/{tag}_pmc_hbm_traffic_per_kernel.csv", "w") as fo:
+    fo.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of: bench.py --steps 1 --warmup 1 (B=32, 384x384)\n")
+    fo.write("# counter values are KiB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE reports half of wide\n")
+    fo.write("# coalesced reads (MI355X_MICROARCH.md, HBM); the x2 is calibrated for 16-byte loads only, so it is an upper bound for\n")
+    fo.write("# the 4-byte gather loads of the implicit-GEMM kernels\n")
+    fo.write("kernel,launches,fetch_KiB_per_launch_raw,write_KiB_per_launch,hbm_bytes_per_launch_corrected\n")
+    for k in sorted(F, key=lambda k: -F[k][1]):
+        n, fs = F[k]
+        ws = W.get(k, [n, 0])[1]
+        fo.write(f"\"{k}\",{n},{fs / n:.1f},{ws / n:.1f},{(2 * fs + ws) / n * 1024:.0f}\n")
+fam = {"wfae_conv4x4s2_wgrad": "0, 4, 1, true", "wfae_conv4x4s2_up": "1, 3, 2, true", "wfae_conv4x4s2_down": "0, 2, 0, true"}
+out = {}
+for ep, sig in fam.items():
+    n = fs = ws = 0
+    for k in F:
+        if "gemm_kernel<" in k and sig in k:
+            n += F[k][0]
+            fs += F[k][1]
+            ws += W.get(k, [0, 0])[1]
+    if n:
+        out[ep] = {"hbm_bytes_per_launch": (2 * fs + ws) / n * 1024, "fetch_raw_KiB": fs / n, "write_KiB": ws / n, "launches": n,
+                   "source": f"profiles/{tag}_pmc_hbm_traffic_per_kernel.csv"}
+json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))

@@ -31,7 +31,8 @@ def _worker(rank, world, port, q):
     torch.manual_seed(100 + rank)                      # different init per rank: the broadcast must fix it
     net = PosAwareAE_TF().to(dev).train()
     opt = FusedAdamW(net.parameters(), lr=5e-5, weight_decay=1e-4)
-    dp = parallel.DataParallelTrainer(net, opt, bucket_mb=64)
+    dp = parallel.DataParallelTrainer(net, opt, bucket_mb=64, overlap=True)
+    assert len(dp._hooks) == 2, "backward hooks for the overlapped all-reduce were not installed"
     a = opt.arenas[0]
     p0 = a.flat_p.clone()
     Fn.set_wgrad_overlap(True)

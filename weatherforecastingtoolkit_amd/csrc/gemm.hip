@@ -675,35 +675,39 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   const int l31 = lane & 31, lh = lane >> 5;
   const int l15 = lane & 15, lq = lane >> 4;
 
+  // Operand fragments of k-step s+1 are read from LDS before the MFMAs of k-step s are issued, so the
+  // LDS latency (~100+ cycles) hides behind 4-8 MFMAs instead of stalling the wave at every k-step.
   auto compute = [&](int buf) {
-    if constexpr (MF == 32) {
+    constexpr int KS = MF == 32 ? 2 : 4;       // k per MFMA
+    constexpr int NSTEP = BK / KS;
+    float a[2][TM], b[2][TN];
+    auto frag = [&](int st, int slot) {
+      if constexpr (MF == 32) {
 #pragma unroll
-      for (int kk = 0; kk < BK; kk += 2) {
-        float a[TM], b[TN];
+        for (int i = 0; i < TM; ++i) a[slot][i] = As[buf][st * 2 + lh][wm0 + i * 32 + l31];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = As[buf][kk + lh][wm0 + i * 32 + l31];
+        for (int j = 0; j < TN; ++j) b[slot][j] = Bs[buf][st * 2 + lh][wn0 + j * 32 + l31];
+      } else {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kk + lh][wn0 + j * 32 + l31];
+        for (int i = 0; i < TM; ++i) a[slot][i] = As[buf][st * 4 + lq][wm0 + i * 16 + l15];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) b[slot][j] = Bs[buf][st * 4 + lq][wn0 + j * 16 + l15];
       }
-    } else {
+    };
+    frag(0, 0);
 #pragma unroll
-      for (int kk = 0; kk < BK; kk += 4) {
-        float a[TM], b[TN];
+    for (int st = 0; st < NSTEP; ++st) {
+      const int cur = st & 1;
+      if (st + 1 < NSTEP) frag(st + 1, cur ^ 1);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = As[buf][kk + lq][wm0 + i * 16 + l15];
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kk + lq][wn0 + j * 16 + l15];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (MF == 32)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+        }
     }
   };
 
@@ -979,8 +983,8 @@ int launch_gemm(const GemmP& p, int zdim, hipStream_t st, const char* what, int 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // choose split count so tiles*splits covers the chip a few times over
-inline int pick_splits(int M, int N, int K, size_t ws_bytes, int* k_per_split) {
-  const long tiles = (long)cdiv(M, M > 64 ? 128 : (M > 32 ? 64 : 32)) * cdiv(N, BN);
+inline int pick_splits(int M, int N, int K, size_t ws_bytes, int* k_per_split, bool big_tiles = false) {
+  const long tiles = (long)cdiv(M, big_tiles && M >= 256 ? 256 : (M > 64 ? 128 : (M > 32 ? 64 : 32))) * cdiv(N, BN);
   const int stages = cdiv(K, BK);
   long want = (1024 + tiles - 1) / tiles;
   if (want < 1) want = 1;
@@ -1193,7 +1197,8 @@ int wfae_conv4x4s2_wgrad(const float* lo, const float* hi, float* dw, int NB, in
   p.b_vec = (Wlo % 8 == 0) && (int64_t)NB * Chi * 4 * HWlo < (1ll << 31);  // pixel cursor + 32-bit offsets
   p.c_vec = aligned16(ws);
   p.Chi = Chi; p.Clo = Clo; p.Hlo = Hlo; p.Wlo = Wlo;
-  const int splits = pick_splits(p.M, p.N, p.K, ws_bytes, &p.k_per_split);
+  // 256-row tiles (launch_gemm picks them for grids >= 1024 blocks): size the split for that tiling
+  const int splits = pick_splits(p.M, p.N, p.K, ws_bytes, &p.k_per_split, true);
   int rc = launch_gemm<A_KCONTIG, B_WGRAD, E_SLAB>(p, splits, (hipStream_t)stream, "conv4x4s2_wgrad");
   if (rc) return rc;
   return splitk_finish((float*)ws, dw, nullptr, (long)Clo * Chi * 16, Chi * 16, splits, accumulate,

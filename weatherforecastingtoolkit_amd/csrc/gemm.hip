@@ -73,10 +73,12 @@ struct GemmP {
 // global traffic is dwordx4.  Loaders are BRANCH-FREE: out-of-range elements load from a clamped
 // (always valid) address and are zeroed by a select, so the compiler issues every global load of
 // a stage back-to-back and waits once, after the MFMAs of the current stage.
+// second launch-bound argument = minimum waves per SIMD: 2 for the 256-row tile (128 accumulator registers),
+// 4 otherwise (3 for the down/up gathers, which spill at 128) — the unified VGPR/AGPR file has 512 entries per lane and SIMD
 template <int BM, int WMW, int WNW, int AK, int BKD, int EK, bool VEC, int MF>
-__global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
+__global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP) ? 3 : 4))) void gemm_kernel(GemmP p) {
   static_assert(WMW * WNW == 4, "4 waves");
-  static_assert(MF == 32 || MF == 16, "MFMA tile 32x32x2 or 16x16x4");
+  static_assert(MF == 32, "v_mfma_f32_32x32x2_f32 (the 16x16x4 form measured the same rate and was dropped)");
   constexpr int WROWS = BM / WMW, WCOLS = BN / WNW;  // wave tile
   constexpr int TM = WROWS / MF;
   constexpr int TN = WCOLS / MF;
@@ -673,26 +675,24 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   const int wm0 = (wave / WNW) * WROWS;
   const int wn0 = (wave % WNW) * WCOLS;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int l15 = lane & 15, lq = lane >> 4;
 
-  // Operand fragments of k-step s+1 are read from LDS before the MFMAs of k-step s are issued, so the
-  // LDS latency (~100+ cycles) hides behind 4-8 MFMAs instead of stalling the wave at every k-step.
+  // INTERLEAVED sub-tiles: MFMA tile i of a wave covers rows  wm0 + l*TM + i  (l = 0..31), not a
+  // contiguous 32-row block, and tile j covers columns  wn0 + l*TN + j.  The TM (TN) operand values a
+  // lane needs for one k are then ADJACENT in the natural As[k][m] / Bs[k][n] images, so one
+  // ds_read_b128 / ds_read_b64 replaces 4 / 2 ds_read_b32.  A register-free probe of this loop
+  // (tools/probe/lds_mfma.hip) sustains 149 TF for 64x64 wave tiles against 114 TF with scalar reads:
+  // the LDS instruction count, not the MFMA pipe, was the ceiling.  Only the epilogue's row/column
+  // map changes.  Fragments of k-step s+1 are read before the MFMAs of k-step s are issued.
+  typedef float vecA __attribute__((ext_vector_type(TM)));
+  typedef float vecB __attribute__((ext_vector_type(TN)));
   auto compute = [&](int buf) {
-    constexpr int KS = MF == 32 ? 2 : 4;       // k per MFMA
-    constexpr int NSTEP = BK / KS;
-    float a[2][TM], b[2][TN];
+    static_assert(MF == 32, "interleaved operand reads are built for v_mfma_f32_32x32x2_f32");
+    constexpr int NSTEP = BK / 2;
+    vecA a[2];
+    vecB b[2];
     auto frag = [&](int st, int slot) {
-      if constexpr (MF == 32) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[slot][i] = As[buf][st * 2 + lh][wm0 + i * 32 + l31];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[slot][j] = Bs[buf][st * 2 + lh][wn0 + j * 32 + l31];
-      } else {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[slot][i] = As[buf][st * 4 + lq][wm0 + i * 16 + l15];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[slot][j] = Bs[buf][st * 4 + lq][wn0 + j * 16 + l15];
-      }
+      a[slot] = *reinterpret_cast<const vecA*>(&As[buf][st * 2 + lh][wm0 + l31 * TM]);
+      b[slot] = *reinterpret_cast<const vecB*>(&Bs[buf][st * 2 + lh][wn0 + l31 * TN]);
     };
     frag(0, 0);
 #pragma unroll
@@ -703,10 +703,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          if constexpr (MF == 32)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-          else
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
         }
     }
   };
@@ -749,14 +746,18 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   }
 
   // ---------------------------------------------------------------- epilogue
-  // C/D map of 32x32 MFMA: col(n) = lane & 31, row(m) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  // C/D map of 32x32 MFMA: column = lane & 31, row R = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5);
+  // with the interleaved sub-tiles: m = m0 + wm0 + R*TM + i,  n = n0 + wn0 + (lane & 31)*TN + j.
   if constexpr (VEC && EK != E_UP) {
-    // Stage 16-row slices of the wave tile through LDS (the operand buffers are free after the
-    // final barrier) and write whole 16-byte pieces: 4x fewer, 4x wider stores / residual loads.
+    // Stage slices of the wave tile through LDS (the operand buffers are free after the final barrier)
+    // and write whole 16-byte pieces: 4x fewer, 4x wider stores / residual loads.  One slice = the 8
+    // tile rows R in [8g, 8g+8) of all TM sub-tiles = 8*TM consecutive output rows.
     constexpr int COLS = WCOLS;
+    constexpr int SROWS = 8 * TM;        // rows per slice
     constexpr int F4R = COLS / 4;        // float4 per row
     constexpr int RPI = 64 / F4R;        // rows per wave-instruction
-    float* sw = smem + wave * (16 * COLS);
+    static_assert(4 * SROWS * COLS <= A_FLOATS + B_FLOATS, "epilogue staging fits the operand buffers");
+    float* sw = smem + wave * (SROWS * COLS);
     const int c4 = lane % F4R, rsub = lane / F4R;
     const int n = n0 + wn0 + c4 * 4;
     const bool nok = n < p.N;
@@ -775,30 +776,22 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
       mstride = p.N;
     }
 #pragma unroll
-    for (int sl = 0; sl < WROWS / 16; ++sl) {
-      __builtin_amdgcn_wave_barrier();
-      if constexpr (MF == 32) {
-        const int i = sl >> 1, q = sl & 1;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r8 = 0; r8 < 8; ++r8) {
-            const int r = q * 8 + r8;
-            const int row = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lh;
-            sw[row * COLS + j * 32 + l31] = acc[i][j][r];
-          }
-      } else {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sw[(lq * 4 + r) * COLS + j * 16 + l15] = acc[sl][j][r];
-      }
+    for (int g = 0; g < 4; ++g) {  // R in [8g, 8g+8): registers 4g..4g+3, both lane halves
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int it = 0; it < 16 / RPI; ++it) {
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int row = (r4 + 4 * lh) * TM + i;  // (R - 8g) * TM + i
+#pragma unroll
+          for (int j = 0; j < TN; ++j) sw[row * COLS + l31 * TN + j] = acc[i][j][4 * g + r4];
+        }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < SROWS / RPI; ++it) {
         const int row = it * RPI + rsub;
         float4 v = *reinterpret_cast<const float4*>(&sw[row * COLS + c4 * 4]);
-        const int m = m0 + wm0 + sl * 16 + row;
+        const int m = m0 + wm0 + g * SROWS + row;
         if (nok && m < p.M) {
           float* dst = cb + (long)m * mstride;
           if constexpr (EK == E_BATCHED) {
@@ -822,7 +815,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   } else {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn0 + j * MF + (MF == 32 ? l31 : l15);
+      const int n = n0 + wn0 + l31 * TN + j;
       if (n >= p.N) continue;
       float* cb;
       const float* rbp = nullptr;
@@ -847,7 +840,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < NREG; ++r) {
-          const int m = m0 + wm0 + i * MF + (MF == 32 ? (r & 3) + 8 * (r >> 2) + 4 * lh : lq * 4 + r);
+          const int m = m0 + wm0 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * TM + i;
           if (m < p.M) {
             float v = acc[i][j][r];
             if constexpr (EK == E_BATCHED) {
@@ -862,7 +855,6 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   }
 }
 
-// out[i] = (beta ? out[i] : 0) + sum_z slab[z][i] (+ bias_n[i % N])   (fixed order => deterministic)
 // transpose_m > 0: the slab is [M = transpose_m][N] and `out` is [N][M]
 __device__ __forceinline__ long out_index(long i, int N, int transpose_m) {
   if (transpose_m <= 0) return i;

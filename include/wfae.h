@@ -99,9 +99,9 @@ int wfae_conv4x4s2_wgrad(const float* lo, const float* hi, float* dw, int NB, in
 /* ---- direct (im2col-free, LDS-tiled VALU) convolution ---------------------
  * grouped 3x3 pad 1 of Bottleneck (ae_64x8x8_lin.py:17), the 128->1 3x3 output
  * conv (:84) and the 1->256 4x4 s2 input conv (:31 with in_ch=1).
- * w is (Cout, Cin/groups, KS, KS).  KS in {3,4}, stride in {1,2}.
- * bwd_data supports stride 1 only (stride-2 data gradients go through
- * wfae_conv4x4s2_up). */
+ * w is (Cout, Cin/groups, KS, KS).  (KS, stride) in {(3,1), (4,2), (4,1)}; (4,1) is the fourth conv of the
+ * PatchGAN discriminator (losses/model.py:137).  bwd_data supports stride 1 only (H, W = input dims;
+ * stride-2 data gradients go through wfae_conv4x4s2_up). */
 int wfae_dconv_fwd(const float* x, const float* w, const float* bias, float* y, int NB, int Cin,
                    int Cout, int H, int W, int KS, int stride, int pad, int groups,
                    wfae_stream_t stream);
@@ -128,7 +128,7 @@ int wfae_gconv3x3_bwd_weight(const float* dy, const float* x, float* dw, int NB,
  *   scale = gamma*invstd and shift = beta - mean*scale, and updates
  *   running_mean/var (unbiased var, momentum) in place.
  * bn_fold_eval: scale/shift from running statistics (module.eval()).
- * bn_act_fwd: y = act(x*scale[c] + shift[c]); act 0 = identity, 1 = exact GELU.
+ * bn_act_fwd: y = act(x*scale[c] + shift[c]); act 0 = identity, 1 = exact GELU, 2 = LeakyReLU(0.2).
  * bn_act_bwd: given dy = dL/dy, x and the saved statistics, computes
  *   dgamma, dbeta and dx (+ res, the residual-branch gradient of
  *   Bottleneck, :22).  training=0 uses the eval-mode formula. */
@@ -156,6 +156,45 @@ int wfae_add(const float* a, const float* b, float* out, int64_t n, wfae_stream_
 /* out[c] (+)= sum_{o,i} x[o,c,i]: conv-bias / pos_emb / linear-bias gradients */
 int wfae_reduce_sum(const float* x, int outer, int C, int inner, float* out, int accumulate,
                     void* ws, size_t ws_bytes, wfae_stream_t stream);
+
+/* ---- 4x4 stride-1 convolution on the MFMA GEMM (PatchGAN layer 4: Conv2d(256, 512, 4, stride=1, padding=1,
+ * bias=False), pipeline/models/autoencoderkl/losses/model.py:137).
+ * fwd, transposed = 0: x (NB,Cin,H,W) -> y (NB,Cout,H+2pad-3,W+2pad-3);
+ * fwd, transposed = 1: the data gradient — x is dy (NB,Cout,H,W) -> y = dx (NB,Cin,H+3-2pad,W+3-2pad).
+ * bwd_weight: dy (NB,Cout,H+2pad-3,W+2pad-3), x (NB,Cin,H,W) -> dw (Cout,Cin,4,4).
+ * The channel count of the operand that is read must be a multiple of 16 (else WFAE_ERR_UNSUPPORTED; use
+ * wfae_dconv_*).  Workspace: padded copy of the input + padded-width output + packed weights
+ * (+ split-K slabs for bwd_weight). */
+int wfae_conv4x4s1_fwd(const float* x, const float* w, float* y, int NB, int Cin, int Cout, int H, int W, int pad,
+                       int transposed, void* ws, size_t ws_bytes, wfae_stream_t stream);
+int wfae_conv4x4s1_bwd_weight(const float* dy, const float* x, float* dw, int NB, int Cin, int Cout, int H, int W,
+                              int pad, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
+
+/* ---- PatchGAN discriminator pieces (pipeline/models/autoencoderkl/losses/model.py:100-150;
+ * hinge loss contperceptual.py:19-23; generator term -mean(D(fake)) experiments/ae_v2/train.py:78).
+ * leaky_relu: nn.LeakyReLU(0.2).  BatchNorm + LeakyReLU is wfae_bn_act_* with act = 2.
+ * pad2d: zero-pad every plane by `pad` pixels (crop = 1: the inverse crop, its gradient) — the final
+ *   Conv2d(512, 1, kernel_size=1, padding=1) of the reference is pad + 1x1 conv.
+ * mean: out[0] = weight * mean(x) (hinge = 0) or weight * mean(relu(1 + sign*x)) (hinge = 1).
+ * scale: y = x * scale * (scale_dev ? scale_dev[0] : 1)  (adaptive weight, gradient clipping). */
+int wfae_leaky_relu_fwd(const float* x, float* y, int64_t n, wfae_stream_t stream);
+int wfae_leaky_relu_bwd(const float* dy, const float* x, float* dx, int64_t n, wfae_stream_t stream);
+int wfae_pad2d(const float* x, float* y, int64_t planes, int H, int W, int pad, int crop, wfae_stream_t stream);
+int wfae_mean_fwd(const float* x, float* out, int64_t n, int hinge, float sign, float weight, void* ws,
+                  size_t ws_bytes, wfae_stream_t stream);
+int wfae_mean_bwd(const float* x, const float* gout, float* dx, int64_t n, int hinge, float sign, float weight,
+                  wfae_stream_t stream);
+int wfae_scale(const float* x, const float* scale_dev, float scale, float* y, int64_t n, wfae_stream_t stream);
+/* gradient clipping by global norm (Lightning clip_gradients -> torch.nn.utils.clip_grad_norm_,
+ * experiments/ae_v2_2/train.py:140,155): sumsq_parts are wfae_sumsq results of the gradient buffers;
+ * total = pre_scale * sqrt(sum) (pre_scale = 1/world when the buffers hold rank-summed gradients);
+ * out2[0] = min(1, max_norm / (total + 1e-6)), out2[1] = total; apply with wfae_scale(scale_dev = out2). */
+int wfae_clip_coef(const double* sumsq_parts, int n_parts, float max_norm, float pre_scale, float* out2,
+                   wfae_stream_t stream);
+/* Loss.calculate_adaptive_weight (experiments/ae_v2_2/train.py:46-52, ae_v2/train.py:46-52):
+ * out[0] = clamp(disc_weight * sqrt(sumsq_rec) / (sqrt(sumsq_disc) + 1e-4), 0, 1e4). */
+int wfae_adaptive_weight(const double* sumsq_rec, const double* sumsq_disc, float disc_weight, float* out,
+                         wfae_stream_t stream);
 
 /* ---- sigmoid + L1 loss (ae_64x8x8_lin.py:102 + experiments/ae_v2/train.py:55)
  * recon = sigmoid(h); loss[0] = weight * mean |recon - x|  (fp64 accumulation).

@@ -22,6 +22,9 @@ Reference lines followed (relative to /root/reference):
   adamw_optimizer       pipeline/helpers.py:63-74
   cosine_warmup         pipeline/helpers.py:76-107
   metrics.ssim / psnr   pipeline/metrics.py:71-93
+  NLayerDiscriminator   pipeline/models/autoencoderkl/losses/model.py:100-150
+  hinge_d_loss          pipeline/models/autoencoderkl/losses/contperceptual.py:19-23
+  adaptive weight, G/D  experiments/ae_v2_2/train.py:54-95 (Loss), :126-168 (training_step)
 """
 from __future__ import annotations
 
@@ -238,3 +241,83 @@ def train_step(x, sd, opt=None, sched=None, recon_weight=1.0, perceptual_weight=
         if sched is not None:
             sched.step()
     return recon.detach(), z.detach(), float(loss.detach())
+
+
+# ------------------------------------------------------------- AE + GAN ---
+def disc_forward(x, sd, training=True, p="main"):
+    """NLayerDiscriminator.forward — autoencoderkl/losses/model.py:123-150: Conv(4,s2,p1,bias)+LReLU,
+    [Conv(4,s2,p1)+BN+LReLU]*(n-1), Conv(4,s1,p1)+BN+LReLU, Conv(1x1, padding=1, bias)."""
+    idx = sorted({int(k.split(".")[1]) for k in sd if k.startswith(p + ".") and k.endswith(".weight") and sd[k].ndim == 4})
+    h = F.leaky_relu(F.conv2d(x, sd[f"{p}.{idx[0]}.weight"], sd[f"{p}.{idx[0]}.bias"], stride=2, padding=1), 0.2)
+    for j, i in enumerate(idx[1:-1]):
+        stride = 1 if j == len(idx) - 3 else 2
+        h = F.conv2d(h, sd[f"{p}.{i}.weight"], None, stride=stride, padding=1)
+        h = F.leaky_relu(_bn(h, sd, f"{p}.{i + 1}", training), 0.2)
+    return F.conv2d(h, sd[f"{p}.{idx[-1]}.weight"], sd[f"{p}.{idx[-1]}.bias"], stride=1, padding=1)
+
+
+def hinge_d_loss(logits_real, logits_fake):
+    """contperceptual.py:19-23"""
+    return 0.5 * (torch.mean(F.relu(1.0 - logits_real)) + torch.mean(F.relu(1.0 + logits_fake)))
+
+
+def adaptive_weight(rec_loss, g_loss, last_layer, disc_weight=1.0):
+    """Loss.calculate_adaptive_weight — experiments/ae_v2_2/train.py:46-52"""
+    rec_grad = torch.autograd.grad(rec_loss, last_layer, retain_graph=True)[0]
+    disc_grad = torch.autograd.grad(g_loss, last_layer, retain_graph=True)[0]
+    d_weight = torch.norm(rec_grad) / (torch.norm(disc_grad) + 1e-4)
+    return torch.clamp(disc_weight * d_weight, 0.0, 1e4).detach()
+
+
+def gan_train_step(x, sd, dsd, g_opt, d_opt, g_sched=None, d_sched=None, gan_on=True, disc_weight=1.0,
+                   recon_weight=1.0, clip=1.0):
+    """one manual-optimisation step of experiments/ae_v2_2/train.py:126-159: forward once; generator
+    loss (L1 + d_weight * -mean(D(x_hat))) with the discriminator frozen (Lightning toggle_optimizer),
+    backward, clip-by-norm, AdamW + scheduler; then hinge discriminator loss on (x, x_hat.detach()),
+    backward, clip, AdamW + scheduler.  gan_on = (global_step >= disc_start)."""
+    ae_params = [q for _, q in trainable(sd)]
+    d_params = [q for _, q in trainable(dsd)]
+    log = {}
+    recon, z = forward(x, sd, training=True)
+    # ---- generator
+    for q in d_params:
+        q.requires_grad_(False)
+    rec_loss = recon_weight * F.l1_loss(recon, x, reduction="mean")
+    if gan_on:
+        g_loss = -torch.mean(disc_forward(recon, dsd, True))
+        d_weight = adaptive_weight(rec_loss, g_loss, sd[_last_layer_key(sd)], disc_weight)
+        loss = rec_loss + d_weight * g_loss
+        log.update(g_loss=float(g_loss.detach()), d_weight=float(d_weight))
+    else:
+        loss = rec_loss
+    log.update(rec_loss=float(rec_loss.detach()), total_loss=float(loss.detach()))
+    loss.backward()
+    log["g_grad_norm"] = float(torch.nn.utils.clip_grad_norm_(ae_params, clip))
+    g_opt.step()
+    if g_sched is not None:
+        g_sched.step()
+    for q in ae_params:
+        q.grad = None
+    for q in d_params:
+        q.requires_grad_(True)
+    # ---- discriminator
+    if gan_on:
+        logits_real = disc_forward(x.detach(), dsd, True)
+        logits_fake = disc_forward(recon.detach(), dsd, True)
+        d_loss = hinge_d_loss(logits_real, logits_fake)
+        d_loss.backward()
+        log.update(disc_loss=float(d_loss.detach()), logits_real=float(logits_real.detach().mean()),
+                   logits_fake=float(logits_fake.detach().mean()))
+        log["d_grad_norm"] = float(torch.nn.utils.clip_grad_norm_(d_params, clip))
+        d_opt.step()
+        if d_sched is not None:
+            d_sched.step()
+        for q in d_params:
+            q.grad = None
+    return recon.detach(), log
+
+
+def _last_layer_key(sd):
+    """Model.get_last_layer — experiments/ae_v2_2/train.py:123-124: autoencoder.dec[-1].weight"""
+    n = max(int(k.split(".")[1]) for k in sd if k.startswith("dec."))
+    return f"dec.{n}.weight"

@@ -321,6 +321,155 @@ def g5_tf():
     save("g5_tf128_b3", **out)
 
 
+# ------------------------------------------------------------------ G6 ---
+def g6_gan():
+    """AE+GAN (experiments/ae_v2_2): (a) the reference PatchGAN discriminator alone, forward + backward;
+    (b) two manual-optimisation steps with the reference AE and discriminator modules, the step order of
+    ae_v2_2/train.py:126-159 (the reference's own Loss class cannot be constructed offline: LPIPS())."""
+    import pipeline.models.autoencoderkl.losses.model as refd
+    out = {}
+    dspec = synth.disc_state_dict_spec(1, 64, 3)
+    dnp = synth.synth_state_dict(dspec, seed=5)
+
+    def make_disc():
+        d = refd.NLayerDiscriminator(input_nc=1, n_layers=3, use_actnorm=False).apply(refd.weights_init)
+        assert list(d.state_dict().keys()) == [k for k, _, _ in dspec], "discriminator key order differs"
+        d.load_state_dict({k: (T(v) if v.ndim else torch.tensor(0)) for k, v in dnp.items()}, strict=True)
+        return d.train()
+
+    # ---- (a) discriminator alone
+    disc = make_disc()
+    x = T(synth.uniform_frames(2, 128, seed=77)).requires_grad_(True)
+    y = disc(x)
+    gy = T(synth.uniform(6, "disc/gy", tuple(y.shape), -1, 1))
+    y.backward(gy)
+    osd = orc.to_torch_sd(dnp)
+    ox = x.detach().clone().requires_grad_(True)
+    oy = orc.disc_forward(ox, osd, True)
+    oy.backward(gy)
+    assert torch.equal(oy, y) and torch.equal(ox.grad, x.grad), "oracle discriminator differs"
+    out["a/y"], out["a/gy"], out["a/gx"] = y.detach().numpy(), gy.numpy(), x.grad.numpy()
+    names, norms = [], []
+    for n, p in disc.named_parameters():
+        names.append(n)
+        norms.append(p.grad.double().norm().item())
+        assert torch.equal(p.grad, osd[n].grad), n
+        if p.numel() <= 4096:
+            out[f"a/grad/{n}"] = p.grad.numpy()
+        else:
+            out[f"a/grad_head/{n}"] = p.grad.flatten()[:2048].numpy()
+    out["a/grad_names"], out["a/grad_norms"] = np.array(names), np.array(norms)
+    for n, b in disc.named_buffers():
+        out[f"a/after/{n}"] = b.detach().numpy()
+    disc.eval()
+    with torch.no_grad():
+        out["a/eval_y"] = disc(x.detach()).numpy()
+
+    # ---- (a32) kink-free case: LeakyReLU'(x) is discontinuous at 0, so an independent fp32 implementation
+    # flips the slope of any pre-activation within rounding distance of 0 (about one element per million).
+    # Search a 32x32 input whose pre-activations all stay clear of the kink: gradients then compare strictly.
+    for seed in range(200):
+        disc = make_disc()
+        mins = []
+        hooks = [m.register_forward_pre_hook(lambda mod, inp: mins.append(inp[0].detach().abs().min().item()))
+                 for m in disc.modules() if isinstance(m, nn.LeakyReLU)]
+        x32 = T(synth.uniform(seed, "disc32/x", (2, 1, 32, 32), 0, 1)).requires_grad_(True)
+        y32 = disc(x32)
+        for h in hooks:
+            h.remove()
+        if min(mins) > 3e-5:
+            break
+    else:
+        raise RuntimeError("no kink-free seed found")
+    print(f"kink-free 32x32 discriminator case: seed {seed}, min |pre-activation| {min(mins):.2e}")
+    gy32 = T(synth.uniform(6, "disc32/gy", tuple(y32.shape), -1, 1))
+    y32.backward(gy32)
+    out["a32/seed"], out["a32/min_preact"] = np.int64(seed), np.float64(min(mins))
+    out["a32/y"], out["a32/gy"], out["a32/gx"] = y32.detach().numpy(), gy32.numpy(), x32.grad.numpy()
+    for n, p in disc.named_parameters():
+        if p.numel() <= 4096:
+            out[f"a32/grad/{n}"] = p.grad.numpy()
+        else:
+            out[f"a32/grad_head/{n}"] = p.grad.flatten()[:2048].numpy()
+        out[f"a32/grad_norm/{n}"] = np.float64(p.grad.double().norm().item())
+
+    # ---- (b) two G-then-D steps at 128^2, B=2
+    spec = synth.ae_state_dict_spec(128)
+    np_sd = synth.synth_state_dict(spec, seed=0)
+    net = _make_ref_net(128)
+    net.load_state_dict({k: (T(v) if v.ndim else torch.tensor(0)) for k, v in np_sd.items()}, strict=True)
+    net.train()
+    disc = make_disc()
+    xb = T(synth.uniform_frames(2, 128, seed=1234))
+    lr, wd, total_steps, warm, clip = 5e-5, 1e-3, 40, 4.0, 1.0
+    g_opt = orc.make_optimizer(net.parameters(), lr=lr, weight_decay=wd)
+    d_opt = orc.make_optimizer(disc.parameters(), lr=lr, weight_decay=wd)
+    g_sch = orc.make_scheduler(g_opt, 5e-6, 5e-7, 5e-5, total_steps, warm)
+    d_sch = orc.make_scheduler(d_opt, 5e-6, 5e-7, 5e-5, total_steps, warm)
+    osd, odsd = orc.to_torch_sd(np_sd), orc.to_torch_sd(dnp)
+    og = orc.make_optimizer([p for _, p in orc.trainable(osd)], lr=lr, weight_decay=wd)
+    od = orc.make_optimizer([p for _, p in orc.trainable(odsd)], lr=lr, weight_decay=wd)
+    ogs = orc.make_scheduler(og, 5e-6, 5e-7, 5e-5, total_steps, warm)
+    ods = orc.make_scheduler(od, 5e-6, 5e-7, 5e-5, total_steps, warm)
+    idx = np.linspace(0, 127, LATTICE).round().astype(np.int64)
+    out["b/lattice"] = idx
+    out["b/cfg"] = np.array([lr, wd, total_steps, warm, clip])
+    steps = 2
+    for s in range(steps):
+        log = {}
+        recon, _ = net(xb)
+        # generator (Lightning toggle_optimizer freezes the discriminator's parameters)
+        for q in disc.parameters():
+            q.requires_grad_(False)
+        rec_loss = 1.0 * F.l1_loss(recon, xb, reduction="mean")
+        g_loss = -torch.mean(disc(recon))
+        last = net.dec[-1].weight
+        rec_grad = torch.autograd.grad(rec_loss, last, retain_graph=True)[0]
+        disc_grad = torch.autograd.grad(g_loss, last, retain_graph=True)[0]
+        d_weight = torch.clamp(1.0 * torch.norm(rec_grad) / (torch.norm(disc_grad) + 1e-4), 0.0, 1e4).detach()
+        loss = rec_loss + d_weight * g_loss
+        loss.backward()
+        if s == 0:
+            out["b/g_dec_last_w"] = last.grad.numpy().copy()
+            out["b/rec_grad_last"] = rec_grad.numpy().copy()
+            out["b/disc_grad_last"] = disc_grad.numpy().copy()
+            out["b/g_grad_names"] = np.array([n for n, _ in net.named_parameters()])
+            out["b/g_grad_norms"] = np.array([p.grad.double().norm().item() for _, p in net.named_parameters()])
+        log["g_grad_norm"] = float(torch.nn.utils.clip_grad_norm_(net.parameters(), clip))
+        g_opt.step()
+        g_sch.step()
+        g_opt.zero_grad(set_to_none=True)
+        for q in disc.parameters():
+            q.requires_grad_(True)
+        # discriminator
+        logits_real = disc(xb.detach())
+        logits_fake = disc(recon.detach())
+        d_loss = 0.5 * (torch.mean(F.relu(1.0 - logits_real)) + torch.mean(F.relu(1.0 + logits_fake)))
+        d_loss.backward()
+        if s == 0:
+            out["b/d_grad_names"] = np.array([n for n, _ in disc.named_parameters()])
+            out["b/d_grad_norms"] = np.array([p.grad.double().norm().item() for _, p in disc.named_parameters()])
+        log["d_grad_norm"] = float(torch.nn.utils.clip_grad_norm_(disc.parameters(), clip))
+        d_opt.step()
+        d_sch.step()
+        d_opt.zero_grad(set_to_none=True)
+        log.update(rec_loss=rec_loss.item(), g_loss=g_loss.item(), d_weight=d_weight.item(), total_loss=loss.item(),
+                   disc_loss=d_loss.item(), logits_real=logits_real.mean().item(), logits_fake=logits_fake.mean().item())
+        orecon, olog = orc.gan_train_step(xb, osd, odsd, og, od, ogs, ods, True, 1.0, 1.0, clip)
+        assert torch.equal(orecon, recon.detach()), f"oracle recon differs at step {s}"
+        for k, v in log.items():
+            assert olog[k] == v, f"oracle {k} differs at step {s}: {olog[k]} vs {v}"
+            out[f"b/{k}{s}"] = np.float64(v)
+        out[f"b/recon_lattice{s}"] = recon.detach()[:, 0][:, idx][:, :, idx].numpy()
+        out[f"b/ae_param_norms{s}"] = np.array([p.detach().double().norm().item() for _, p in net.named_parameters()])
+        out[f"b/d_param_norms{s}"] = np.array([p.detach().double().norm().item() for _, p in disc.named_parameters()])
+    for k, v in odsd.items():
+        assert torch.equal(v.detach(), disc.state_dict()[k]), f"oracle disc state differs: {k}"
+    for k, v in osd.items():
+        assert torch.equal(v.detach(), net.state_dict()[k]), f"oracle ae state differs: {k}"
+    save("g6_gan128_b2", **out)
+
+
 # ------------------------------------------------------------------ G7 ---
 def g7_metrics():
     """SSIM/PSNR from the restatement (UNPINNED: pytorch_msssim/torchmetrics absent)."""
@@ -377,6 +526,8 @@ def main():
         g_full("g4_full384_b1", 384, 1, 1, "blobs")
     if want("g5"):
         g5_tf()
+    if want("g6"):
+        g6_gan()
     if want("g7"):
         g7_metrics()
     if want("g8"):

@@ -119,6 +119,77 @@ def test_dconv3x3(ops, dev, nb, cin, cout, h, w, groups):
     assert relerr(dw, wr.grad) < TOL
 
 
+@pytest.mark.parametrize("nb,cin,cout,h,w,pad", [
+    (2, 16, 32, 16, 16, 1), (1, 32, 48, 12, 20, 1), (3, 64, 16, 9, 7, 1), (2, 256, 512, 16, 16, 1), (1, 16, 16, 6, 6, 0),
+    (2, 48, 80, 11, 13, 2),
+])
+def test_conv4x4s1_gemm(ops, dev, nb, cin, cout, h, w, pad):
+    """flat-shift MFMA path of the stride-1 4x4 convolution (PatchGAN layer 4) against torch"""
+    x = rnd((nb, cin, h, w), 1)
+    wt = rnd((cout, cin, 4, 4), 2, -0.3, 0.3)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, stride=1, padding=pad)
+    dy = rnd(tuple(ref.shape), 4)
+    ref.backward(dy)
+    assert relerr(ops.conv4x4s1_fwd(x.to(dev), wt.to(dev), pad, False), ref) < TOL
+    if cout % 16 == 0:
+        assert relerr(ops.conv4x4s1_fwd(dy.to(dev), wt.to(dev), pad, True), xr.grad) < TOL
+    dw = torch.empty_like(wt, device=dev)
+    ops.conv4x4s1_bwd_weight(dy.to(dev), x.to(dev), dw, pad)
+    assert relerr(dw, wr.grad) < TOL
+    ops.conv4x4s1_bwd_weight(dy.to(dev), x.to(dev), dw, pad, accumulate=True)
+    assert relerr(dw, 2 * wr.grad) < TOL
+
+
+@pytest.mark.parametrize("nb,cin,cout,h,w", [(2, 1, 8, 16, 16), (1, 8, 4, 9, 12), (2, 3, 5, 7, 7)])
+def test_dconv4x4s1_direct(ops, dev, nb, cin, cout, h, w):
+    """direct (VALU) kernels of the stride-1 4x4 convolution for channel counts the GEMM path does not take"""
+    x = rnd((nb, cin, h, w), 1)
+    wt = rnd((cout, cin, 4, 4), 2, -0.3, 0.3)
+    bias = rnd((cout,), 3)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, bias, stride=1, padding=1)
+    dy = rnd(tuple(ref.shape), 4)
+    ref.backward(dy)
+    assert relerr(ops.dconv_fwd(x.to(dev), wt.to(dev), bias.to(dev), 4, 1, 1, 1), ref) < TOL
+    assert relerr(ops.dconv_bwd_data(dy.to(dev), wt.to(dev), cin, 4, 1, 1), xr.grad) < TOL
+    dw = torch.empty_like(wt, device=dev)
+    ops.dconv_bwd_weight(dy.to(dev), x.to(dev), dw, 4, 1, 1, 1)
+    assert relerr(dw, wr.grad) < TOL
+
+
+def test_gan_elementwise(ops, dev):
+    """LeakyReLU(0.2), BN + LeakyReLU (act = 2), pad/crop, hinge/mean reductions, scale"""
+    x = rnd((3, 6, 9, 11), 1, -2, 2)
+    dy = rnd((3, 6, 9, 11), 2)
+    xr = x.clone().requires_grad_(True)
+    ref = F.leaky_relu(xr, 0.2)
+    ref.backward(dy)
+    assert relerr(ops.leaky_relu_fwd(x.to(dev)), ref) < 1e-6
+    assert relerr(ops.leaky_relu_bwd(dy.to(dev), x.to(dev)), xr.grad) < 1e-6
+    xp = ops.pad2d(x.to(dev), 2)
+    assert relerr(xp, F.pad(x, (2, 2, 2, 2))) == 0
+    assert relerr(ops.crop2d(xp, 2), x) == 0
+    # BatchNorm + LeakyReLU
+    g, b = rnd((6,), 3, 0.8, 1.2), rnd((6,), 4, -0.1, 0.1)
+    xr2, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref2 = F.leaky_relu(F.batch_norm(xr2, None, None, gr, br, True, 0.1, 1e-5), 0.2)
+    ref2.backward(dy)
+    rm, rv = torch.zeros(6, device=dev), torch.ones(6, device=dev)
+    st = ops.bn_stats_train(x.to(dev), g.to(dev), b.to(dev), rm, rv)
+    assert relerr(ops.bn_act_fwd(x.to(dev), st, 2), ref2) < 1e-5
+    dg, db = torch.empty(6, device=dev), torch.empty(6, device=dev)
+    dx = ops.bn_act_bwd(dy.to(dev), x.to(dev), g.to(dev), st, dg, db, None, 2, True)
+    assert relerr(dx, xr2.grad) < 2e-5 and relerr(dg, gr.grad) < 2e-5 and relerr(db, br.grad) < 2e-5
+    # reductions
+    v = rnd((2, 1, 17, 17), 5, -2, 2)
+    assert abs(ops.mean_fwd(v.to(dev), False, 1.0, -1.0).item() + v.mean().item()) < 1e-6
+    assert abs(ops.mean_fwd(v.to(dev), True, -1.0, 0.5).item() - 0.5 * F.relu(1 - v).mean().item()) < 1e-6
+    assert abs(ops.mean_fwd(v.to(dev), True, 1.0, 0.5).item() - 0.5 * F.relu(1 + v).mean().item()) < 1e-6
+    sdev = torch.tensor([0.25], device=dev)
+    assert relerr(ops.scale(v.to(dev), 2.0, sdev), v * 0.5) < 1e-7
+
+
 @pytest.mark.parametrize("nb,c,h,w", [(2, 32, 16, 16), (1, 64, 24, 40), (2, 128, 24, 24), (2, 256, 8, 8), (1, 256, 24, 24),
                                       (3, 32, 7, 9), (1, 64, 33, 35)])
 def test_gconv3x3_blocked(ops, dev, nb, c, h, w):

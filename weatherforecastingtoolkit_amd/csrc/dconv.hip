@@ -257,6 +257,7 @@ int wfae_dconv_fwd(const float* x, const float* w, const float* bias, float* y, 
   hipStream_t st = (hipStream_t)stream;
   if (KS == 3 && stride == 1) return launch_dconv<3, 1, false>(p, NB, st);
   if (KS == 4 && stride == 2) return launch_dconv<4, 2, false>(p, NB, st);
+  if (KS == 4 && stride == 1) return launch_dconv<4, 1, false>(p, NB, st);  // PatchGAN layer 4 (losses/model.py:137)
   return fail(WFAE_ERR_UNSUPPORTED, "dconv_fwd: KS=%d stride=%d unsupported", KS, stride);
 }
 
@@ -266,17 +267,20 @@ int wfae_dconv_bwd_data(const float* dy, const float* w, float* dx, int NB, int 
   WFAE_REQUIRE(NB > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && groups > 0 && Cin % groups == 0 &&
                    Cout % groups == 0,
                WFAE_ERR_BAD_SHAPE, "dconv_bwd_data: bad shape");
-  WFAE_REQUIRE(KS == 3 && 2 * pad == KS - 1, WFAE_ERR_UNSUPPORTED,
-               "dconv_bwd_data: only 3x3 'same' stride-1 convolutions");
+  WFAE_REQUIRE((KS == 3 || KS == 4) && pad <= KS - 1, WFAE_ERR_UNSUPPORTED,
+               "dconv_bwd_data: stride-1 3x3 / 4x4 convolutions");
   WFAE_REQUIRE(NB <= 65535, WFAE_ERR_BAD_SHAPE, "dconv_bwd_data: batch > 65535");
-  // data gradient = convolution of dy (Cout channels) producing Cin channels with
-  // transposed + spatially flipped weights and pad' = KS-1-pad.
+  // data gradient = stride-1 convolution of dy (Cout channels, (H+2pad-KS+1) x (W+2pad-KS+1)) producing the
+  // Cin x H x W input gradient with transposed + spatially flipped weights and pad' = KS-1-pad.
   DConvP p = {};
   p.x = dy; p.w = w; p.bias = nullptr; p.y = dx;
-  p.Cin = Cout; p.Cout = Cin; p.H = H; p.W = W; p.Ho = H; p.Wo = W;
+  p.Cin = Cout; p.Cout = Cin;
+  p.H = H + 2 * pad - KS + 1; p.W = W + 2 * pad - KS + 1;
+  p.Ho = H; p.Wo = W;
   p.pad = KS - 1 - pad; p.groups = groups;
   p.tiles_x = cdiv(p.Wo, 16);
-  return launch_dconv<3, 1, true>(p, NB, (hipStream_t)stream);
+  if (KS == 3) return launch_dconv<3, 1, true>(p, NB, (hipStream_t)stream);
+  return launch_dconv<4, 1, true>(p, NB, (hipStream_t)stream);
 }
 
 int wfae_dconv_bwd_weight(const float* dy, const float* x, float* dw, int NB, int Cin, int Cout,
@@ -339,6 +343,8 @@ int wfae_dconv_bwd_weight(const float* dy, const float* x, float* dw, int NB, in
     if (OB == 4) WFAE_WG(3, 1, 4); else WFAE_WG(3, 1, 1);
   } else if (KS == 4 && stride == 2) {
     if (OB == 4) WFAE_WG(4, 2, 4); else WFAE_WG(4, 2, 1);
+  } else if (KS == 4 && stride == 1) {
+    if (OB == 4) WFAE_WG(4, 1, 4); else WFAE_WG(4, 1, 1);
   } else {
     return fail(WFAE_ERR_UNSUPPORTED, "dconv_bwd_weight: KS=%d stride=%d unsupported", KS, stride);
   }

@@ -34,7 +34,7 @@ constexpr int BN = 128;
 constexpr int NT = 256;
 
 enum AKind { A_KCONTIG = 0, A_MCONTIG = 1 };
-enum BKind { B_NCONTIG = 0, B_KCONTIG = 1, B_DOWN = 2, B_UP = 3, B_WGRAD = 4, B_WGRAD3 = 5 };
+enum BKind { B_NCONTIG = 0, B_KCONTIG = 1, B_DOWN = 2, B_UP = 3, B_WGRAD = 4, B_WGRAD3 = 5, B_TAPN = 6, B_TAPK = 7 };
 enum EKind { E_BATCHED = 0, E_SLAB = 1, E_UP = 2 };
 
 struct GemmP {
@@ -67,7 +67,22 @@ struct GemmP {
   // grouped 3x3 weight gradient (B_WGRAD3): blockIdx.y = group, Chi = total channels,
   // Hlo x Wlo = the (stride-1) image size, cpg = channels per group
   int cpg;
+  // flat-shift 4x4 stride-1 convolution (B_TAPN / B_TAPK): the B operand is a zero-padded activation
+  // stored as planes of stride b_ld = P floats with rows of Wlo = Wp floats; an output position is the
+  // flat index q = oy*Wp + ox, and tap (ky,kx) of channel c reads plane c at q + ky*Wp + kx — a constant
+  // shift per tap, so the convolution is a GEMM over k = tap*Chi + c (Chi = channels, Chi % 16 == 0)
+  // whose B rows are shifted, unaligned views of the same planes.  Columns ox >= Wo are computed and
+  // dropped by the caller.  B_TAPN: B(k,n=q) (forward / data gradient); B_TAPK: B(k=(img,q), n=tap*Chi+c)
+  // (weight gradient).
 };
+
+// 16-byte global access that is only 4-byte aligned (gfx9 global memory runs in unaligned access mode)
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef vf4 __attribute__((aligned(4))) vf4u;
+__device__ __forceinline__ float4 load4u(const float* ptr) {
+  const vf4 v = *reinterpret_cast<const vf4u*>(ptr);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 
 // VEC: every operand/result row is 16-byte aligned and a multiple of 4 floats long, so all
 // global traffic is dwordx4.  Loaders are BRANCH-FREE: out-of-range elements load from a clamped
@@ -136,7 +151,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
   bool g_ok = false;
   int g_hi = 0, g_ky = 0, g_kx = 0;
 
-  if constexpr (BKD == B_NCONTIG) {
+  if constexpr (BKD == B_NCONTIG || BKD == B_TAPN) {
     const int n = n0 + (t & 31) * 4;
     bn_ok = n < p.N;
     const int nn = bn_ok ? n : 0;
@@ -204,6 +219,12 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
   auto ld4raw = [&](const float* base, long off, bool ok) -> float4 {
     return *reinterpret_cast<const float4*>(base + (ok ? off : 0));
   };
+  auto ld4raw_u = [&](const float* base, long off, bool ok) -> float4 {
+    return load4u(base + (ok ? off : 0));
+  };
+  auto tap_off = [&](int tap) -> int { return (tap >> 2) * p.Wlo + (tap & 3); };
+  (void)ld4raw_u;
+  (void)tap_off;
   auto ld1 = [&](const float* base, long off, bool ok) -> float {
     const float v = base[ok ? off : 0];
     return ok ? v : 0.f;
@@ -232,6 +253,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
   int lg_rel[8];          // gather: loop-invariant relative offsets (clamped to a valid tap)
   unsigned lg_static = 0; // gather: loop-invariant validity bits
   int lg_k = 0, c_x = 0, c_iy = 0, c_img = 0;  // wgrad pixel cursor
+  int lt_tap = 0, lt_c = 0;                     // B_TAPN: tap / first channel of the current stage (wave-uniform)
   if constexpr (VEC) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -272,6 +294,30 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
         const int img = k / p.b_hw;
         lb_pk[i] = k - img * p.b_hw;
         lb_off[i] = (long)img * p.b_img + (long)(lb_st[i] ? n : 0) * p.b_ld + lb_pk[i];
+        lb_k[i] = k;
+      }
+    } else if constexpr (BKD == B_TAPN) {
+      lt_tap = k_begin / p.Chi;
+      lt_c = k_begin - lt_tap * p.Chi;
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        lb_k[i] = k_begin + (t >> 5) + i * 8;
+        lb_st[i] = bn_ok;
+        lb_pk[i] = 0;
+        lb_off[i] = bn_base + (long)(lt_c + (t >> 5) + i * 8) * p.b_ld + tap_off(lt_tap);
+      }
+    } else if constexpr (BKD == B_TAPK) {
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        const int idx = t + i * NT;
+        const int n = n0 + (idx >> 2);
+        const int k = k_begin + (idx & 3) * 4;
+        lb_st[i] = n < p.N;
+        const int nn = lb_st[i] ? n : 0;
+        const int tap = nn / p.Chi, c = nn - tap * p.Chi;
+        const int img = k / p.b_hw;
+        lb_pk[i] = k - img * p.b_hw;
+        lb_off[i] = (long)img * p.b_img + (long)c * p.b_ld + tap_off(tap) + lb_pk[i];
         lb_k[i] = k;
       }
     } else if constexpr (BKD == B_DOWN) {
@@ -324,7 +370,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
       if (!la_st[i]) la_off[i] = 0;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i)
-      if constexpr (BKD == B_NCONTIG || BKD == B_KCONTIG)
+      if constexpr (BKD == B_NCONTIG || BKD == B_KCONTIG || BKD == B_TAPN || BKD == B_TAPK)
         if (!lb_st[i]) lb_off[i] = 0;
   }
 
@@ -349,11 +395,14 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
   };
 
   auto load_b_lean = [&]() {
-    if constexpr (BKD == B_NCONTIG || BKD == B_KCONTIG) {
+    if constexpr (BKD == B_NCONTIG || BKD == B_KCONTIG || BKD == B_TAPN || BKD == B_TAPK) {
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
-        rb[i] = *reinterpret_cast<const float4*>(Bp + lb_off[i]);
-        if constexpr (BKD == B_NCONTIG) {
+        if constexpr (BKD == B_TAPN || BKD == B_TAPK)
+          rb[i] = load4u(Bp + lb_off[i]);
+        else
+          rb[i] = *reinterpret_cast<const float4*>(Bp + lb_off[i]);
+        if constexpr (BKD == B_NCONTIG || BKD == B_TAPN) {
           lb_off[i] += (long)BK * p.b_ld;
         } else {
           lb_off[i] += BK;
@@ -364,6 +413,16 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
               lb_off[i] += p.b_img - p.b_hw;
             }
           }
+        }
+      }
+      if constexpr (BKD == B_TAPN) {  // next tap after Chi channels: rewind the channel walk, shift by one tap
+        lt_c += BK;
+        if (lt_c >= p.Chi) {
+          lt_c = 0;
+          const long d = (long)(((lt_tap & 3) == 3) ? p.Wlo - 3 : 1) - (long)p.Chi * p.b_ld;
+          ++lt_tap;
+#pragma unroll
+          for (int i = 0; i < B_IT; ++i) lb_off[i] += d;
         }
       }
       b_okbits = 0xFFFFFFFFu;
@@ -528,6 +587,59 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
           rb[i] = make_float4(e[0], e[1], e[2], e[3]);
         }
       }
+    } else if constexpr (BKD == B_TAPN) {
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        const int k = k0 + (t >> 5) + i * 8;
+        const bool ok = bn_ok && k < k_end;
+        const int kk = ok ? k : 0;
+        const int tap = kk / p.Chi, c = kk - tap * p.Chi;
+        const long row = (long)c * p.b_ld + tap_off(tap);
+        if constexpr (VEC) {
+          rb[i] = ld4raw_u(Bp, bn_base + row, ok);
+          b_okbits = (b_okbits & ~(1u << i)) | ((unsigned)ok << i);
+        } else {
+          b_okbits |= 1u << i;
+          const int n = n0 + (t & 31) * 4;
+          float e[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool okj = ok && (n + j) < p.N;
+            const int nn = okj ? n + j : 0;
+            const int img = nn / p.b_hw;
+            e[j] = ld1(Bp, (long)img * p.b_img + row + (nn - img * p.b_hw), okj);
+          }
+          rb[i] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      }
+    } else if constexpr (BKD == B_TAPK) {
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        const int idx = t + i * NT;
+        const int n = n0 + (idx >> 2);
+        const int k = k0 + (idx & 3) * 4;
+        const bool ok = n < p.N && k < k_end;
+        const int nn = n < p.N ? n : 0;
+        const int tap = nn / p.Chi, c = nn - tap * p.Chi;
+        const long row = (long)c * p.b_ld + tap_off(tap);
+        if constexpr (VEC) {
+          const int kk = ok ? k : 0;
+          const int img = kk / p.b_hw;
+          rb[i] = ld4raw_u(Bp, (long)img * p.b_img + row + (kk - img * p.b_hw), ok);
+          b_okbits = (b_okbits & ~(1u << i)) | ((unsigned)ok << i);
+        } else {
+          b_okbits |= 1u << i;
+          float e[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool okj = ok && (k + j) < k_end;
+            const int kk = okj ? k + j : 0;
+            const int img = kk / p.b_hw;
+            e[j] = ld1(Bp, (long)img * p.b_img + row + (kk - img * p.b_hw), okj);
+          }
+          rb[i] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      }
     } else if constexpr (BKD == B_DOWN) {
       // k = hi*16 + ky*4 + kx ; one hi channel per stage
       const int hi = k0 >> 4;
@@ -632,14 +744,14 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
   };
 
   auto store_b = [&](int buf) {
-    if constexpr (BKD == B_NCONTIG) {
+    if constexpr (BKD == B_NCONTIG || BKD == B_TAPN) {
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         float4 v = rb[i];
         if (!lean_regs) v = sel4(v, b_okbits, i);
         *reinterpret_cast<float4*>(&Bs[buf][(t >> 5) + i * 8][(t & 31) * 4]) = v;
       }
-    } else if constexpr (BKD == B_KCONTIG) {
+    } else if constexpr (BKD == B_KCONTIG || BKD == B_TAPK) {
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         const int idx = t + i * NT;
@@ -924,6 +1036,60 @@ __global__ void pack_up_weights_kernel(const float* __restrict__ w, float* __res
   const int py = phase >> 1, px = phase & 1;
   const int ky = 1 - py + 2 * ty, kx = 1 - px + 2 * tx;
   wp[i] = w[((long)lo * Chi + hi) * 16 + ky * 4 + kx];
+}
+
+// ---- flat-shift layout helpers of the stride-1 4x4 convolution --------------------------------
+// dst plane (stride P, rows of Wp floats) = src plane (H x W) placed at (oy, ox), zero elsewhere
+__global__ void embed_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int Wp, int P,
+                             int oy, int ox, long total) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long pl = i / P;
+    const int r = (int)(i - pl * P);
+    const int yy = r / Wp - oy, xx = r % Wp - ox;
+    dst[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[(pl * H + yy) * W + xx] : 0.f;
+  }
+}
+
+// dst plane (H x W) = the first W columns of the first H rows of a src plane (stride P, rows of Wp)
+__global__ void extract_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int Wp, int P,
+                               long total) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int xx = (int)(i % W);
+    const long r = i / W;
+    const int yy = (int)(r % H);
+    const long pl = r / H;
+    dst[i] = src[pl * P + (long)yy * Wp + xx];
+  }
+}
+
+// forward:    wp[co][tap*Cin + ci]        = w[co][ci][tap]
+// transposed: wp[ci][(15 - tap)*Cout + co] = w[co][ci][tap]     (flipped taps, swapped channels)
+__global__ void pack_taps_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
+                                 int transposed) {
+  const long total = (long)Cout * Cin * 16;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int tap = (int)(i & 15);
+  const long r = i >> 4;
+  const int ci = (int)(r % Cin), co = (int)(r / Cin);
+  const long o = transposed ? ((long)ci * 16 + (15 - tap)) * Cout + co : ((long)co * 16 + tap) * Cin + ci;
+  wp[o] = w[i];
+}
+
+// dw[co][ci][tap] (+)= dwp[co][tap*Cin + ci]
+__global__ void unpack_taps_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cout, int Cin,
+                                   int beta) {
+  const long total = (long)Cout * Cin * 16;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int tap = (int)(i & 15);
+  const long r = i >> 4;
+  const int ci = (int)(r % Cin), co = (int)(r / Cin);
+  float v = dwp[((long)co * 16 + tap) * Cin + ci];
+  if (beta) v += dw[i];
+  dw[i] = v;
 }
 
 inline int env_int(const char* name, int dflt) {
@@ -1232,6 +1398,105 @@ int wfae_gconv3x3_bwd_weight(const float* dy, const float* x, float* dw, int NB,
   if (rc) return rc;
   return splitk_finish((float*)ws, dw, nullptr, (long)groups * p.M * p.N, p.N, splits, accumulate,
                        (hipStream_t)stream);
+}
+
+namespace {
+struct FlatGeom {
+  int pe, Ho, Wo, Hp, Wp, Q, P;
+};
+inline FlatGeom flat_geom(int H, int W, int pe) {
+  FlatGeom g;
+  g.pe = pe;
+  g.Ho = H + 2 * pe - 3; g.Wo = W + 2 * pe - 3;
+  g.Hp = H + 2 * pe; g.Wp = W + 2 * pe;
+  g.Q = cdiv(g.Ho * g.Wp, 16) * 16;           // per-image GEMM extent (16 | Q: K stages never straddle images)
+  g.P = cdiv(g.Q + 3 * g.Wp + 3, 4) * 4;      // plane stride: the last tap of the last position stays inside
+  return g;
+}
+inline int ew_grid(long n) {
+  long b = (n + 255) / 256;
+  return (int)(b > 65535 * 4 ? 65535 * 4 : b);
+}
+}  // namespace
+
+int wfae_conv4x4s1_fwd(const float* x, const float* w, float* y, int NB, int Cin, int Cout, int H, int W, int pad,
+                       int transposed, void* ws, size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(x && w && y, WFAE_ERR_NULL_POINTER, "conv4x4s1_fwd: null pointer");
+  WFAE_REQUIRE(NB > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && pad >= 0 && pad <= 3, WFAE_ERR_BAD_SHAPE,
+               "conv4x4s1_fwd: bad shape");
+  const int Cc = transposed ? Cout : Cin;   // channels of the operand that is read
+  const int M = transposed ? Cin : Cout;    // channels that are produced
+  WFAE_REQUIRE(Cc % 16 == 0, WFAE_ERR_UNSUPPORTED, "conv4x4s1_fwd: %d input channels (need a multiple of 16)", Cc);
+  const FlatGeom g = flat_geom(H, W, transposed ? 3 - pad : pad);
+  WFAE_REQUIRE(g.Ho > 0 && g.Wo > 0, WFAE_ERR_BAD_SHAPE, "conv4x4s1_fwd: empty output");
+  WFAE_REQUIRE((int64_t)NB * g.Q < (1ll << 31) && (int64_t)Cc * g.P < (1ll << 31), WFAE_ERR_BAD_SHAPE,
+               "conv4x4s1_fwd: too large");
+  const size_t n_xp = (size_t)NB * Cc * g.P, n_yq = (size_t)NB * M * g.Q, n_wp = (size_t)M * Cc * 16;
+  const size_t need = (n_xp + n_yq + n_wp) * sizeof(float);
+  WFAE_REQUIRE(ws && ws_bytes >= need, WFAE_ERR_WORKSPACE, "conv4x4s1_fwd: workspace %zu < %zu", ws_bytes, need);
+  float* xp = (float*)ws;
+  float* yq = xp + n_xp;
+  float* wp = yq + n_yq;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(embed_kernel, dim3(ew_grid((long)n_xp)), dim3(256), 0, st, x, xp, H, W, g.Wp, g.P, g.pe, g.pe,
+                     (long)n_xp);
+  hipLaunchKernelGGL(pack_taps_kernel, dim3(cdiv((long)n_wp, 256)), dim3(256), 0, st, w, wp, Cout, Cin, transposed);
+  int rc = check_launch("conv4x4s1 embed/pack");
+  if (rc) return rc;
+  GemmP p = {};
+  p.A = wp; p.B = xp; p.C = yq;
+  p.M = M; p.N = NB * g.Q; p.K = 16 * Cc; p.k_per_split = p.K;
+  p.a_hw = p.K; p.a_img = 0; p.a_ld = p.K;
+  p.b_hw = g.Q; p.b_img = (long)Cc * g.P; p.b_ld = g.P;
+  p.c_hw = g.Q; p.c_img = (long)M * g.Q; p.c_ld = g.Q;
+  p.a_vec = p.b_vec = p.c_vec = 1;
+  p.Chi = Cc; p.Wlo = g.Wp;
+  rc = launch_gemm<A_KCONTIG, B_TAPN, E_BATCHED>(p, 1, st, "conv4x4s1_fwd");
+  if (rc) return rc;
+  const long n_y = (long)NB * M * g.Ho * g.Wo;
+  hipLaunchKernelGGL(extract_kernel, dim3(ew_grid(n_y)), dim3(256), 0, st, yq, y, g.Ho, g.Wo, g.Wp, g.Q, n_y);
+  return check_launch("conv4x4s1 extract");
+}
+
+int wfae_conv4x4s1_bwd_weight(const float* dy, const float* x, float* dw, int NB, int Cin, int Cout, int H, int W,
+                              int pad, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(dy && x && dw, WFAE_ERR_NULL_POINTER, "conv4x4s1_bwd_weight: null pointer");
+  WFAE_REQUIRE(NB > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && pad >= 0 && pad <= 3, WFAE_ERR_BAD_SHAPE,
+               "conv4x4s1_bwd_weight: bad shape");
+  const FlatGeom g = flat_geom(H, W, pad);
+  WFAE_REQUIRE(g.Ho > 0 && g.Wo > 0, WFAE_ERR_BAD_SHAPE, "conv4x4s1_bwd_weight: empty output");
+  WFAE_REQUIRE((int64_t)NB * g.Q < (1ll << 31) && (int64_t)Cin * g.P < (1ll << 31), WFAE_ERR_BAD_SHAPE,
+               "conv4x4s1_bwd_weight: too large");
+  const size_t n_xp = (size_t)NB * Cin * g.P, n_dq = (size_t)NB * Cout * g.Q, n_w = (size_t)Cout * Cin * 16;
+  const size_t fixed = (n_xp + n_dq + n_w) * sizeof(float);
+  WFAE_REQUIRE(ws && ws_bytes >= fixed + n_w * sizeof(float), WFAE_ERR_WORKSPACE,
+               "conv4x4s1_bwd_weight: workspace %zu < %zu", ws_bytes, fixed + n_w * sizeof(float));
+  float* xp = (float*)ws;
+  float* dq = xp + n_xp;
+  float* dwp = dq + n_dq;
+  float* slabs = dwp + n_w;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(embed_kernel, dim3(ew_grid((long)n_xp)), dim3(256), 0, st, x, xp, H, W, g.Wp, g.P, pad, pad,
+                     (long)n_xp);
+  hipLaunchKernelGGL(embed_kernel, dim3(ew_grid((long)n_dq)), dim3(256), 0, st, dy, dq, g.Ho, g.Wo, g.Wp, g.Q, 0, 0,
+                     (long)n_dq);
+  int rc = check_launch("conv4x4s1 embed");
+  if (rc) return rc;
+  GemmP p = {};
+  p.A = dq; p.B = xp; p.C = slabs;
+  p.M = Cout; p.N = 16 * Cin; p.K = NB * g.Q;
+  p.a_hw = g.Q; p.a_img = (long)Cout * g.Q; p.a_ld = g.Q;
+  p.b_hw = g.Q; p.b_img = (long)Cin * g.P; p.b_ld = g.P;
+  p.a_vec = p.b_vec = p.c_vec = 1;
+  p.Chi = Cin; p.Wlo = g.Wp;
+  const int splits = pick_splits(p.M, p.N, p.K, ws_bytes - fixed, &p.k_per_split);
+  rc = launch_gemm<A_KCONTIG, B_TAPK, E_SLAB>(p, splits, st, "conv4x4s1_bwd_weight");
+  if (rc) return rc;
+  rc = splitk_finish(slabs, dwp, nullptr, (long)n_w, p.N, splits, 0, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(unpack_taps_kernel, dim3(cdiv((long)n_w, 256)), dim3(256), 0, st, dwp, dw, Cout, Cin,
+                     accumulate ? 1 : 0);
+  return check_launch("conv4x4s1 unpack");
 }
 
 }  // extern "C"

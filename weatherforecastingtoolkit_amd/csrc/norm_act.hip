@@ -9,6 +9,21 @@ using namespace wfae;
 namespace {
 
 constexpr int RT = 256;  // reduction block size
+constexpr float kLeaky = 0.2f;  // nn.LeakyReLU(0.2) of the PatchGAN discriminator (losses/model.py:125-141)
+
+// ACT: 0 identity, 1 exact GELU, 2 LeakyReLU(0.2)
+template <int ACT>
+__device__ __forceinline__ float act_f(float u) {
+  if (ACT == 1) return gelu_f(u);
+  if (ACT == 2) return u > 0.f ? u : kLeaky * u;
+  return u;
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad_f(float u) {
+  if (ACT == 1) return gelu_grad_f(u);
+  if (ACT == 2) return u > 0.f ? 1.f : kLeaky;
+  return 1.f;
+}
 
 // ------------------------------------------------------------- reductions
 // Generic per-channel reduction over x[outer][C][inner]:
@@ -145,14 +160,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n4; i += gridDim.y * blockDim.x) {
       float4 v = reinterpret_cast<const float4*>(xp)[i];
       v.x = fmaf(v.x, a, b); v.y = fmaf(v.y, a, b); v.z = fmaf(v.z, a, b); v.w = fmaf(v.w, a, b);
-      if (ACT == 1) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+      v.x = act_f<ACT>(v.x); v.y = act_f<ACT>(v.y); v.z = act_f<ACT>(v.z); v.w = act_f<ACT>(v.w);
       reinterpret_cast<float4*>(yp)[i] = v;
     }
   } else {
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < HW; i += gridDim.y * blockDim.x) {
-      float v = fmaf(xp[i], a, b);
-      if (ACT == 1) v = gelu_f(v);
-      yp[i] = v;
+      yp[i] = act_f<ACT>(fmaf(xp[i], a, b));
     }
   }
 }
@@ -175,8 +188,7 @@ __global__ __launch_bounds__(RT) void bn_act_bwd_reduce_kernel(const float* __re
   const float a = scale[c], b = shift[c], mu = mean[c], is = invstd[c];
   double s1 = 0.0, s2 = 0.0;
   auto one = [&](float xv, float dv) {
-    float du = dv;
-    if (ACT == 1) du *= gelu_grad_f(fmaf(xv, a, b));
+    const float du = dv * act_grad_f<ACT>(fmaf(xv, a, b));
     s1 += du;
     s2 += (double)du * ((xv - mu) * is);
   };
@@ -239,8 +251,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dx_kernel(const float* __restr
   const float k2 = training ? coef[2 * c + 1] * inv_count : 0.f;
   const long base = (long)plane * HW;
   auto one = [&](float xv, float dv, float rv) {
-    float du = dv;
-    if (ACT == 1) du *= gelu_grad_f(fmaf(xv, a, b));
+    const float du = dv * act_grad_f<ACT>(fmaf(xv, a, b));
     const float xh = (xv - mu) * is;
     return gi * (du - k1 - xh * k2) + rv;
   };
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dx_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------ element-wise
-enum EwOp { EW_GELU = 0, EW_GELU_BWD = 1, EW_SIGMOID = 2, EW_SIGMOID_BWD = 3, EW_ADD = 4 };
+enum EwOp { EW_GELU = 0, EW_GELU_BWD = 1, EW_SIGMOID = 2, EW_SIGMOID_BWD = 3, EW_ADD = 4, EW_LRELU = 5, EW_LRELU_BWD = 6 };
 
 template <int OP>
 __device__ __forceinline__ float ew_apply(float a, float b) {
@@ -271,6 +282,8 @@ __device__ __forceinline__ float ew_apply(float a, float b) {
   if (OP == EW_GELU_BWD) return a * gelu_grad_f(b);           // a = dy, b = x
   if (OP == EW_SIGMOID) return sigmoid_f(a);
   if (OP == EW_SIGMOID_BWD) return a * b * (1.f - b);         // a = dy, b = y
+  if (OP == EW_LRELU) return a > 0.f ? a : kLeaky * a;
+  if (OP == EW_LRELU_BWD) return b > 0.f ? a : kLeaky * a;    // a = dy, b = x
   return a + b;
 }
 
@@ -419,6 +432,86 @@ __global__ void vil_u8_to_f32_kernel(const uint8_t* __restrict__ src, float* __r
   }
 }
 
+// zero padding of every (n,c) plane by `pad` pixels (mode 0) / cropping the interior back (mode 1)
+template <int MODE>
+__global__ __launch_bounds__(256) void pad2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W,
+                                                    int pad, long total) {
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    if (MODE == 0) {  // i indexes the padded tensor
+      const int xw = (int)(i % Wp);
+      const long r = i / Wp;
+      const int yh = (int)(r % Hp);
+      const long pl = r / Hp;
+      const int sy = yh - pad, sx = xw - pad;
+      dst[i] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? src[(pl * H + sy) * W + sx] : 0.f;
+    } else {  // i indexes the cropped tensor
+      const int xw = (int)(i % W);
+      const long r = i / W;
+      const int yh = (int)(r % H);
+      const long pl = r / H;
+      dst[i] = src[(pl * Hp + yh + pad) * Wp + xw + pad];
+    }
+  }
+}
+
+// mode 0: sum x ; mode 1: sum relu(1 + sign*x)   (hinge terms, contperceptual.py:19-23)
+template <int MODE>
+__global__ __launch_bounds__(RT) void mean_part_kernel(const float* __restrict__ x, double* __restrict__ part, long n,
+                                                       float sign) {
+  __shared__ double sm[16];
+  const long stride = (long)gridDim.x * blockDim.x;
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    s += MODE == 0 ? (double)x[i] : (double)fmaxf(1.f + sign * x[i], 0.f);
+  const double r = block_sum(s, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
+// mode 0: dx = g*w ; mode 1: dx = g*w*sign*[1 + sign*x > 0]
+template <int MODE>
+__global__ __launch_bounds__(256) void mean_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, float w,
+                                                       float sign, float* __restrict__ dx, long n) {
+  const float gv = g[0] * w;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dx[i] = MODE == 0 ? gv : ((1.f + sign * x[i] > 0.f) ? gv * sign : 0.f);
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x, const float* __restrict__ sdev, float s,
+                                                    float* __restrict__ y, long n) {
+  const float f = sdev ? sdev[0] * s : s;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = x[i] * f;
+}
+
+// torch.nn.utils.clip_grad_norm_ coefficient from partial sums of squares:
+// out[0] = min(1, max_norm / (sqrt(sum) + 1e-6)), out[1] = sqrt(sum)
+__global__ void clip_coef_kernel(const double* __restrict__ parts, int n, float max_norm, float pre_scale,
+                                 float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += parts[i];
+    const float total = (float)sqrt(s) * pre_scale;
+    const float coef = max_norm / (total + 1e-6f);
+    out[0] = coef < 1.f ? coef : 1.f;
+    out[1] = total;
+  }
+}
+
+// Loss.calculate_adaptive_weight (experiments/ae_v2_2/train.py:46-52):
+// clamp(disc_weight * ||rec_grad|| / (||disc_grad|| + 1e-4), 0, 1e4)
+__global__ void adaptive_weight_kernel(const double* __restrict__ ss_rec, const double* __restrict__ ss_disc,
+                                       float disc_weight, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float nr = (float)sqrt(ss_rec[0]), nd = (float)sqrt(ss_disc[0]);
+    float w = disc_weight * (nr / (nd + 1e-4f));
+    w = fminf(fmaxf(w, 0.f), 1e4f);
+    out[0] = w;
+  }
+}
+
 inline int grid_1d(long n, int per_thread = 4) {
   long b = (n / per_thread + 255) / 256;
   if (b > 4096) b = 4096;
@@ -474,6 +567,8 @@ int wfae_bn_act_fwd(const float* x, const float* scale, const float* shift, floa
   hipStream_t st = (hipStream_t)stream;
   if (act == 1)
     hipLaunchKernelGGL((bn_act_fwd_kernel<1>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec);
+  else if (act == 2)
+    hipLaunchKernelGGL((bn_act_fwd_kernel<2>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec);
   else
     hipLaunchKernelGGL((bn_act_fwd_kernel<0>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec);
   return check_launch("bn_act_fwd");
@@ -501,6 +596,9 @@ int wfae_bn_act_bwd(const float* dy, const float* x, const float* gamma, const f
   if (act == 1)
     hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<1>), dim3(C, g.splits), dim3(RT), 0, st, dy, x, scale, shift,
                        save_mean, save_invstd, part, g, vec);
+  else if (act == 2)
+    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<2>), dim3(C, g.splits), dim3(RT), 0, st, dy, x, scale, shift,
+                       save_mean, save_invstd, part, g, vec);
   else
     hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<0>), dim3(C, g.splits), dim3(RT), 0, st, dy, x, scale, shift,
                        save_mean, save_invstd, part, g, vec);
@@ -518,6 +616,9 @@ int wfae_bn_act_bwd(const float* dy, const float* x, const float* gamma, const f
     const float inv_count = 1.0f / (float)((double)NB * HW);
     if (act == 1)
       hipLaunchKernelGGL((bn_act_bwd_dx_kernel<1>), grid, dim3(256), 0, st, dy, x, gamma, scale, shift, save_mean,
+                         save_invstd, coef, res, dx, C, HW, inv_count, training, vec);
+    else if (act == 2)
+      hipLaunchKernelGGL((bn_act_bwd_dx_kernel<2>), grid, dim3(256), 0, st, dy, x, gamma, scale, shift, save_mean,
                          save_invstd, coef, res, dx, C, HW, inv_count, training, vec);
     else
       hipLaunchKernelGGL((bn_act_bwd_dx_kernel<0>), grid, dim3(256), 0, st, dy, x, gamma, scale, shift, save_mean,
@@ -644,6 +745,80 @@ int wfae_vil_u8_to_f32(const uint8_t* src, float* dst, int NB, int H, int W, int
   hipLaunchKernelGGL(vil_u8_to_f32_kernel, dim3(grid_1d(total, 1)), dim3(256), 0, (hipStream_t)stream, src, dst, H,
                      W, T, scale, total);
   return check_launch("vil_u8_to_f32");
+}
+
+int wfae_leaky_relu_fwd(const float* x, float* y, int64_t n, wfae_stream_t s) {
+  return launch_ew<EW_LRELU>(x, nullptr, y, n, (hipStream_t)s, "leaky_relu_fwd");
+}
+int wfae_leaky_relu_bwd(const float* dy, const float* x, float* dx, int64_t n, wfae_stream_t s) {
+  WFAE_REQUIRE(x, WFAE_ERR_NULL_POINTER, "leaky_relu_bwd: null pointer");
+  return launch_ew<EW_LRELU_BWD>(dy, x, dx, n, (hipStream_t)s, "leaky_relu_bwd");
+}
+
+int wfae_pad2d(const float* x, float* y, int64_t planes, int H, int W, int pad, int crop, wfae_stream_t stream) {
+  WFAE_REQUIRE(x && y, WFAE_ERR_NULL_POINTER, "pad2d: null pointer");
+  WFAE_REQUIRE(planes > 0 && H > 0 && W > 0 && pad >= 0, WFAE_ERR_BAD_SHAPE, "pad2d: bad shape");
+  const long total = crop ? planes * H * W : planes * (H + 2 * pad) * (W + 2 * pad);
+  if (crop)
+    hipLaunchKernelGGL((pad2d_kernel<1>), dim3(grid_1d(total, 1)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, pad, total);
+  else
+    hipLaunchKernelGGL((pad2d_kernel<0>), dim3(grid_1d(total, 1)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, pad, total);
+  return check_launch("pad2d");
+}
+
+int wfae_mean_fwd(const float* x, float* out, int64_t n, int hinge, float sign, float weight, void* ws, size_t ws_bytes,
+                  wfae_stream_t stream) {
+  WFAE_REQUIRE(x && out, WFAE_ERR_NULL_POINTER, "mean_fwd: null pointer");
+  WFAE_REQUIRE(n > 0, WFAE_ERR_BAD_SHAPE, "mean_fwd: bad size");
+  int blocks = grid_1d(n, 16);
+  if (blocks > 1024) blocks = 1024;
+  WFAE_REQUIRE(ws && ws_bytes >= (size_t)blocks * sizeof(double), WFAE_ERR_WORKSPACE, "mean_fwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (hinge)
+    hipLaunchKernelGGL((mean_part_kernel<1>), dim3(blocks), dim3(RT), 0, st, x, (double*)ws, (long)n, sign);
+  else
+    hipLaunchKernelGGL((mean_part_kernel<0>), dim3(blocks), dim3(RT), 0, st, x, (double*)ws, (long)n, sign);
+  int rc = check_launch("mean_fwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, blocks,
+                     (double)weight / (double)n, out, (double*)nullptr);
+  return check_launch("mean_finalize");
+}
+
+int wfae_mean_bwd(const float* x, const float* gout, float* dx, int64_t n, int hinge, float sign, float weight,
+                  wfae_stream_t stream) {
+  WFAE_REQUIRE(x && gout && dx, WFAE_ERR_NULL_POINTER, "mean_bwd: null pointer");
+  WFAE_REQUIRE(n > 0, WFAE_ERR_BAD_SHAPE, "mean_bwd: bad size");
+  const float w = (float)((double)weight / (double)n);
+  if (hinge)
+    hipLaunchKernelGGL((mean_bwd_kernel<1>), dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, x, gout, w, sign, dx, (long)n);
+  else
+    hipLaunchKernelGGL((mean_bwd_kernel<0>), dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, x, gout, w, sign, dx, (long)n);
+  return check_launch("mean_bwd");
+}
+
+int wfae_scale(const float* x, const float* scale_dev, float scale, float* y, int64_t n, wfae_stream_t stream) {
+  WFAE_REQUIRE(x && y, WFAE_ERR_NULL_POINTER, "scale: null pointer");
+  if (n <= 0) return WFAE_OK;
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, x, scale_dev, scale, y, (long)n);
+  return check_launch("scale");
+}
+
+int wfae_adaptive_weight(const double* sumsq_rec, const double* sumsq_disc, float disc_weight, float* out,
+                         wfae_stream_t stream) {
+  WFAE_REQUIRE(sumsq_rec && sumsq_disc && out, WFAE_ERR_NULL_POINTER, "adaptive_weight: null pointer");
+  hipLaunchKernelGGL(adaptive_weight_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sumsq_rec, sumsq_disc,
+                     disc_weight, out);
+  return check_launch("adaptive_weight");
+}
+
+int wfae_clip_coef(const double* sumsq_parts, int n_parts, float max_norm, float pre_scale, float* out2,
+                   wfae_stream_t stream) {
+  WFAE_REQUIRE(sumsq_parts && out2, WFAE_ERR_NULL_POINTER, "clip_coef: null pointer");
+  WFAE_REQUIRE(n_parts > 0 && max_norm > 0.f, WFAE_ERR_BAD_SHAPE, "clip_coef: bad arguments");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sumsq_parts, n_parts, max_norm,
+                     pre_scale, out2);
+  return check_launch("clip_coef");
 }
 
 }  // extern "C"

@@ -83,12 +83,36 @@ def _wgrad(fn, *tensors):
         join_side_stream()
 
 
+_arena_grads = [True]
+
+
+class detached_grads:
+    """Context in which parameter gradients are written to fresh buffers instead of the optimiser's
+    gradient arena — for torch.autograd.grad(...) probes whose results must survive later backward
+    passes (the adaptive GAN weight, experiments/ae_v2_2/train.py:46-52)."""
+
+    def __enter__(self):
+        self.prev = _arena_grads[0]
+        _arena_grads[0] = False
+
+    def __exit__(self, *exc):
+        _arena_grads[0] = self.prev
+
+
 def grad_buffer(p):
+    """Where a backward kernel writes the gradient of parameter p: p's slot in the optimiser's gradient
+    arena when p has no gradient yet — at most ONCE per backward pass.  A parameter that is used twice in
+    one graph (the discriminator on real and fake batches, ae_v2_2/train.py:88-89) gets a fresh buffer for
+    the second use: the autograd engine sums both contributions before AccumulateGrad runs, so lending the
+    same slot twice would make it add a buffer to itself."""
     v = getattr(p, "_wfae_grad_view", None)
-    if v is not None and p.grad is None:
-        # a fresh alias: autograd adopts the tensor as p.grad without a copy only
-        # when nobody else references the same TensorImpl
-        return v.view(v.shape)
+    if v is not None and p.grad is None and _arena_grads[0]:
+        task = torch._C._current_graph_task_id()
+        if getattr(p, "_wfae_lent_task", None) != task or task < 0:
+            p._wfae_lent_task = task
+            # a fresh alias: autograd adopts the tensor as p.grad without a copy only
+            # when nobody else references the same TensorImpl
+            return v.view(v.shape)
     return torch.empty_like(p)
 
 
@@ -172,6 +196,189 @@ class UpUnitFn(Function):
         _wgrad(lambda: ops.conv4x4s2_wgrad(x, dt, dw), x, dt)  # lo = x, hi = dt
         dx = ops.conv4x4s2_down(dt, w) if ctx.needs_input_grad[0] else None
         return dx, dw, dg, db, None
+
+
+# ------------------------------------------------- PatchGAN discriminator --
+# (pipeline/models/autoencoderkl/losses/model.py:100-150).  Parameters that do not require grad (the
+# discriminator during the generator step, Lightning's toggle_optimizer in ae_v2_2/train.py:133) get no
+# weight-gradient launches at all.
+def _maybe_buffer(p, needed):
+    return grad_buffer(p) if needed else torch.empty_like(p)
+
+
+def _conv4_fwd(x, w, bias, stride):
+    if stride == 1:
+        if bias is None and ops.conv4x4s1_supported(w.shape[1]):
+            return ops.conv4x4s1_fwd(x, w, 1, False)
+        return ops.dconv_fwd(x, w, bias, 4, 1, 1, 1)
+    if bias is not None or w.shape[1] < 16:
+        return ops.dconv_fwd(x, w, bias, 4, 2, 1, 1)
+    return ops.conv4x4s2_down(x, w)
+
+
+def _conv4_wgrad(dy, x, dw, stride):
+    if stride == 1:
+        if ops.conv4x4s1_supported(x.shape[1]):
+            return ops.conv4x4s1_bwd_weight(dy, x, dw, 1)
+        return ops.dconv_bwd_weight(dy, x, dw, 4, 1, 1, 1)
+    return _down_wgrad(dy, x, dw)
+
+
+def _conv4_dgrad(dy, w, stride):
+    if stride == 1:
+        if ops.conv4x4s1_supported(w.shape[0]):
+            return ops.conv4x4s1_fwd(dy, w, 1, True)
+        return ops.dconv_bwd_data(dy, w, w.shape[1], 4, 1, 1)
+    return ops.conv4x4s2_up(dy, w)
+
+
+class DiscUnitFn(Function):
+    """Conv2d(4x4, stride s, pad 1, bias=False) -> BatchNorm2d -> LeakyReLU(0.2)  (model.py:129-141)"""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, bn, stride):
+        x = _c(x)
+        training = _use_batch_stats(bn)
+        t = _conv4_fwd(x, w, None, stride)
+        st = _bn_stats(t, bn, training)
+        a = ops.bn_act_fwd(t, st, 2)
+        ctx.save_for_backward(x, w, gamma, t, st.mean, st.invstd, st.scale, st.shift)
+        ctx.training, ctx.beta, ctx.stride = training, beta, stride
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x, w, gamma, t, *s = ctx.saved_tensors
+        st = _mk_stats(*s)
+        need_w, need_g = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dg, db = _maybe_buffer(gamma, need_g), _maybe_buffer(ctx.beta, need_g)
+        dt = ops.bn_act_bwd(_c(da), t, gamma, st, dg, db, None, 2, ctx.training)
+        dw = None
+        if need_w:
+            dw = grad_buffer(w)
+            _wgrad(lambda: _conv4_wgrad(dt, x, dw, ctx.stride), dt, x)
+        dx = _conv4_dgrad(dt, w, ctx.stride) if ctx.needs_input_grad[0] else None
+        return dx, dw, dg if need_g else None, db if need_g else None, None, None
+
+
+class Conv4LeakyFn(Function):
+    """Conv2d(4x4, stride 2, pad 1, bias) -> LeakyReLU(0.2)  (model.py:125)"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x = _c(x)
+        t = _conv4_fwd(x, w, bias, 2)
+        ctx.save_for_backward(x, w, t)
+        ctx.bias = bias
+        return ops.leaky_relu_fwd(t)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, t = ctx.saved_tensors
+        dt = ops.leaky_relu_bwd(_c(dy), t)
+        dw = dbias = None
+        if ctx.needs_input_grad[1]:
+            dw = grad_buffer(w)
+            _conv4_wgrad(dt, x, dw, 2)
+        if ctx.bias is not None and ctx.needs_input_grad[2]:
+            nb, cout, h, wd = dt.shape
+            dbias = grad_buffer(ctx.bias)
+            ops.reduce_sum(dt, nb, cout, h * wd, dbias)
+        dx = ops.conv4x4s2_up(dt, w) if ctx.needs_input_grad[0] else None
+        return dx, dw, dbias
+
+
+class Conv4Fn(Function):
+    """Conv2d(4x4, stride 1|2, pad 1, optional bias) as a standalone layer"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride):
+        x = _c(x)
+        ctx.save_for_backward(x, w)
+        ctx.bias, ctx.stride = bias, stride
+        return _conv4_fwd(x, w, bias, stride)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        dw = dbias = None
+        if ctx.needs_input_grad[1]:
+            dw = grad_buffer(w)
+            _conv4_wgrad(dy, x, dw, ctx.stride)
+        if ctx.bias is not None and ctx.needs_input_grad[2]:
+            nb, cout, h, wd = dy.shape
+            dbias = grad_buffer(ctx.bias)
+            ops.reduce_sum(dy, nb, cout, h * wd, dbias)
+        dx = _conv4_dgrad(dy, w, ctx.stride) if ctx.needs_input_grad[0] else None
+        return dx, dw, dbias, None
+
+
+class Pad2dFn(Function):
+    """zero padding of the spatial dims (the `padding=1` of the reference's final 1x1 conv, model.py:145)"""
+
+    @staticmethod
+    def forward(ctx, x, pad):
+        ctx.pad = pad
+        return ops.pad2d(_c(x), pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.crop2d(_c(dy), ctx.pad), None
+
+
+class LeakyReluFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        return ops.leaky_relu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.leaky_relu_bwd(_c(dy), x)
+
+
+class MeanFn(Function):
+    """weight * mean(x)  or  weight * mean(relu(1 + sign * x))  (hinge terms, contperceptual.py:19-23)"""
+
+    @staticmethod
+    def forward(ctx, x, hinge, sign, weight):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        ctx.cfg = (hinge, sign, weight)
+        return ops.mean_fwd(x, hinge, sign, weight)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        hinge, sign, weight = ctx.cfg
+        return ops.mean_bwd(x, _c(g), hinge, sign, weight), None, None, None
+
+
+class ScaleByFn(Function):
+    """y = x * s with s a detached device scalar (the adaptive weight, ae_v2/train.py:46-52,84)"""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.save_for_backward(s)
+        return ops.scale(_c(x), 1.0, s)
+
+    @staticmethod
+    def backward(ctx, g):
+        (s,) = ctx.saved_tensors
+        return ops.scale(_c(g), 1.0, s), None
+
+
+def hinge_d_loss(logits_real, logits_fake):
+    """0.5 * (mean(relu(1 - real)) + mean(relu(1 + fake)))  (contperceptual.py:19-23)"""
+    return AddFn.apply(MeanFn.apply(logits_real, True, -1.0, 0.5), MeanFn.apply(logits_fake, True, 1.0, 0.5))
+
+
+def neg_mean(x):
+    """generator term -mean(D(x_hat))  (ae_v2/train.py:78)"""
+    return MeanFn.apply(x, False, 1.0, -1.0)
 
 
 # grouped 3x3 conv of the Bottleneck: register-blocked kernels when channels/group is 4/8/16/32

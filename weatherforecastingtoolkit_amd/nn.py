@@ -17,8 +17,9 @@ def _pair(v):
 
 
 class Conv2d(tnn.Conv2d):
-    """nn.Conv2d restricted to the three geometries the hot path uses:
-    1x1 (ae_64x8x8_lin.py:15,19,69,79), 4x4 s2 p1 (:31), 3x3 s1 p1 any groups (:17,84)."""
+    """nn.Conv2d restricted to the geometries the hot path uses:
+    1x1 (ae_64x8x8_lin.py:15,19,69,79), 4x4 s2 p1 (:31), 3x3 s1 p1 any groups (:17,84), and the PatchGAN
+    discriminator's 4x4 s2/s1 p1 (+bias) and zero-padded 1x1 (autoencoderkl/losses/model.py:125-145)."""
 
     def forward(self, x):
         k, s, p = _pair(self.kernel_size), _pair(self.stride), _pair(self.padding)
@@ -28,6 +29,10 @@ class Conv2d(tnn.Conv2d):
             return Fn.DConvFn.apply(x, self.weight, self.bias, self.groups)
         if k == (4, 4) and s == (2, 2) and p == (1, 1) and self.groups == 1 and self.bias is None:
             return Fn.Conv4x4DownFn.apply(x, self.weight)
+        if k == (4, 4) and s in ((1, 1), (2, 2)) and p == (1, 1) and self.groups == 1:
+            return Fn.Conv4Fn.apply(x, self.weight, self.bias, s[0])
+        if k == (1, 1) and s == (1, 1) and p[0] == p[1] and self.groups == 1 and self.padding_mode == "zeros":
+            return Fn.Conv1x1Fn.apply(Fn.Pad2dFn.apply(x, p[0]), self.weight, self.bias, None)
         raise WfaeError(f"Conv2d geometry k={k} s={s} p={p} g={self.groups} bias={self.bias is not None} "
                         "has no gfx950 kernel in this build")
 
@@ -75,6 +80,18 @@ class GELU(tnn.GELU):
         if self.approximate != "none":
             raise WfaeError("only exact (erf) GELU is built")
         return Fn.GeluFn.apply(x)
+
+
+class LeakyReLU(tnn.LeakyReLU):
+    """nn.LeakyReLU(0.2[, inplace]) — the only slope the reference uses (autoencoderkl/losses/model.py:125-141)."""
+
+    def __init__(self, negative_slope=0.2, inplace=False):
+        super().__init__(negative_slope, inplace)
+        if abs(negative_slope - 0.2) > 1e-12:
+            raise WfaeError("LeakyReLU: only negative_slope=0.2 is built")
+
+    def forward(self, x):
+        return Fn.LeakyReluFn.apply(x)
 
 
 class Sigmoid(tnn.Sigmoid):

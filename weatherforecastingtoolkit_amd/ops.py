@@ -184,8 +184,10 @@ def dconv_fwd(x, w, bias, ks, stride, pad, groups):
 
 
 def dconv_bwd_data(dy, w, cin, ks, pad, groups):
+    """data gradient of a stride-1 convolution; the input plane is (Ho + ks - 1 - 2 pad)^2"""
     _chk(dy, w)
-    nb, cout, h, wd = dy.shape
+    nb, cout, ho, wo = dy.shape
+    h, wd = ho + ks - 1 - 2 * pad, wo + ks - 1 - 2 * pad
     dx = torch.empty((nb, cin, h, wd), dtype=dy.dtype, device=dy.device)
     _call("wfae_dconv_bwd_data", 2 * nb * h * wd * cout * (cin // groups) * ks * ks, 4 * (nb * h * wd * (cin + cout) + w.numel()), _p(dy), _p(w), _p(dx), nb, cin, cout, h, wd, ks, pad, groups, _stream())
     return dx
@@ -198,6 +200,37 @@ def dconv_bwd_weight(dy, x, dw, ks, stride, pad, groups, accumulate=False):
     ws = workspace()
     _call("wfae_dconv_bwd_weight", 2 * dy.numel() * (cin // groups) * ks * ks, 4 * (x.numel() + dy.numel() + dw.numel()), _p(dy), _p(x), _p(dw), nb, cin, cout, h, wd, ks, stride, pad, groups,
               int(accumulate), ws.data_ptr(), ws.numel(), _stream())
+    return dw
+
+
+def conv4x4s1_supported(c_read):
+    """MFMA path of the stride-1 4x4 convolution: the channel count of the operand that is read must be a
+    multiple of 16 (smaller layers go through the direct kernels)"""
+    return c_read % 16 == 0
+
+
+def conv4x4s1_fwd(x, w, pad=1, transposed=False):
+    """4x4 stride-1 convolution on the GEMM kernel; transposed=True: x is dy, the result is the data gradient"""
+    _chk(x, w)
+    nb, c, h, wd = x.shape
+    cout, cin = w.shape[0], w.shape[1]
+    pe = 3 - pad if transposed else pad
+    m = cin if transposed else cout
+    ho, wo = h + 2 * pe - 3, wd + 2 * pe - 3
+    y = torch.empty((nb, m, ho, wo), dtype=x.dtype, device=x.device)
+    ws = workspace()
+    _call("wfae_conv4x4s1_fwd", 32 * nb * ho * wo * cin * cout, 4 * (x.numel() + y.numel() + w.numel()), _p(x), _p(w), _p(y),
+          nb, cin, cout, h, wd, pad, int(transposed), ws.data_ptr(), ws.numel(), _stream())
+    return y
+
+
+def conv4x4s1_bwd_weight(dy, x, dw, pad=1, accumulate=False):
+    _chk(dy, x, dw)
+    nb, cin, h, wd = x.shape
+    cout = dy.shape[1]
+    ws = workspace()
+    _call("wfae_conv4x4s1_bwd_weight", 32 * dy.numel() * cin, 4 * (x.numel() + dy.numel() + dw.numel()), _p(dy), _p(x), _p(dw),
+          nb, cin, cout, h, wd, pad, int(accumulate), ws.data_ptr(), ws.numel(), _stream())
     return dw
 
 
@@ -304,6 +337,54 @@ def sigmoid_bwd(dy, y):
 
 def add(a, b):
     return _ew("wfae_add", a, b)
+
+
+def leaky_relu_fwd(x):
+    return _ew("wfae_leaky_relu_fwd", x)
+
+
+def leaky_relu_bwd(dy, x):
+    return _ew("wfae_leaky_relu_bwd", dy, x)
+
+
+def pad2d(x, pad):
+    _chk(x)
+    nb, c, h, wd = x.shape
+    y = torch.empty((nb, c, h + 2 * pad, wd + 2 * pad), dtype=x.dtype, device=x.device)
+    _call("wfae_pad2d", 0, 4 * (x.numel() + y.numel()), _p(x), _p(y), nb * c, h, wd, pad, 0, _stream())
+    return y
+
+
+def crop2d(xp, pad):
+    _chk(xp)
+    nb, c, hp, wp = xp.shape
+    y = torch.empty((nb, c, hp - 2 * pad, wp - 2 * pad), dtype=xp.dtype, device=xp.device)
+    _call("wfae_pad2d", 0, 4 * (xp.numel() + y.numel()), _p(xp), _p(y), nb * c, hp - 2 * pad, wp - 2 * pad, pad, 1, _stream())
+    return y
+
+
+def mean_fwd(x, hinge=False, sign=1.0, weight=1.0):
+    """weight * mean(x)  or  weight * mean(relu(1 + sign*x))"""
+    _chk(x)
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    ws = workspace()
+    _call("wfae_mean_fwd", 0, 4 * x.numel(), _p(x), _p(out), x.numel(), int(hinge), sign, weight, ws.data_ptr(), ws.numel(), _stream())
+    return out
+
+
+def mean_bwd(x, gout, hinge=False, sign=1.0, weight=1.0):
+    _chk(x, gout)
+    dx = torch.empty_like(x)
+    _call("wfae_mean_bwd", 0, 8 * x.numel(), _p(x), _p(gout), _p(dx), x.numel(), int(hinge), sign, weight, _stream())
+    return dx
+
+
+def scale(x, s=1.0, s_dev=None, out=None):
+    """x * s * (s_dev[0] if given); out may alias x"""
+    _chk(x, s_dev)
+    y = torch.empty_like(x) if out is None else out
+    _call("wfae_scale", 0, 8 * x.numel(), _p(x), _p(s_dev), float(s), _p(y), x.numel(), _stream())
+    return y
 
 
 def reduce_sum(x, outer, c, inner, out, accumulate=False):
@@ -448,6 +529,26 @@ def sumsq(x):
     out = torch.empty((), dtype=torch.float64, device=x.device)
     ws = workspace()
     _call("wfae_sumsq", 0, 4 * x.numel(), _p(x), x.numel(), _p(out), ws.data_ptr(), ws.numel(), _stream())
+    return out
+
+
+def sumsq_into(x, out_slot):
+    """sum of squares of x written into a 0-dim fp64 view (one slot of a parts vector)"""
+    _chk(x)
+    ws = workspace()
+    _call("wfae_sumsq", 0, 4 * x.numel(), _p(x), x.numel(), _p(out_slot), ws.data_ptr(), ws.numel(), _stream())
+
+
+def clip_coef(parts, max_norm, pre_scale=1.0):
+    """(coef, total_norm) device pair from fp64 partial sums of squares"""
+    out = torch.empty(2, dtype=torch.float32, device=parts.device)
+    _call("wfae_clip_coef", 0, 0, _p(parts), parts.numel(), float(max_norm), float(pre_scale), _p(out), _stream())
+    return out
+
+
+def adaptive_weight(ss_rec, ss_disc, disc_weight=1.0):
+    out = torch.empty((), dtype=torch.float32, device=ss_rec.device)
+    _call("wfae_adaptive_weight", 0, 0, _p(ss_rec), _p(ss_disc), float(disc_weight), _p(out), _stream())
     return out
 
 

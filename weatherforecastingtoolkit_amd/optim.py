@@ -97,6 +97,39 @@ class FusedAdamW(torch.optim.Optimizer):
     def arenas(self):
         return [a for a in self._arenas if a is not None]
 
+    def _grad_chunks(self):
+        """flat views covering every gradient this optimiser would consume"""
+        chunks = []
+        for g, arena in zip(self.param_groups, self._arenas):
+            if arena is not None:
+                runs, stray = arena.runs()
+                chunks += [arena.flat_g[a:b] for a, b in runs]
+                chunks += [arena.params[i].grad.view(-1) for i in stray if arena.params[i].grad.is_contiguous()]
+                if any(not arena.params[i].grad.is_contiguous() for i in stray):
+                    raise RuntimeError("clip_grad_norm_: non-contiguous gradient outside the arena")
+            else:
+                chunks += [p.grad.view(-1) for p in g["params"] if p.grad is not None]
+        return chunks
+
+    @torch.no_grad()
+    def clip_grad_norm_(self, max_norm):
+        """torch.nn.utils.clip_grad_norm_(params, max_norm) (what Lightning's clip_gradients calls,
+        experiments/ae_v2_2/train.py:140,155) over the flat gradient arenas, without a host sync:
+        sum-of-squares per contiguous run -> device-side coefficient -> in-place scale.  Returns the
+        total norm as a 0-dim device tensor."""
+        from .functional import join_side_stream
+        join_side_stream()
+        chunks = self._grad_chunks()
+        if not chunks:
+            return torch.zeros((), device="cuda")
+        parts = torch.empty(len(chunks), dtype=torch.float64, device=chunks[0].device)
+        for i, c in enumerate(chunks):
+            ops.sumsq_into(c, parts[i])
+        coef = ops.clip_coef(parts, max_norm, self.grad_scale)
+        for c in chunks:
+            ops.scale(c, 1.0, coef[0:1], out=c)
+        return coef[1]
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

@@ -159,7 +159,33 @@ def ae_tf_state_dict_spec(img_size: int = 128, num_layers: int = 8):
     return base[:cut] + tf + base[cut:]
 
 
+def disc_state_dict_spec(input_nc: int = 1, ndf: int = 64, n_layers: int = 3):
+    """state_dict of NLayerDiscriminator (reference pipeline/models/autoencoderkl/losses/model.py:100-150)
+    after `.apply(weights_init)` (:6-12): conv weights ~N(0, 0.02), BN gamma ~N(1, 0.02), beta 0,
+    conv biases at the torch default."""
+    e = [("main.0.weight", (ndf, input_nc, 4, 4), "gan_conv"), ("main.0.bias", (ndf,), ("bias", input_nc * 16))]
+    idx, mult = 2, 1
+    for n in range(1, n_layers + 1):
+        prev, mult = mult, min(2 ** n, 8)
+        e.append((f"main.{idx}.weight", (ndf * mult, ndf * prev, 4, 4), "gan_conv"))
+        c = ndf * mult
+        e += [(f"main.{idx + 1}.weight", (c,), "gan_bn_w"), (f"main.{idx + 1}.bias", (c,), "zeros"),
+              (f"main.{idx + 1}.running_mean", (c,), "zeros"), (f"main.{idx + 1}.running_var", (c,), "ones"),
+              (f"main.{idx + 1}.num_batches_tracked", (), "bn_n")]
+        idx += 3
+    e += [(f"main.{idx}.weight", (1, ndf * mult, 1, 1), "gan_conv"), (f"main.{idx}.bias", (1,), ("bias", ndf * mult))]
+    return e
+
+
 def synth_tensor(seed: int, key: str, shape, kind) -> np.ndarray:
+    if kind == "gan_conv":
+        return (np.float32(0.02) * normal(seed, key, shape)).astype(np.float32)
+    if kind == "gan_bn_w":
+        return (np.float32(1.0) + np.float32(0.02) * normal(seed, key, shape)).astype(np.float32)
+    if kind == "zeros":
+        return np.zeros(shape, dtype=np.float32)
+    if kind == "ones":
+        return np.ones(shape, dtype=np.float32)
     if isinstance(kind, tuple) and kind[0] == "bias":
         b = 1.0 / np.sqrt(kind[1])
         return uniform(seed, key, shape, -b, b)

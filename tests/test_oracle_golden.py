@@ -104,3 +104,52 @@ def test_ssim_psnr_restatement_self_consistent():
         assert abs(orc.psnr(p, t) - float(g[f"{i}/psnr"])) < 1e-3
         assert abs(float(orc.ssim(t, t)) - 1.0) < 1e-6
         assert abs(float(orc.ssim(p, t)) - float(orc.ssim(t, p))) < 1e-6
+
+
+# ------------------------------------------------------------------ AE + GAN (G6) ---
+def test_discriminator_oracle_bit_exact():
+    """oracle discriminator vs the fixture produced by the reference NLayerDiscriminator (model.py:100-150)"""
+    g = golden("g6_gan128_b2")
+    dnp = synth.synth_state_dict(synth.disc_state_dict_spec(1, 64, 3), seed=5)
+    for tag, x in (("a", synth.uniform_frames(2, 128, seed=77)),
+                   ("a32", synth.uniform(int(g["a32/seed"]), "disc32/x", (2, 1, 32, 32), 0, 1))):
+        sd = orc.to_torch_sd(dnp)
+        xt = torch.from_numpy(x).requires_grad_(True)
+        y = orc.disc_forward(xt, sd, True)
+        y.backward(torch.from_numpy(g[f"{tag}/gy"]))
+        assert np.array_equal(y.detach().numpy(), g[f"{tag}/y"])
+        assert np.array_equal(xt.grad.numpy(), g[f"{tag}/gx"])
+        for k, v in sd.items():
+            if f"{tag}/grad/{k}" in g.files:
+                assert np.array_equal(v.grad.numpy(), g[f"{tag}/grad/{k}"]), k
+            elif f"{tag}/grad_head/{k}" in g.files:
+                assert np.array_equal(v.grad.flatten()[:2048].numpy(), g[f"{tag}/grad_head/{k}"]), k
+        if tag == "a":
+            for k, v in sd.items():
+                if "running_" in k or "num_batches" in k:
+                    assert np.array_equal(v.numpy(), g[f"a/after/{k}"]), k
+            with torch.no_grad():
+                assert np.array_equal(orc.disc_forward(xt.detach(), sd, False).numpy(), g["a/eval_y"])
+
+
+def test_gan_step_oracle_bit_exact():
+    """two G-then-D steps of the oracle vs the fixture made with the reference AE + discriminator modules in
+    the step order of experiments/ae_v2_2/train.py:126-159"""
+    g = golden("g6_gan128_b2")
+    lr, wd, total, warm, clip = [float(v) for v in g["b/cfg"]]
+    sd = orc.to_torch_sd(synth.synth_state_dict(synth.ae_state_dict_spec(128), seed=0))
+    dsd = orc.to_torch_sd(synth.synth_state_dict(synth.disc_state_dict_spec(1, 64, 3), seed=5))
+    og = orc.make_optimizer([p for _, p in orc.trainable(sd)], lr=lr, weight_decay=wd)
+    od = orc.make_optimizer([p for _, p in orc.trainable(dsd)], lr=lr, weight_decay=wd)
+    ogs = orc.make_scheduler(og, 5e-6, 5e-7, 5e-5, int(total), warm)
+    ods = orc.make_scheduler(od, 5e-6, 5e-7, 5e-5, int(total), warm)
+    x = torch.from_numpy(synth.uniform_frames(2, 128, seed=1234))
+    idx = g["b/lattice"]
+    for s in range(2):
+        recon, log = orc.gan_train_step(x, sd, dsd, og, od, ogs, ods, True, 1.0, 1.0, clip)
+        assert np.array_equal(recon[:, 0][:, idx][:, :, idx].numpy(), g[f"b/recon_lattice{s}"])
+        for k, v in log.items():
+            assert v == float(g[f"b/{k}{s}"]), (s, k)
+        an = np.array([p.detach().double().norm().item() for _, p in orc.trainable(sd)])
+        dn = np.array([p.detach().double().norm().item() for _, p in orc.trainable(dsd)])
+        assert np.array_equal(an, g[f"b/ae_param_norms{s}"]) and np.array_equal(dn, g[f"b/d_param_norms{s}"])

@@ -44,10 +44,12 @@ def parse_header(path: str = HEADER):
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"//[^\n]*", "", src)
     out = {}
-    for m in re.finditer(r"\b(int|size_t|const char\s*\*)\s+(wfae_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"\b(int64_t|int|size_t|const char\s*\*)\s+(wfae_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         if ret == "int":
             restype = ctypes.c_int
+        elif ret == "int64_t":
+            restype = ctypes.c_int64
         elif ret == "size_t":
             restype = ctypes.c_size_t
         else:

@@ -61,6 +61,9 @@ struct GemmP {
   int c_ld;
   long res_img;
   int beta;          // 1: C += result
+  // batch over blockIdx.y (plain operand kinds): element offsets added per y (Winograd: y = transform position)
+  long a_y, b_y, c_y;
+  int big_ok;        // 256-row tiles allowed for this launch (long-K plain GEMMs)
   int a_vec, b_vec, c_vec;  // 16-byte vector accesses are legal for this operand / the result
   // 4x4 s2 geometry (gather kinds): lo side Hlo x Wlo, hi side 2Hlo x 2Wlo
   int Chi, Clo, Hlo, Wlo;
@@ -130,6 +133,10 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
   }
   const float* __restrict__ Bp = p.B;
   if constexpr (BKD == B_WGRAD3) Ap += (long)blockIdx.y * p.cpg * p.a_hw;  // dY channels of this group
+  if constexpr (BKD == B_NCONTIG || BKD == B_KCONTIG) {
+    Ap += (long)blockIdx.y * p.a_y;
+    Bp += (long)blockIdx.y * p.b_y;
+  }
 
   // ------------------------------------------------ per-thread loader state
   constexpr int A_CNT = BM * BK / 4;
@@ -877,6 +884,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
     const float* rbp = nullptr;
     long mstride;
     if constexpr (EK == E_BATCHED) {
+      cb += (long)blockIdx.y * p.c_y;
       const int nn = nok ? n : 0;
       const int img = nn / p.c_hw;
       const int pn = nn - img * p.c_hw;
@@ -935,7 +943,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
       if constexpr (EK == E_BATCHED) {
         const int img = n / p.c_hw;
         const int pn = n - img * p.c_hw;
-        cb = p.C + (long)img * p.c_img + pn;
+        cb = p.C + (long)blockIdx.y * p.c_y + (long)img * p.c_img + pn;
         if (p.res) rbp = p.res + (long)img * p.res_img + pn;
         mstride = p.c_ld;
       } else if constexpr (EK == E_SLAB) {
@@ -1110,7 +1118,7 @@ int launch_gemm_v(const GemmP& p, int zdim, hipStream_t st, const char* what, in
   if constexpr (VEC) {
     // measured (tools/kbench.py): pays for the gather GEMMs once the grid fills the 512 resident slots twice
     constexpr bool gather = BKD == B_DOWN || BKD == B_UP || BKD == B_WGRAD;
-    if (gather && use256 && p.M >= 256 && (long)cdiv(p.M, 256) * ntiles * zdim * ydim >= 1024) {
+    if ((gather || p.big_ok) && use256 && p.M >= 256 && (long)cdiv(p.M, 256) * ntiles * zdim * ydim >= 1024) {
       big = true;
       dim3 grid(cdiv(p.M, 256) * ntiles, ydim, zdim);
       hipLaunchKernelGGL((gemm_kernel<256, 2, 2, AK, BKD, EK, true, 32>), grid, block, 0, st, p);
@@ -1497,6 +1505,142 @@ int wfae_conv4x4s1_bwd_weight(const float* dy, const float* x, float* dw, int NB
   hipLaunchKernelGGL(unpack_taps_kernel, dim3(cdiv((long)n_w, 256)), dim3(256), 0, st, dwp, dw, Cout, Cin,
                      accumulate ? 1 : 0);
   return check_launch("conv4x4s1 unpack");
+}
+
+// ---- Winograd F(2x2,2x2) forms of the three 4x4 stride-2 operations (transforms in wino.hip) ----------
+namespace {
+struct WinoGeom {
+  long T;      // tiles
+  int K4;      // 4 * Chi
+  size_t nU, nV, nM;
+};
+inline bool wino_geom(int NB, int Chi, int Clo, int Hlo, int Wlo, WinoGeom* g) {
+  if (NB <= 0 || Chi <= 0 || Clo <= 0 || Hlo <= 0 || Wlo <= 0) return false;
+  if ((Hlo & 1) || (Wlo & 1)) return false;
+  g->T = (long)NB * (Hlo / 2) * (Wlo / 2);
+  // 16-byte rows for the all-vector GEMM kernels
+  if (g->T % 4 != 0 || g->T >= (1ll << 31) || Chi % 4 != 0 || Clo % 4 != 0) return false;
+  g->K4 = 4 * Chi;
+  g->nU = (size_t)9 * Clo * g->K4;
+  g->nV = (size_t)9 * g->K4 * g->T;
+  g->nM = (size_t)9 * Clo * g->T;
+  return true;
+}
+}  // namespace
+
+int wfae_wino_sizes(int NB, int Chi, int Clo, int Hlo, int Wlo, int64_t* out4) {
+  WFAE_REQUIRE(out4, WFAE_ERR_NULL_POINTER, "wino_sizes: null pointer");
+  WinoGeom g;
+  if (!wino_geom(NB, Chi, Clo, Hlo, Wlo, &g)) return WFAE_ERR_UNSUPPORTED;  // no message: a query, not a failure
+  out4[0] = g.T; out4[1] = (int64_t)g.nU; out4[2] = (int64_t)g.nV; out4[3] = (int64_t)g.nM;
+  return WFAE_OK;
+}
+
+int wfae_wino_weights(const float* w, float* U, int Chi, int Clo, wfae_stream_t stream) {
+  WFAE_REQUIRE(w && U, WFAE_ERR_NULL_POINTER, "wino_weights: null pointer");
+  WFAE_REQUIRE(Chi > 0 && Clo > 0, WFAE_ERR_BAD_SHAPE, "wino_weights: bad shape");
+  return wino_weights(w, U, Clo, Chi, (hipStream_t)stream);
+}
+
+int wfae_wino_in(const float* hi, float* V, int NB, int Chi, int Hlo, int Wlo, wfae_stream_t stream) {
+  WFAE_REQUIRE(hi && V, WFAE_ERR_NULL_POINTER, "wino_in: null pointer");
+  WFAE_REQUIRE(NB > 0 && NB <= 65535 && Chi > 0 && Chi <= 65535 && Hlo > 0 && Wlo > 0 && !(Hlo & 1) && !(Wlo & 1),
+               WFAE_ERR_BAD_SHAPE, "wino_in: bad shape");
+  return wino_in(hi, V, NB, Chi, Hlo, Wlo, (hipStream_t)stream);
+}
+
+int wfae_wino_out_t(const float* lo, float* Mt, int NB, int Clo, int Hlo, int Wlo, wfae_stream_t stream) {
+  WFAE_REQUIRE(lo && Mt, WFAE_ERR_NULL_POINTER, "wino_out_t: null pointer");
+  WFAE_REQUIRE(NB > 0 && NB <= 65535 && Clo > 0 && Clo <= 65535 && Hlo > 0 && Wlo > 0 && !(Hlo & 1) && !(Wlo & 1),
+               WFAE_ERR_BAD_SHAPE, "wino_out_t: bad shape");
+  return wino_out_t(lo, Mt, NB, Clo, Hlo, Wlo, (hipStream_t)stream);
+}
+
+int wfae_wino_out(const float* M, float* lo, int NB, int Clo, int Hlo, int Wlo, wfae_stream_t stream) {
+  WFAE_REQUIRE(M && lo, WFAE_ERR_NULL_POINTER, "wino_out: null pointer");
+  WFAE_REQUIRE(NB > 0 && NB <= 65535 && Clo > 0 && Clo <= 65535 && Hlo > 0 && Wlo > 0 && !(Hlo & 1) && !(Wlo & 1),
+               WFAE_ERR_BAD_SHAPE, "wino_out: bad shape");
+  return wino_out(M, lo, NB, Clo, Hlo, Wlo, (hipStream_t)stream);
+}
+
+int wfae_wino_in_t(const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, wfae_stream_t stream) {
+  WFAE_REQUIRE(dV && hi, WFAE_ERR_NULL_POINTER, "wino_in_t: null pointer");
+  WFAE_REQUIRE(NB > 0 && NB <= 65535 && Chi > 0 && Chi <= 65535 && Hlo > 0 && Wlo > 0 && !(Hlo & 1) && !(Wlo & 1),
+               WFAE_ERR_BAD_SHAPE, "wino_in_t: bad shape");
+  return wino_in_t(dV, hi, NB, Chi, Hlo, Wlo, (hipStream_t)stream);
+}
+
+int wfae_wino_gemm_down(const float* U, const float* V, float* M, int NB, int Chi, int Clo, int Hlo, int Wlo,
+                        wfae_stream_t stream) {
+  WFAE_REQUIRE(U && V && M, WFAE_ERR_NULL_POINTER, "wino_gemm_down: null pointer");
+  WinoGeom g;
+  WFAE_REQUIRE(wino_geom(NB, Chi, Clo, Hlo, Wlo, &g) && NB <= 65535 && Clo <= 65535, WFAE_ERR_UNSUPPORTED,
+               "wino_gemm_down: needs even Hlo, Wlo, channels %% 4 == 0 and a tile count divisible by 4");
+  hipStream_t st = (hipStream_t)stream;
+  GemmP p = {};  // M_xi (Clo x T) = U_xi (Clo x 4Chi) * V_xi (4Chi x T)
+  p.A = U; p.B = V; p.C = M;
+  p.M = Clo; p.N = (int)g.T; p.K = g.K4; p.k_per_split = p.K;
+  p.a_hw = p.K; p.a_img = 0; p.a_ld = p.K;
+  p.b_hw = p.N; p.b_img = 0; p.b_ld = p.N;
+  p.c_hw = p.N; p.c_img = 0; p.c_ld = p.N;
+  p.a_y = (long)Clo * g.K4; p.b_y = (long)g.K4 * g.T; p.c_y = (long)Clo * g.T;
+  p.a_vec = aligned16(U); p.b_vec = aligned16(V); p.c_vec = aligned16(M);
+  p.big_ok = 1;
+  return launch_gemm<A_KCONTIG, B_NCONTIG, E_BATCHED>(p, 1, st, "wino_gemm_down", 9);
+}
+
+int wfae_wino_gemm_up(const float* U, const float* Mt, float* dV, int NB, int Chi, int Clo, int Hlo, int Wlo,
+                      wfae_stream_t stream) {
+  WFAE_REQUIRE(U && Mt && dV, WFAE_ERR_NULL_POINTER, "wino_gemm_up: null pointer");
+  WinoGeom g;
+  WFAE_REQUIRE(wino_geom(NB, Chi, Clo, Hlo, Wlo, &g) && NB <= 65535 && Chi <= 65535, WFAE_ERR_UNSUPPORTED,
+               "wino_gemm_up: needs even Hlo, Wlo, channels %% 4 == 0 and a tile count divisible by 4");
+  hipStream_t st = (hipStream_t)stream;
+  GemmP p = {};  // dV_xi (4Chi x T) = U_xi^T (4Chi x Clo) * Mt_xi (Clo x T)
+  p.A = U; p.B = Mt; p.C = dV;
+  p.M = g.K4; p.N = (int)g.T; p.K = Clo; p.k_per_split = cdiv(Clo, BK) * BK;
+  p.a_ld = g.K4;  // A(m = c, k = l) = U[l * 4Chi + c]
+  p.b_hw = p.N; p.b_img = 0; p.b_ld = p.N;
+  p.c_hw = p.N; p.c_img = 0; p.c_ld = p.N;
+  p.a_y = (long)Clo * g.K4; p.b_y = (long)Clo * g.T; p.c_y = (long)g.K4 * g.T;
+  p.a_vec = aligned16(U); p.b_vec = aligned16(Mt); p.c_vec = aligned16(dV);
+  p.big_ok = 1;
+  return launch_gemm<A_MCONTIG, B_NCONTIG, E_BATCHED>(p, 1, st, "wino_gemm_up", 9);
+}
+
+int wfae_wino_gemm_wgrad(const float* Mt, const float* V, float* dw, int NB, int Chi, int Clo, int Hlo, int Wlo,
+                    int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(Mt && V && dw, WFAE_ERR_NULL_POINTER, "wino_gemm_wgrad: null pointer");
+  WinoGeom g;
+  WFAE_REQUIRE(wino_geom(NB, Chi, Clo, Hlo, Wlo, &g), WFAE_ERR_UNSUPPORTED,
+               "wino_gemm_wgrad: needs even Hlo, Wlo, channels %% 4 == 0 and a tile count divisible by 4");
+  const size_t slab = g.nU * sizeof(float);
+  WFAE_REQUIRE(ws && ws_bytes >= 2 * slab, WFAE_ERR_WORKSPACE, "wino_gemm_wgrad: workspace %zu < %zu", ws_bytes, 2 * slab);
+  hipStream_t st = (hipStream_t)stream;
+  float* dU = (float*)ws;
+  float* slabs = dU + g.nU;
+  GemmP p = {};  // dU_xi (Clo x 4Chi) = Mt_xi (Clo x T) * V_xi^T (T x 4Chi)
+  p.A = Mt; p.B = V; p.C = slabs;
+  p.M = Clo; p.N = g.K4; p.K = (int)g.T;
+  p.a_hw = p.K; p.a_img = 0; p.a_ld = p.K;
+  p.b_hw = p.K; p.b_img = 0; p.b_ld = p.K;
+  p.a_y = (long)Clo * g.T; p.b_y = (long)g.K4 * g.T;
+  p.a_vec = aligned16(Mt); p.b_vec = aligned16(V); p.c_vec = aligned16(slabs);
+  p.big_ok = 1;
+  // split K so that 9 * tiles * splits covers the chip a few times; a slab holds all nine dU_xi
+  const long tiles = (long)cdiv(Clo, Clo >= 256 ? 256 : 128) * cdiv(g.K4, BN) * 9;
+  const int stages = cdiv(p.K, BK);
+  long want = (2048 + tiles - 1) / tiles;
+  if (want < 1) want = 1;
+  if (want > stages) want = stages;
+  while (want > 1 && (size_t)want * slab > ws_bytes - slab) --want;
+  p.k_per_split = cdiv(stages, (int)want) * BK;
+  const int splits = cdiv(p.K, p.k_per_split);
+  int rc = launch_gemm<A_KCONTIG, B_KCONTIG, E_SLAB>(p, splits, st, "wino_gemm_wgrad", 9);
+  if (rc) return rc;
+  rc = splitk_finish(slabs, dU, nullptr, (long)g.nU, g.K4, splits, 0, st);
+  if (rc) return rc;
+  return wino_weights_t(dU, dw, Clo, Chi, accumulate ? 1 : 0, st);
 }
 
 }  // extern "C"

@@ -73,6 +73,13 @@ def _wgrad(fn, *tensors):
     """run fn() (a weight-gradient launch reading `tensors`) on the side stream when overlap is on"""
     if not _overlap:
         return fn()
+    if _force_main[0]:
+        # the gradient buffer handed out last will be summed with an earlier contribution by autograd on the
+        # main stream: wait for the side stream (the earlier contribution may still be in flight there) and
+        # stay on the main stream
+        _force_main[0] = False
+        join_side_stream()
+        return fn()
     side = _side_stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -99,20 +106,28 @@ class detached_grads:
         _arena_grads[0] = self.prev
 
 
+_force_main = [False]
+
+
 def grad_buffer(p):
     """Where a backward kernel writes the gradient of parameter p: p's slot in the optimiser's gradient
-    arena when p has no gradient yet — at most ONCE per backward pass.  A parameter that is used twice in
-    one graph (the discriminator on real and fake batches, ae_v2_2/train.py:88-89) gets a fresh buffer for
-    the second use: the autograd engine sums both contributions before AccumulateGrad runs, so lending the
-    same slot twice would make it add a buffer to itself."""
+    arena when this is the only contribution autograd will see for p in this pass.  When the gradient is
+    going to be ADDED to another one — p already has a .grad (gradient accumulation), or p is used more
+    than once in the graph (the discriminator on real and fake batches, ae_v2_2/train.py:88-89; the engine
+    sums both before AccumulateGrad runs) — it gets a fresh buffer, and the launch that fills it is kept
+    on the main stream behind the side stream (`_wgrad`), because autograd performs that addition on the
+    main stream."""
+    task = torch._C._current_graph_task_id()
+    again = task >= 0 and getattr(p, "_wfae_lent_task", None) == task
+    p._wfae_lent_task = task
+    if p.grad is not None or again:
+        _force_main[0] = True
+        return torch.empty_like(p)
     v = getattr(p, "_wfae_grad_view", None)
-    if v is not None and p.grad is None and _arena_grads[0]:
-        task = torch._C._current_graph_task_id()
-        if getattr(p, "_wfae_lent_task", None) != task or task < 0:
-            p._wfae_lent_task = task
-            # a fresh alias: autograd adopts the tensor as p.grad without a copy only
-            # when nobody else references the same TensorImpl
-            return v.view(v.shape)
+    if v is not None and _arena_grads[0]:
+        # a fresh alias: autograd adopts the tensor as p.grad without a copy only
+        # when nobody else references the same TensorImpl
+        return v.view(v.shape)
     return torch.empty_like(p)
 
 
@@ -146,29 +161,69 @@ def _down_wgrad(dlo, hi, dw):
     return ops.conv4x4s2_wgrad(dlo, hi, dw)
 
 
+# Winograd form of the 4x4 stride-2 GEMMs (ops.wino_*): every tensor is transformed ONCE per step.
+# The forward keeps the transformed input (V = In(hi) for a Conv2d, Mt = Out^T(lo) for a ConvTranspose2d) and the
+# transformed weights U; the backward transforms the incoming gradient once and feeds it to both the data-
+# gradient GEMM and the weight-gradient GEMM.
+def _down_plan(x, w):
+    """plan for Conv2d(Chi -> Clo, 4, s2, p1) on x (N,Chi,2Hlo,2Wlo); None: direct kernels"""
+    if w.shape[1] < 16 or (x.shape[2] & 1) or (x.shape[3] & 1):
+        return None
+    return ops.wino_plan(x.shape[0], w.shape[1], w.shape[0], x.shape[2] // 2, x.shape[3] // 2)
+
+
+def _down_forward(x, w):
+    """-> (t, pl, U, V): 4x4 s2 convolution of x; U, V are None on the direct path"""
+    pl = _down_plan(x, w)
+    if pl is None:
+        return _down_fwd(x, w), None, None, None
+    U, V = ops.wino_weights(w, pl), ops.wino_in(x, pl)
+    return ops.wino_down(U, V, pl), pl, U, V
+
+
+def _down_backward(dt, x, w, pl, U, V, need_dx, need_dw):
+    """gradients of the 4x4 s2 convolution: (dx or None, dw or None); the weight gradient goes to the side stream"""
+    dw = dx = None
+    if pl is None:
+        if need_dw:
+            dw = grad_buffer(w)
+            _wgrad(lambda: _down_wgrad(dt, x, dw), dt, x)
+        if need_dx:
+            dx = ops.conv4x4s2_up(dt, w)
+        return dx, dw
+    Mt = ops.wino_out_t(dt, pl)
+    if need_dw:
+        dw = grad_buffer(w)
+        _wgrad(lambda: ops.wino_wgrad(Mt, V, dw, pl), Mt, V)
+    if need_dx:
+        dx = ops.wino_up(U, Mt, pl)
+    return dx, dw
+
+
+def _opt(t):
+    """placeholder for an absent cached tensor in save_for_backward"""
+    return t if t is not None else torch.empty(0)
+
+
 class DownUnitFn(Function):
     @staticmethod
     def forward(ctx, x, w, gamma, beta, bn):
         x = _c(x)
         training = _use_batch_stats(bn)
-        t = _down_fwd(x, w)
+        t, pl, U, V = _down_forward(x, w)
         st = _bn_stats(t, bn, training)
         a = ops.bn_act_fwd(t, st, 1)
-        ctx.save_for_backward(x, w, gamma, t, st.mean, st.invstd, st.scale, st.shift)
-        ctx.training = training
-        ctx.beta = beta
+        ctx.save_for_backward(x, w, gamma, t, st.mean, st.invstd, st.scale, st.shift, _opt(U), _opt(V))
+        ctx.training, ctx.beta, ctx.pl = training, beta, pl
         return a
 
     @staticmethod
     def backward(ctx, da):
-        x, w, gamma, t, mean, invstd, scale, shift = ctx.saved_tensors
-        st = ops.BnStats.__new__(ops.BnStats)
-        st.mean, st.invstd, st.scale, st.shift = mean, invstd, scale, shift
+        x, w, gamma, t, mean, invstd, scale, shift, U, V = ctx.saved_tensors
+        st = _mk_stats(mean, invstd, scale, shift)
         dg, db = grad_buffer(gamma), grad_buffer(ctx.beta)
         dt = ops.bn_act_bwd(_c(da), t, gamma, st, dg, db, None, 1, ctx.training)
-        dw = grad_buffer(w)
-        _wgrad(lambda: _down_wgrad(dt, x, dw), dt, x)
-        dx = ops.conv4x4s2_up(dt, w) if ctx.needs_input_grad[0] else None
+        dx, dw = _down_backward(dt, x, w, ctx.pl, U, V, ctx.needs_input_grad[0], True)
         return dx, dw, dg, db, None
 
 
@@ -177,24 +232,34 @@ class UpUnitFn(Function):
     def forward(ctx, x, w, gamma, beta, bn):
         x = _c(x)
         training = _use_batch_stats(bn)
-        t = ops.conv4x4s2_up(x, w)
+        pl = ops.wino_plan(x.shape[0], w.shape[1], w.shape[0], x.shape[2], x.shape[3])
+        U = Mt = None
+        if pl is not None:
+            U, Mt = ops.wino_weights(w, pl), ops.wino_out_t(x, pl)
+            t = ops.wino_up(U, Mt, pl)
+        else:
+            t = ops.conv4x4s2_up(x, w)
         st = _bn_stats(t, bn, training)
         a = ops.bn_act_fwd(t, st, 1)
-        ctx.save_for_backward(x, w, gamma, t, st.mean, st.invstd, st.scale, st.shift)
-        ctx.training = training
-        ctx.beta = beta
+        ctx.save_for_backward(x, w, gamma, t, st.mean, st.invstd, st.scale, st.shift, _opt(U), _opt(Mt))
+        ctx.training, ctx.beta, ctx.pl = training, beta, pl
         return a
 
     @staticmethod
     def backward(ctx, da):
-        x, w, gamma, t, mean, invstd, scale, shift = ctx.saved_tensors
-        st = ops.BnStats.__new__(ops.BnStats)
-        st.mean, st.invstd, st.scale, st.shift = mean, invstd, scale, shift
+        x, w, gamma, t, mean, invstd, scale, shift, U, Mt = ctx.saved_tensors
+        st = _mk_stats(mean, invstd, scale, shift)
         dg, db = grad_buffer(gamma), grad_buffer(ctx.beta)
         dt = ops.bn_act_bwd(_c(da), t, gamma, st, dg, db, None, 1, ctx.training)
         dw = grad_buffer(w)
-        _wgrad(lambda: ops.conv4x4s2_wgrad(x, dt, dw), x, dt)  # lo = x, hi = dt
-        dx = ops.conv4x4s2_down(dt, w) if ctx.needs_input_grad[0] else None
+        pl = ctx.pl
+        if pl is not None:
+            V = ops.wino_in(dt, pl)                                  # the hi-side tensor of this layer is dt
+            _wgrad(lambda: ops.wino_wgrad(Mt, V, dw, pl), Mt, V)     # lo = x (Mt kept from forward), hi = dt
+            dx = ops.wino_down(U, V, pl) if ctx.needs_input_grad[0] else None
+        else:
+            _wgrad(lambda: ops.conv4x4s2_wgrad(x, dt, dw), x, dt)    # lo = x, hi = dt
+            dx = ops.conv4x4s2_down(dt, w) if ctx.needs_input_grad[0] else None
         return dx, dw, dg, db, None
 
 
@@ -239,25 +304,32 @@ class DiscUnitFn(Function):
     def forward(ctx, x, w, gamma, beta, bn, stride):
         x = _c(x)
         training = _use_batch_stats(bn)
-        t = _conv4_fwd(x, w, None, stride)
+        pl = U = V = None
+        if stride == 2:
+            t, pl, U, V = _down_forward(x, w)
+        else:
+            t = _conv4_fwd(x, w, None, stride)
         st = _bn_stats(t, bn, training)
         a = ops.bn_act_fwd(t, st, 2)
-        ctx.save_for_backward(x, w, gamma, t, st.mean, st.invstd, st.scale, st.shift)
-        ctx.training, ctx.beta, ctx.stride = training, beta, stride
+        ctx.save_for_backward(x, w, gamma, t, st.mean, st.invstd, st.scale, st.shift, _opt(U), _opt(V))
+        ctx.training, ctx.beta, ctx.stride, ctx.pl = training, beta, stride, pl
         return a
 
     @staticmethod
     def backward(ctx, da):
-        x, w, gamma, t, *s = ctx.saved_tensors
-        st = _mk_stats(*s)
+        x, w, gamma, t, mean, invstd, scale, shift, U, V = ctx.saved_tensors
+        st = _mk_stats(mean, invstd, scale, shift)
         need_w, need_g = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dg, db = _maybe_buffer(gamma, need_g), _maybe_buffer(ctx.beta, need_g)
         dt = ops.bn_act_bwd(_c(da), t, gamma, st, dg, db, None, 2, ctx.training)
-        dw = None
-        if need_w:
-            dw = grad_buffer(w)
-            _wgrad(lambda: _conv4_wgrad(dt, x, dw, ctx.stride), dt, x)
-        dx = _conv4_dgrad(dt, w, ctx.stride) if ctx.needs_input_grad[0] else None
+        if ctx.stride == 2:
+            dx, dw = _down_backward(dt, x, w, ctx.pl, U, V, ctx.needs_input_grad[0], need_w)
+        else:
+            dw = None
+            if need_w:
+                dw = grad_buffer(w)
+                _wgrad(lambda: _conv4_wgrad(dt, x, dw, 1), dt, x)
+            dx = _conv4_dgrad(dt, w, 1) if ctx.needs_input_grad[0] else None
         return dx, dw, dg if need_g else None, db if need_g else None, None, None
 
 

@@ -139,12 +139,116 @@ def linear_bwd_weight(dy, x, dw, accumulate=False):
 
 
 # ------------------------------------------------------ 4x4 stride-2 family
+# Winograd F(2x2,2x2) form of the 4x4 stride-2 operations (csrc/wino.hip, include/wfae.h): 9/16 of the
+# multiplies, paid for with streaming transforms of the operands.  WFAE_WINO = 0 never, 1 / unset: whenever
+# the geometry allows and both channel counts are >= 16 (measured, tools/kbench.py: every GEMM-class layer of
+# the model gains, 1.2x at 128ch@384^2 up to 1.6x at 1024ch@48^2).
+_WINO_MODE = os.environ.get("WFAE_WINO", "auto")
+_plans = {}
+
+
+def set_winograd(mode):
+    """'auto' | True | False — overrides WFAE_WINO (A/B tests, parity tests)"""
+    global _WINO_MODE
+    _WINO_MODE = "auto" if mode == "auto" else ("1" if mode else "0")
+
+
+class WinoPlan:
+    __slots__ = ("nb", "chi", "clo", "hlo", "wlo", "T", "nU", "nV", "nM")
+
+    @property
+    def dims(self):
+        return (self.nb, self.chi, self.clo, self.hlo, self.wlo)
+
+    @property
+    def gemm_flops(self):
+        return 18 * self.nb * self.hlo * self.wlo * self.clo * self.chi
+
+
+def wino_plan(nb, chi, clo, hlo, wlo):
+    """WinoPlan when the Winograd form should run for this layer geometry, else None"""
+    if _WINO_MODE == "0":
+        return None
+    key = (nb, chi, clo, hlo, wlo)
+    pl = _plans.get(key, False)
+    if pl is False:
+        import ctypes
+        out = (ctypes.c_int64 * 4)()
+        rc = _lib.load().wfae_wino_sizes(nb, chi, clo, hlo, wlo, ctypes.cast(out, ctypes.c_void_p))
+        pl = None
+        if rc == 0:
+            pl = WinoPlan()
+            pl.nb, pl.chi, pl.clo, pl.hlo, pl.wlo = key
+            pl.T, pl.nU, pl.nV, pl.nM = (int(v) for v in out)
+        _plans[key] = pl
+    if pl is not None and _WINO_MODE == "auto" and min(chi, clo) < 16:
+        return None
+    return pl
+
+
+def _buf(n, like):
+    return torch.empty(n, dtype=torch.float32, device=like.device)
+
+
+def wino_weights(w, pl):
+    _chk(w)
+    U = _buf(pl.nU, w)
+    _call("wfae_wino_weights", 0, 4 * (w.numel() + pl.nU), _p(w), _p(U), pl.chi, pl.clo, _stream())
+    return U
+
+
+def wino_in(hi, pl):
+    """hi-side tensor (N,Chi,2Hlo,2Wlo) -> V[9][4Chi][T]"""
+    _chk(hi)
+    V = _buf(pl.nV, hi)
+    _call("wfae_wino_in", 0, 4 * (hi.numel() + pl.nV), _p(hi), _p(V), pl.nb, pl.chi, pl.hlo, pl.wlo, _stream())
+    return V
+
+
+def wino_out_t(lo, pl):
+    """lo-side tensor (N,Clo,Hlo,Wlo) -> Mt[9][Clo][T]"""
+    _chk(lo)
+    Mt = _buf(pl.nM, lo)
+    _call("wfae_wino_out_t", 0, 4 * (lo.numel() + pl.nM), _p(lo), _p(Mt), pl.nb, pl.clo, pl.hlo, pl.wlo, _stream())
+    return Mt
+
+
+def wino_down(U, V, pl):
+    """lo = Out(U * V)"""
+    M = _buf(pl.nM, V)
+    lo = torch.empty((pl.nb, pl.clo, pl.hlo, pl.wlo), dtype=torch.float32, device=V.device)
+    _call("wfae_wino_gemm_down", pl.gemm_flops, 4 * (pl.nU + pl.nV + pl.nM), _p(U), _p(V), _p(M), *pl.dims, _stream())
+    _call("wfae_wino_out", 0, 4 * (pl.nM + lo.numel()), _p(M), _p(lo), pl.nb, pl.clo, pl.hlo, pl.wlo, _stream())
+    return lo
+
+
+def wino_up(U, Mt, pl):
+    """hi = In^T(U^T * Mt)"""
+    dV = _buf(pl.nV, Mt)
+    hi = torch.empty((pl.nb, pl.chi, 2 * pl.hlo, 2 * pl.wlo), dtype=torch.float32, device=Mt.device)
+    _call("wfae_wino_gemm_up", pl.gemm_flops, 4 * (pl.nU + pl.nV + pl.nM), _p(U), _p(Mt), _p(dV), *pl.dims, _stream())
+    _call("wfae_wino_in_t", 0, 4 * (pl.nV + hi.numel()), _p(dV), _p(hi), pl.nb, pl.chi, pl.hlo, pl.wlo, _stream())
+    return hi
+
+
+def wino_wgrad(Mt, V, dw, pl, accumulate=False):
+    """dw (Clo,Chi,4,4) (+)= G^T (Mt * V^T) G"""
+    _chk(dw)
+    ws = workspace(pl.nU * 4 * 6)
+    _call("wfae_wino_gemm_wgrad", pl.gemm_flops, 4 * (pl.nU + pl.nV + pl.nM), _p(Mt), _p(V), _p(dw), *pl.dims,
+          int(accumulate), ws.data_ptr(), ws.numel(), _stream())
+    return dw
+
+
 def conv4x4s2_down(hi, w):
     """hi (N,Chi,2H,2W), w (Clo,Chi,4,4) -> lo (N,Clo,H,W)"""
     _chk(hi, w)
     nb, chi, h2, w2 = hi.shape
     clo = w.shape[0]
     hlo, wlo = h2 // 2, w2 // 2
+    pl = wino_plan(nb, chi, clo, hlo, wlo)
+    if pl is not None:
+        return wino_down(wino_weights(w, pl), wino_in(hi, pl), pl)
     lo = torch.empty((nb, clo, hlo, wlo), dtype=hi.dtype, device=hi.device)
     _call("wfae_conv4x4s2_down", 32 * nb * hlo * wlo * clo * chi, 4 * (nb * hlo * wlo * (clo + 4 * chi) + 16 * clo * chi), _p(hi), _p(w), _p(lo), nb, chi, clo, hlo, wlo, _stream())
     return lo
@@ -155,6 +259,9 @@ def conv4x4s2_up(lo, w):
     _chk(lo, w)
     nb, clo, hlo, wlo = lo.shape
     chi = w.shape[1]
+    pl = wino_plan(nb, chi, clo, hlo, wlo)
+    if pl is not None:
+        return wino_up(wino_weights(w, pl), wino_out_t(lo, pl), pl)
     hi = torch.empty((nb, chi, 2 * hlo, 2 * wlo), dtype=lo.dtype, device=lo.device)
     ws = workspace(w.numel() * 4)
     _call("wfae_conv4x4s2_up", 32 * nb * hlo * wlo * clo * chi, 4 * (nb * hlo * wlo * (clo + 4 * chi) + 16 * clo * chi), _p(lo), _p(w), _p(hi), nb, chi, clo, hlo, wlo, ws.data_ptr(), ws.numel(), _stream())
@@ -165,6 +272,9 @@ def conv4x4s2_wgrad(lo, hi, dw, accumulate=False):
     _chk(lo, hi, dw)
     nb, clo, hlo, wlo = lo.shape
     chi = hi.shape[1]
+    pl = wino_plan(nb, chi, clo, hlo, wlo)
+    if pl is not None:
+        return wino_wgrad(wino_out_t(lo, pl), wino_in(hi, pl), dw, pl, accumulate)
     ws = workspace(dw.numel() * 4 * 2)
     _call("wfae_conv4x4s2_wgrad", 32 * nb * hlo * wlo * clo * chi, 4 * (nb * hlo * wlo * (clo + 4 * chi) + 16 * clo * chi), _p(lo), _p(hi), _p(dw), nb, chi, clo, hlo, wlo, int(accumulate),
               ws.data_ptr(), ws.numel(), _stream())

@@ -41,6 +41,12 @@ PEAK_FP32 = 157.3e12            # MI355X_MICROARCH.md: fp32 vector = fp32 matrix
 PEAK_HBM = 8.0e12
 
 KERNEL_OF = {
+    "wfae_wino_gemm_wgrad": "gemm_kernel<256,2,2,A_KCONTIG,B_KCONTIG,E_SLAB> (Winograd-domain weight-gradient GEMMs "
+                            "dU_xi = Mt_xi V_xi^T of the 4x4 s2 convs, 9 per launch, split-K, fp32 MFMA)",
+    "wfae_wino_gemm_down": "gemm_kernel<256,2,2,A_KCONTIG,B_NCONTIG,E_BATCHED> (Winograd-domain GEMMs M_xi = U_xi V_xi, "
+                           "Conv2d fwd / ConvTranspose2d dgrad, 9 per launch, fp32 MFMA)",
+    "wfae_wino_gemm_up": "gemm_kernel<256,2,2,A_MCONTIG,B_NCONTIG,E_BATCHED> (Winograd-domain GEMMs dV_xi = U_xi^T Mt_xi, "
+                         "ConvTranspose2d fwd / Conv2d dgrad, 9 per launch, fp32 MFMA)",
     "wfae_conv4x4s2_up": "gemm_kernel<B_UP> (ConvTranspose2d fwd / Conv2d dgrad, fp32 MFMA implicit GEMM)",
     "wfae_conv4x4s2_down": "gemm_kernel<B_DOWN> (Conv2d fwd / ConvTranspose2d dgrad, fp32 MFMA implicit GEMM)",
     "wfae_conv4x4s2_wgrad": "gemm_kernel<B_WGRAD> (4x4 s2 weight gradient, fp32 MFMA implicit GEMM, split-K)",
@@ -194,6 +200,17 @@ def main():
             tot_ms = sum(v[1] for v in prof.values())
             fam = sorted(prof.items(), key=lambda kv: -kv[1][1])
             name, (calls, ms, fl, by) = fam[0]
+            # the dominant KERNEL is the top row of the committed rocprofv3 --kernel-trace --stats summary of this
+            # same command (profiles/dominant_kernel.json, written by tools/make_profiles.py); some entry points
+            # launch two kernels (bn_act_bwd = reduce + dx), so the largest entry point is not always it
+            try:
+                with open(os.path.join(ROOT, "profiles", "dominant_kernel.json")) as f:
+                    dom = json.load(f)
+                if dom.get("entry_point") in prof:
+                    name = dom["entry_point"]
+                    calls, ms, fl, by = prof[name]
+            except (OSError, ValueError):
+                pass
             if fl > 0:
                 ach, peak, unit, bound = fl / (ms * 1e-3) / 1e12, PEAK_FP32 / 1e12, "TFLOP/s", "mfma"
             else:
@@ -208,6 +225,11 @@ def main():
                                "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic,
                                "launches": calls, "avg_launch_ms": ms / calls,
                                "share_of_kernel_time": ms / tot_ms}
+            if name.startswith("wfae_wino_gemm"):
+                # the kernel's own work is 2*M*N*K of the nine transform-domain GEMMs (what `achieved` counts);
+                # the convolution it implements has 16/9 as many algorithmic FLOPs (SURVEY.md 8d counts 2*MAC
+                # of the direct form) — that is the rate the whole-step fp32_fraction above is built from
+                out["roofline"]["conv_algorithmic_tflops"] = ach * 16.0 / 9.0
             out["kernel_breakdown"] = [
                 {"entry_point": k, "calls_per_step": v[0] / args.steps, "ms_per_step": v[1] / args.steps,
                  "tflops": (v[2] / (v[1] * 1e-3) / 1e12) if v[2] else None,

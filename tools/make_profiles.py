@@ -4,6 +4,7 @@
 expects gpurun_out/prof (kernel stats), gpurun_out/pmc_fetch, gpurun_out/pmc_write, gpurun_out/bench.log
 """
 import collections
+import os
 import csv
 import glob
 import json
@@ -14,7 +15,7 @@ tag = sys.argv[1]
 
 
 def one(pat):
-    g = sorted(glob.glob(pat))
+    g = sorted(glob.glob(pat), key=os.path.getmtime)   # newest run (pid-named files do not sort by name)
     assert g, pat
     return g[-1]
 
@@ -44,7 +45,9 @@ with open(f"profiles/{tag}_pmc_hbm_traffic_per_kernel.csv", "w") as fo:
         n, fs = F[k]
         ws = W.get(k, [n, 0])[1]
         fo.write(f"\"{k}\",{n},{fs / n:.1f},{ws / n:.1f},{(2 * fs + ws) / n * 1024:.0f}\n")
-fam = {"wfae_conv4x4s2_wgrad": "0, 4, 1, true", "wfae_conv4x4s2_up": "1, 3, 2, true", "wfae_conv4x4s2_down": "0, 2, 0, true"}
+fam = {"wfae_conv4x4s2_wgrad": "0, 4, 1, true", "wfae_conv4x4s2_up": "1, 3, 2, true", "wfae_conv4x4s2_down": "0, 2, 0, true",
+       "wfae_wino_gemm_wgrad": "256, 2, 2, 0, 1, 1, true", "wfae_wino_gemm_down": "256, 2, 2, 0, 0, 0, true",
+       "wfae_wino_gemm_up": "256, 2, 2, 1, 0, 0, true"}
 out = {}
 for ep, sig in fam.items():
     n = fs = ws = 0
@@ -57,4 +60,14 @@ for ep, sig in fam.items():
         out[ep] = {"hbm_bytes_per_launch": (2 * fs + ws) / n * 1024, "fetch_raw_KiB": fs / n, "write_KiB": ws / n, "launches": n,
                    "source": f"profiles/{tag}_pmc_hbm_traffic_per_kernel.csv"}
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
+# dominant kernel = top row (by total time) of the kernel-trace stats; map its template signature to the entry point
+rows = list(csv.DictReader(open(f"profiles/{tag}_bench_b32_384_kernel_stats.csv")))
+top = rows[0]
+ep = next((e for e, sig in fam.items() if "gemm_kernel<" in top["Name"] and sig in top["Name"]), None)
+if ep is None:
+    for key, e in (("bn_act_bwd", "wfae_bn_act_bwd"), ("bn_act_fwd", "wfae_bn_act_fwd")):
+        if key in top["Name"]:
+            ep = e
+json.dump({"kernel": top["Name"], "entry_point": ep, "calls": int(top["Calls"]), "avg_ns": float(top["AverageNs"]),
+           "source": f"profiles/{tag}_bench_b32_384_kernel_stats.csv"}, open("profiles/dominant_kernel.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

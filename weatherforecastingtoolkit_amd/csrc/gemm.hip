@@ -64,6 +64,7 @@ struct GemmP {
   // batch over blockIdx.y (plain operand kinds): element offsets added per y (Winograd: y = transform position)
   long a_y, b_y, c_y;
   int big_ok;        // 256-row tiles allowed for this launch (long-K plain GEMMs)
+  int swizzle;       // XCD-aware tile order (set by launch_gemm_v from WFAE_SWIZZLE, default off)
   int a_vec, b_vec, c_vec;  // 16-byte vector accesses are legal for this operand / the result
   // 4x4 s2 geometry (gather kinds): lo side Hlo x Wlo, hi side 2Hlo x 2Wlo
   int Chi, Clo, Hlo, Wlo;
@@ -116,8 +117,14 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
   const int lane = t & 63;
   const int wave = t >> 6;
   const int mtiles = (p.M + BM - 1) / BM;
-  const int m0 = (blockIdx.x % mtiles) * BM;
-  const int n0 = (blockIdx.x / mtiles) * BN;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2), so
+  // give every XCD a CONTIGUOUS run of tile indices — the blocks resident on one XCD then work on the same B
+  // columns (all M tiles of an N tile are neighbours) and on neighbouring A rows, and re-read them from that
+  // XCD's L2 instead of HBM.
+  int bid = blockIdx.x;
+  if (p.swizzle && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  const int m0 = (bid % mtiles) * BM;
+  const int n0 = (bid / mtiles) * BN;
   const int z = blockIdx.z;
 
   int k_begin = 0, k_end = p.K;
@@ -1110,8 +1117,11 @@ inline int env_int(const char* name, int dflt) {
 // and MFMA instructions from one port, so non-MFMA instructions per MFMA set the achieved rate
 // (PMC: SQ_VALU_MFMA_BUSY_CYCLES vs SQ_INSTS_VALU).  WFAE_BM256=0 disables it (A/B testing).
 template <int AK, int BKD, int EK, bool VEC>
-int launch_gemm_v(const GemmP& p, int zdim, hipStream_t st, const char* what, int ydim = 1) {
+int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what, int ydim = 1) {
   static const int use256 = env_int("WFAE_BM256", 1);
+  static const int swz = env_int("WFAE_SWIZZLE", 0);  // measured: no change (the GEMMs are not L2-miss bound), kept for A/B
+  GemmP p = p_in;
+  p.swizzle = swz;
   const int ntiles = cdiv(p.N, BN);
   dim3 block(NT);
   bool big = false;

@@ -224,6 +224,23 @@ int wfae_clip_coef(const double* sumsq_parts, int n_parts, float max_norm, float
 int wfae_adaptive_weight(const double* sumsq_rec, const double* sumsq_disc, float disc_weight, float* out,
                          wfae_stream_t stream);
 
+/* ---- Path-B latent linear forecaster (reference
+ * experiments/v1_experiments/pretrained_ae_linear_sevir/train.py:67 `nn.Linear(T_in*C, T_out*C)` per latent pixel,
+ * :73-83 training_step).  v is the latent sequence (B,T,C,H*W).
+ * latent_diff_pack: X (B*HW, Tin*C)[t*C+c] = v[b,t,c,p] - v[b,Tin-1,c,p]  (the reference's `inp - inp_t` followed
+ *   by permute(0,3,4,1,2).reshape(b,h,w,Tin*C), :77-81), Y (B*HW, Tout*C) = the same for the target frames (:78).
+ *   The linear layer itself is wfae_linear_fwd / _bwd_weight on X.
+ * latent_unpack_add: out (B,Tout,C,HW) = pred (B*HW, Tout*C) re-laid out + last input frame (`pred + inp_t`, :87).
+ * mse: loss = mean((pred - target)^2) (F.mse_loss, :82), dpred = gloss * 2 (pred - target) / n. */
+int wfae_latent_diff_pack(const float* v, float* X, float* Y, int B, int T, int Tin, int C, int HW,
+                          wfae_stream_t stream);
+int wfae_latent_unpack_add(const float* pred, const float* v, float* out, int B, int T, int Tin, int C, int HW,
+                           wfae_stream_t stream);
+int wfae_mse_fwd(const float* pred, const float* target, float* loss, int64_t n, void* ws, size_t ws_bytes,
+                 wfae_stream_t stream);
+int wfae_mse_bwd(const float* pred, const float* target, const float* gloss, float* dpred, int64_t n,
+                 wfae_stream_t stream);
+
 /* ---- sigmoid + L1 loss (ae_64x8x8_lin.py:102 + experiments/ae_v2/train.py:55)
  * recon = sigmoid(h); loss[0] = weight * mean |recon - x|  (fp64 accumulation).
  * bwd: dh = gloss[0] * weight * sign(recon-x) * recon*(1-recon) / n */

@@ -25,6 +25,9 @@ Reference lines followed (relative to /root/reference):
   NLayerDiscriminator   pipeline/models/autoencoderkl/losses/model.py:100-150
   hinge_d_loss          pipeline/models/autoencoderkl/losses/contperceptual.py:19-23
   adaptive weight, G/D  experiments/ae_v2_2/train.py:54-95 (Loss), :126-168 (training_step)
+  linear forecaster     experiments/v1_experiments/pretrained_ae_linear_sevir/train.py:67,73-83
+                        ("parity unpinned": that script cannot be imported here — wandb / lightning / diffusers —
+                        and the reference holds no fixture for it; the restatement is the same torch calls)
 """
 from __future__ import annotations
 
@@ -321,3 +324,19 @@ def _last_layer_key(sd):
     """Model.get_last_layer — experiments/ae_v2_2/train.py:123-124: autoencoder.dec[-1].weight"""
     n = max(int(k.split(".")[1]) for k in sd if k.startswith("dec."))
     return f"dec.{n}.weight"
+
+
+# ------------------------------------------------ Path-B linear forecaster ---
+def linear_forecast_loss(v, weight, bias, input_frames):
+    """Model.training_step of v1_experiments/pretrained_ae_linear_sevir/train.py:73-82 on latents v (B,T,C,h,w):
+    difference against the last input frame, per-latent-pixel nn.Linear(Tin*C, Tout*C), F.mse_loss.
+    (The reference hard-codes 13 / 12 frames in the reshapes; here they follow input_frames / T.)"""
+    b, t, c, h, w = v.shape
+    tout = t - input_frames
+    inp, tgt = v[:, :input_frames], v[:, input_frames:]
+    inp_t = inp[:, -1].unsqueeze(1)
+    inp = inp - inp_t
+    tgt = tgt - inp_t
+    x = inp.permute(0, 3, 4, 1, 2).reshape(b, h, w, input_frames * c)
+    pred = F.linear(x, weight, bias).permute(0, 3, 1, 2).reshape(b, tout, c, h, w)
+    return F.mse_loss(pred, tgt), pred + inp_t

@@ -506,6 +506,35 @@ def g8_sched():
     save("g8_sched", **out)
 
 
+# ------------------------------------------------------------------ G9 ---
+def g9_linear_forecast():
+    """Path-B linear latent forecaster (v1_experiments/pretrained_ae_linear_sevir/train.py:67,73-83).
+    UNPINNED: that script cannot be imported (wandb / pytorch_lightning / diffusers-style AutoencoderKL deps) and
+    the reference has no fixture for it; the numbers below come from the same torch calls its lines make
+    (nn.Linear, F.mse_loss, clip_grad_norm_, AdamW) through the oracle restatement."""
+    out = {}
+    for i, (b, t, tin, c, h, w) in enumerate([(2, 25, 13, 4, 6, 6), (1, 25, 13, 16, 8, 8), (3, 10, 4, 5, 7, 9)]):
+        v = T(synth.uniform(9, f"lf{i}/v", (b, t, c, h, w), -1, 1))
+        lin = nn.Linear(tin * c, (t - tin) * c)
+        with torch.no_grad():
+            lin.weight.copy_(T(synth.uniform(9, f"lf{i}/w", tuple(lin.weight.shape), -0.1, 0.1)))
+            lin.bias.copy_(T(synth.uniform(9, f"lf{i}/b", tuple(lin.bias.shape), -0.1, 0.1)))
+        loss, pred_abs = orc.linear_forecast_loss(v, lin.weight, lin.bias, tin)
+        loss.backward()
+        out[f"{i}/cfg"] = np.array([b, t, tin, c, h, w])
+        out[f"{i}/loss"] = np.float64(loss.item())
+        out[f"{i}/pred_abs"] = pred_abs.detach().numpy()
+        out[f"{i}/gw"], out[f"{i}/gb"] = lin.weight.grad.numpy().copy(), lin.bias.grad.numpy().copy()
+        gn = torch.nn.utils.clip_grad_norm_(lin.parameters(), 1.0)
+        opt = orc.make_optimizer(lin.parameters(), lr=1e-4, weight_decay=1e-2)
+        sch = orc.make_scheduler(opt, 1e-5, 1e-7, 1e-4, 20, 2.0)
+        opt.step()
+        sch.step()
+        out[f"{i}/grad_norm"] = np.float64(float(gn))
+        out[f"{i}/w_after"], out[f"{i}/b_after"] = lin.weight.detach().numpy().copy(), lin.bias.detach().numpy().copy()
+    save("g9_linear_forecast", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -530,6 +559,8 @@ def main():
         g6_gan()
     if want("g7"):
         g7_metrics()
+    if want("g9"):
+        g9_linear_forecast()
     if want("g8"):
         g8_sched()
 

@@ -153,3 +153,23 @@ def test_gan_step_oracle_bit_exact():
         an = np.array([p.detach().double().norm().item() for _, p in orc.trainable(sd)])
         dn = np.array([p.detach().double().norm().item() for _, p in orc.trainable(dsd)])
         assert np.array_equal(an, g[f"b/ae_param_norms{s}"]) and np.array_equal(dn, g[f"b/d_param_norms{s}"])
+
+
+def test_linear_forecaster_oracle_matches_fixture():
+    """G9 (unpinned fixture): the oracle restatement reproduces it bit-exactly and equals a direct loop form"""
+    g = golden("g9_linear_forecast")
+    for case in range(3):
+        b, t, tin, c, h, w = [int(x) for x in g[f"{case}/cfg"]]
+        v = torch.from_numpy(synth.uniform(9, f"lf{case}/v", (b, t, c, h, w), -1, 1))
+        wt = torch.from_numpy(synth.uniform(9, f"lf{case}/w", ((t - tin) * c, tin * c), -0.1, 0.1)).requires_grad_(True)
+        bs = torch.from_numpy(synth.uniform(9, f"lf{case}/b", ((t - tin) * c,), -0.1, 0.1)).requires_grad_(True)
+        loss, pred_abs = orc.linear_forecast_loss(v, wt, bs, tin)
+        loss.backward()
+        assert loss.item() == float(g[f"{case}/loss"])
+        assert np.array_equal(pred_abs.detach().numpy(), g[f"{case}/pred_abs"])
+        assert np.array_equal(wt.grad.numpy(), g[f"{case}/gw"])
+        # independent per-pixel loop form of the same definition (one latent pixel)
+        last = v[0, tin - 1, :, 0, 0]
+        x = (v[0, :tin, :, 0, 0] - last).reshape(-1)
+        y = (wt.detach() @ x + bs.detach()).reshape(t - tin, c) + last
+        assert torch.allclose(y, pred_abs[0, :, :, 0, 0].detach(), atol=1e-6)

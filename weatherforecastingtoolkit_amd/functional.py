@@ -822,6 +822,25 @@ class SsimFn(Function):
         return None, ops.ssim_bwd(x, y, _c(g))
 
 
+class MseLossFn(Function):
+    """F.mse_loss(pred, target) (reference v1_experiments/pretrained_ae_linear_sevir/train.py:82)"""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred, target = _c(pred), _c(target)
+        ctx.save_for_backward(pred, target)
+        return ops.mse_fwd(pred, target)
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target = ctx.saved_tensors
+        return ops.mse_bwd(pred, target, _c(g)), None
+
+
+def mse_loss(pred, target):
+    return MseLossFn.apply(pred, target)
+
+
 def l1_loss(recon, x, weight=1.0):
     return L1LossFn.apply(recon, x, weight)
 

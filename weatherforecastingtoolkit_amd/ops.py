@@ -537,6 +537,41 @@ def l1_bwd(recon, x, gloss, weight=1.0):
     return d
 
 
+# ------------------------------------------------- Path-B latent forecaster
+def latent_diff_pack(v, tin):
+    """v (B,T,C,H,W) -> X (B*H*W, tin*C), Y (B*H*W, (T-tin)*C), both differenced against frame tin-1"""
+    _chk(v)
+    b, t, c, h, w = v.shape
+    X = torch.empty((b * h * w, tin * c), dtype=torch.float32, device=v.device)
+    Y = torch.empty((b * h * w, (t - tin) * c), dtype=torch.float32, device=v.device)
+    _call("wfae_latent_diff_pack", 0, 8 * v.numel(), _p(v), _p(X), _p(Y), b, t, tin, c, h * w, _stream())
+    return X, Y
+
+
+def latent_unpack_add(pred, v, tin):
+    """pred (B*H*W, Tout*C) + last input frame of v (B,T,C,H,W) -> (B,Tout,C,H,W)"""
+    _chk(pred, v)
+    b, t, c, h, w = v.shape
+    out = torch.empty((b, t - tin, c, h, w), dtype=torch.float32, device=v.device)
+    _call("wfae_latent_unpack_add", 0, 8 * out.numel(), _p(pred), _p(v), _p(out), b, t, tin, c, h * w, _stream())
+    return out
+
+
+def mse_fwd(pred, target):
+    _chk(pred, target)
+    loss = torch.empty((), dtype=torch.float32, device=pred.device)
+    ws = workspace()
+    _call("wfae_mse_fwd", 0, 8 * pred.numel(), _p(pred), _p(target), _p(loss), pred.numel(), ws.data_ptr(), ws.numel(), _stream())
+    return loss
+
+
+def mse_bwd(pred, target, gloss):
+    _chk(pred, target, gloss)
+    d = torch.empty_like(pred)
+    _call("wfae_mse_bwd", 0, 12 * pred.numel(), _p(pred), _p(target), _p(gloss), _p(d), pred.numel(), _stream())
+    return d
+
+
 def ssim_fwd(x, y, clamp01=False):
     _chk(x, y)
     nb = x.shape[0] * x.shape[1]

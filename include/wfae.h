@@ -283,6 +283,13 @@ int wfae_layernorm_fwd(const float* x, const float* res, const float* gamma, con
 int wfae_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma, const float* mean,
                        const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int E, int accumulate,
                        void* ws, size_t ws_bytes, wfae_stream_t stream);
+/* mha: the same with a layout switch — batch_first = 0: row = s*N + n (above); batch_first = 1: row = n*S + s, i.e. qkv
+ * is (N batch elements, S tokens, 3E) as nn.TransformerEncoderLayer(batch_first=True) of AE_ViT_2048 has it
+ * (pipeline/models/ae_vit.py:104-109).  S <= 64, D in {8, 16, 64}. */
+int wfae_mha_fwd(const float* qkv, float* out, float* probs, int S, int N, int H, int D, int batch_first, float p_drop,
+                 uint64_t seed, wfae_stream_t stream);
+int wfae_mha_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, int S, int N, int H, int D,
+                 int batch_first, float p_drop, uint64_t seed, wfae_stream_t stream);
 int wfae_mha_seqfirst_fwd(const float* qkv, float* out, float* probs, int S, int N, int H, int D, float p_drop,
                           uint64_t seed, wfae_stream_t stream);
 int wfae_mha_seqfirst_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, int S, int N, int H,
@@ -290,6 +297,24 @@ int wfae_mha_seqfirst_bwd(const float* qkv, const float* probs, const float* dou
 int wfae_relu_fwd(const float* x, float* y, int64_t n, wfae_stream_t stream);
 int wfae_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, wfae_stream_t stream);
 int wfae_dropout(const float* x, float* y, int64_t n, float p_drop, uint64_t seed, wfae_stream_t stream);
+
+/* ---- Path-B token autoencoder AE_ViT_2048 (pipeline/models/ae_vit.py:84-162), pieces beyond the kernels above.
+ * patchify / unpatchify: image (B,C,Hp*P,Wp*P) <-> rows (B*Hp*Wp, C*P*P) — the permutation that turns
+ *   Conv2d(C, E, P, P) (:99) and ConvTranspose2d(E, C, P, P) (:128) into linear GEMMs; unpatchify adds bias[c].
+ * add_bcast: out[o][i] = x[o][i] + p[i] (positional tokens, :142,158).
+ * sq_attn: single-query attention of GlobalCrossEncode (:22-42): q (B, H*D) already projected, kv rows (b, l)
+ *   with columns [k | v] (H*D each, as `.view(B, L, 2, nh, dh)` lays them out), softmax(q.k / sqrt(D)) over
+ *   the L <= 64 tokens, out (B, H*D), probs (B, H, L) saved for backward. */
+int wfae_patchify(const float* img, float* rows, int B, int C, int Hp, int Wp, int P, wfae_stream_t stream);
+int wfae_unpatchify(const float* rows, const float* bias, float* img, int B, int C, int Hp, int Wp, int P,
+                    wfae_stream_t stream);
+int wfae_add_bcast(const float* x, const float* p, float* out, int64_t outer, int64_t inner, wfae_stream_t stream);
+/* sum_mid: out[a][b] = sum_m x[a][m][b] (gradient of a row broadcast over the token axis) */
+int wfae_sum_mid(const float* x, float* out, int64_t A, int M, int64_t Bn, wfae_stream_t stream);
+int wfae_sq_attn_fwd(const float* q, const float* kv, float* out, float* probs, int B, int L, int H, int D,
+                     wfae_stream_t stream);
+int wfae_sq_attn_bwd(const float* q, const float* kv, const float* probs, const float* dout, float* dq, float* dkv, int B,
+                     int L, int H, int D, wfae_stream_t stream);
 
 /* ---- AdamW (torch.optim.AdamW via pipeline/helpers.py:63-74) ---------------
  * p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;

@@ -535,6 +535,50 @@ def g9_linear_forecast():
     save("g9_linear_forecast", **out)
 
 
+# ----------------------------------------------------------------- G10 ---
+def g10_vit():
+    """Path-B token autoencoder AE_ViT_2048 (pipeline/models/ae_vit.py:84-162), from the real reference module:
+    eval-mode forward and one train-mode forward/backward with every dropout probability set to 0."""
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):       # the reference module runs a smoke test on import
+        import pipeline.models.ae_vit as refvit
+    net = refvit.AE_ViT_2048()
+    shapes = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    np_sd = synth.generic_state_dict(shapes, seed=3)
+    net.load_state_dict({k: T(v) for k, v in np_sd.items()}, strict=True)
+    x = T(synth.uniform_frames(3, 128, seed=1234))
+    out = {"keys": np.array([k for k, _ in shapes])}
+    idx = np.linspace(0, 127, LATTICE).round().astype(np.int64)
+    out["lattice"] = idx
+    net.eval()
+    with torch.no_grad():
+        er, ez = net(x)
+    out["eval_out_lattice"], out["eval_latent"] = er[:, 0][:, idx][:, :, idx].numpy(), ez.numpy()
+    net.train()
+    for m in net.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, nn.MultiheadAttention):
+            m.dropout = 0.0
+    rec, z = net(x)
+    loss = F.mse_loss(rec, x)
+    loss.backward()
+    out["out_lattice"], out["latent"], out["loss"] = rec.detach()[:, 0][:, idx][:, :, idx].numpy(), z.detach().numpy(), np.float64(loss.item())
+    names, norms = [], []
+    for n, p in net.named_parameters():
+        names.append(n)
+        norms.append(-1.0 if p.grad is None else p.grad.double().norm().item())
+    out["grad_names"], out["grad_norms"] = np.array(names), np.array(norms)
+    for n in ["patch_embed.weight", "pos_embed", "query_vec", "unpatch.bias", "to_latent.q_proj.bias", "from_latent.out.bias",
+              "encoder.layers.0.norm1.weight", "decoder.layers.5.norm2.bias", "from_latent.kv_proj.bias"]:
+        out[f"grad/{n}"] = dict(net.named_parameters())[n].grad.numpy().copy()
+    out["grad_head/encoder.layers.2.self_attn.in_proj_weight"] = net.encoder.layers[2].self_attn.in_proj_weight.grad.flatten()[:4096].numpy().copy()
+    out["grad_head/decoder.layers.0.linear1.weight"] = net.decoder.layers[0].linear1.weight.grad.flatten()[:4096].numpy().copy()
+    out["grad_head/to_latent.kv_proj.weight"] = net.to_latent.kv_proj.weight.grad.flatten()[:4096].numpy().copy()
+    save("g10_vit128_b3", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -561,6 +605,8 @@ def main():
         g7_metrics()
     if want("g9"):
         g9_linear_forecast()
+    if want("g10"):
+        g10_vit()
     if want("g8"):
         g8_sched()
 

@@ -96,24 +96,25 @@ __global__ void ln_param_reduce_kernel(const float* __restrict__ part, int block
 }
 
 // ---------------------------------------------------------------- attention
-// qkv rows are (s, n) pairs: row = s*N + n, columns [q | k | v] each E = H*D wide.
-// One wavefront per (n, h); lane i < S owns query row i.  S <= 64, D <= 16.
+// qkv rows are (s, n) pairs: row = s*rs + n*rn (seq-first: rs = N, rn = 1; batch-first: rs = 1, rn = S),
+// columns [q | k | v] each E = H*D wide.  One wavefront per (n, h); lane i < S owns query row i.  S <= 64,
+// D in {8, 16, 64}.
 template <int D>
 __global__ __launch_bounds__(64) void mha_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                      float* __restrict__ probs, int S, int N, int H, float scale,
-                                                     float p_drop, unsigned long long seed) {
+                                                     float p_drop, unsigned long long seed, long rs, long rn) {
   __shared__ float ks[64][D + 1], vs[64][D + 1];
   const int n = blockIdx.x / H, h = blockIdx.x % H;
   const int E = H * D, i = threadIdx.x;
   if (i < S) {
-    const float* row = qkv + ((long)i * N + n) * 3 * E + h * D;
+    const float* row = qkv + ((long)i * rs + (long)n * rn) * 3 * E + h * D;
 #pragma unroll
     for (int d = 0; d < D; ++d) { ks[i][d] = row[E + d]; vs[i][d] = row[2 * E + d]; }
   }
   __syncthreads();
   if (i >= S) return;
   float q[D];
-  const float* row = qkv + ((long)i * N + n) * 3 * E + h * D;
+  const float* row = qkv + ((long)i * rs + (long)n * rn) * 3 * E + h * D;
 #pragma unroll
   for (int d = 0; d < D; ++d) q[d] = row[d] * scale;
   float* pr = probs + (((long)n * H + h) * S + i) * S;
@@ -140,20 +141,26 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const float* __restrict__ q
     for (int d = 0; d < D; ++d) o[d] = fmaf(pj, vs[j][d], o[d]);
   }
 #pragma unroll
-  for (int d = 0; d < D; ++d) out[((long)i * N + n) * E + h * D + d] = o[d];
+  for (int d = 0; d < D; ++d) out[((long)i * rs + (long)n * rn) * E + h * D + d] = o[d];
 }
 
 template <int D>
 __global__ __launch_bounds__(64) void mha_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ probs,
                                                      const float* __restrict__ dout, float* __restrict__ dqkv, int S,
-                                                     int N, int H, float scale, float p_drop, unsigned long long seed) {
-  __shared__ float qs[64][D + 1], ks[64][D + 1], vs[64][D + 1], dos[64][D + 1];
-  __shared__ float dss[64][65], pds[64][65];  // dS and dropped probabilities
+                                                     int N, int H, float scale, float p_drop, unsigned long long seed,
+                                                     long rs, long rn) {
+  extern __shared__ float mha_lds[];
+  float(*qs)[D + 1] = reinterpret_cast<float(*)[D + 1]>(mha_lds);
+  float(*ks)[D + 1] = qs + 64;
+  float(*vs)[D + 1] = ks + 64;
+  float(*dos)[D + 1] = vs + 64;
+  float(*dss)[65] = reinterpret_cast<float(*)[65]>(mha_lds + 4 * 64 * (D + 1));  // dS
+  float(*pds)[65] = dss + 64;                                                      // dropped probabilities
   const int n = blockIdx.x / H, h = blockIdx.x % H;
   const int E = H * D, i = threadIdx.x;
   if (i < S) {
-    const float* row = qkv + ((long)i * N + n) * 3 * E + h * D;
-    const float* dr = dout + ((long)i * N + n) * E + h * D;
+    const float* row = qkv + ((long)i * rs + (long)n * rn) * 3 * E + h * D;
+    const float* dr = dout + ((long)i * rs + (long)n * rn) * E + h * D;
 #pragma unroll
     for (int d = 0; d < D; ++d) { qs[i][d] = row[d]; ks[i][d] = row[E + d]; vs[i][d] = row[2 * E + d]; dos[i][d] = dr[d]; }
   }
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const float* __restrict__ q
 #pragma unroll
       for (int d = 0; d < D; ++d) dq[d] = fmaf(ds, ks[j][d], dq[d]);
     }
-    float* o = dqkv + ((long)i * N + n) * 3 * E + h * D;
+    float* o = dqkv + ((long)i * rs + (long)n * rn) * 3 * E + h * D;
 #pragma unroll
     for (int d = 0; d < D; ++d) o[d] = dq[d] * scale;
   }
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const float* __restrict__ q
 #pragma unroll
       for (int d = 0; d < D; ++d) { dk[d] = fmaf(ds, qs[r][d], dk[d]); dv[d] = fmaf(pd, dos[r][d], dv[d]); }
     }
-    float* o = dqkv + ((long)j * N + n) * 3 * E + h * D;
+    float* o = dqkv + ((long)j * rs + (long)n * rn) * 3 * E + h * D;
 #pragma unroll
     for (int d = 0; d < D; ++d) { o[E + d] = dk[d] * scale; o[2 * E + d] = dv[d]; }
   }
@@ -230,6 +237,18 @@ inline int ew_grid(long n) {
   return (int)b;
 }
 
+}  // namespace
+
+namespace {
+template <int D>
+int launch_mha_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, int S, int N, int H, float p_drop,
+                   unsigned long long seed, long rs, long rn, hipStream_t st) {
+  const size_t lds = (size_t)(4 * 64 * (D + 1) + 2 * 64 * 65) * sizeof(float);
+  (void)hipFuncSetAttribute((const void*)mha_bwd_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((mha_bwd_kernel<D>), dim3(N * H), dim3(64), lds, st, qkv, probs, dout, dqkv, S, N, H,
+                     1.0f / sqrtf((float)D), p_drop, seed, rs, rn);
+  return check_launch("mha_bwd");
+}
 }  // namespace
 
 extern "C" {
@@ -265,35 +284,48 @@ int wfae_layernorm_bwd(const float* dy, const float* x, const float* res, const 
   return check_launch("layernorm_bwd_reduce");
 }
 
-int wfae_mha_seqfirst_fwd(const float* qkv, float* out, float* probs, int S, int N, int H, int D, float p_drop,
-                          uint64_t seed, wfae_stream_t stream) {
+
+int wfae_mha_fwd(const float* qkv, float* out, float* probs, int S, int N, int H, int D, int batch_first, float p_drop,
+                 uint64_t seed, wfae_stream_t stream) {
   WFAE_REQUIRE(qkv && out && probs, WFAE_ERR_NULL_POINTER, "mha_fwd: null pointer");
   WFAE_REQUIRE(S > 0 && S <= 64 && N > 0 && H > 0, WFAE_ERR_BAD_SHAPE, "mha_fwd: sequence length must be 1..64");
   WFAE_REQUIRE(p_drop >= 0.f && p_drop < 1.f, WFAE_ERR_BAD_SHAPE, "mha_fwd: dropout probability");
-  const float scale = 1.0f / sqrtf((float)D);
   hipStream_t st = (hipStream_t)stream;
+  const float scale = 1.0f / sqrtf((float)D);
+  const long rs = batch_first ? 1 : N, rn = batch_first ? S : 1;
+  const unsigned long long sd = (unsigned long long)seed;
   if (D == 8)
-    hipLaunchKernelGGL((mha_fwd_kernel<8>), dim3(N * H), dim3(64), 0, st, qkv, out, probs, S, N, H, scale, p_drop, seed);
+    hipLaunchKernelGGL((mha_fwd_kernel<8>), dim3(N * H), dim3(64), 0, st, qkv, out, probs, S, N, H, scale, p_drop, sd, rs, rn);
   else if (D == 16)
-    hipLaunchKernelGGL((mha_fwd_kernel<16>), dim3(N * H), dim3(64), 0, st, qkv, out, probs, S, N, H, scale, p_drop, seed);
+    hipLaunchKernelGGL((mha_fwd_kernel<16>), dim3(N * H), dim3(64), 0, st, qkv, out, probs, S, N, H, scale, p_drop, sd, rs, rn);
+  else if (D == 64)
+    hipLaunchKernelGGL((mha_fwd_kernel<64>), dim3(N * H), dim3(64), 0, st, qkv, out, probs, S, N, H, scale, p_drop, sd, rs, rn);
   else
-    return fail(WFAE_ERR_UNSUPPORTED, "mha_fwd: head dim %d (8 and 16 built)", D);
+    return fail(WFAE_ERR_UNSUPPORTED, "mha_fwd: head dim %d (8, 16 and 64 built)", D);
   return check_launch("mha_fwd");
+}
+
+int wfae_mha_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, int S, int N, int H, int D,
+                 int batch_first, float p_drop, uint64_t seed, wfae_stream_t stream) {
+  WFAE_REQUIRE(qkv && probs && dout && dqkv, WFAE_ERR_NULL_POINTER, "mha_bwd: null pointer");
+  WFAE_REQUIRE(S > 0 && S <= 64 && N > 0 && H > 0, WFAE_ERR_BAD_SHAPE, "mha_bwd: sequence length must be 1..64");
+  hipStream_t st = (hipStream_t)stream;
+  const long rs = batch_first ? 1 : N, rn = batch_first ? S : 1;
+  const unsigned long long sd = (unsigned long long)seed;
+  if (D == 8) return launch_mha_bwd<8>(qkv, probs, dout, dqkv, S, N, H, p_drop, sd, rs, rn, st);
+  if (D == 16) return launch_mha_bwd<16>(qkv, probs, dout, dqkv, S, N, H, p_drop, sd, rs, rn, st);
+  if (D == 64) return launch_mha_bwd<64>(qkv, probs, dout, dqkv, S, N, H, p_drop, sd, rs, rn, st);
+  return fail(WFAE_ERR_UNSUPPORTED, "mha_bwd: head dim %d (8, 16 and 64 built)", D);
+}
+
+int wfae_mha_seqfirst_fwd(const float* qkv, float* out, float* probs, int S, int N, int H, int D, float p_drop,
+                          uint64_t seed, wfae_stream_t stream) {
+  return wfae_mha_fwd(qkv, out, probs, S, N, H, D, 0, p_drop, seed, stream);
 }
 
 int wfae_mha_seqfirst_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, int S, int N, int H,
                           int D, float p_drop, uint64_t seed, wfae_stream_t stream) {
-  WFAE_REQUIRE(qkv && probs && dout && dqkv, WFAE_ERR_NULL_POINTER, "mha_bwd: null pointer");
-  WFAE_REQUIRE(S > 0 && S <= 64 && N > 0 && H > 0, WFAE_ERR_BAD_SHAPE, "mha_bwd: sequence length must be 1..64");
-  const float scale = 1.0f / sqrtf((float)D);
-  hipStream_t st = (hipStream_t)stream;
-  if (D == 8)
-    hipLaunchKernelGGL((mha_bwd_kernel<8>), dim3(N * H), dim3(64), 0, st, qkv, probs, dout, dqkv, S, N, H, scale, p_drop, seed);
-  else if (D == 16)
-    hipLaunchKernelGGL((mha_bwd_kernel<16>), dim3(N * H), dim3(64), 0, st, qkv, probs, dout, dqkv, S, N, H, scale, p_drop, seed);
-  else
-    return fail(WFAE_ERR_UNSUPPORTED, "mha_bwd: head dim %d (8 and 16 built)", D);
-  return check_launch("mha_bwd");
+  return wfae_mha_bwd(qkv, probs, dout, dqkv, S, N, H, D, 0, p_drop, seed, stream);
 }
 
 int wfae_relu_fwd(const float* x, float* y, int64_t n, wfae_stream_t stream) {

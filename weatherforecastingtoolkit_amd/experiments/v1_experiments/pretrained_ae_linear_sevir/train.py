@@ -33,18 +33,34 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 class Autoencoder(tnn.Module):
-    """frozen latent provider with the reference wrapper's interface (:21-56): encode (B,T,1,H,W) -> (B,T,C,h,w)"""
+    """frozen latent provider with the reference wrapper's interface (:21-56): encode (B,T,1,H,W) -> (B,T,C,h,w).
+    kind "ae_64x8x8_lin.enc": the conv encoder stack (64 channels at 1/16 resolution);
+    kind "ae_vit.tokens": the structured token latent [64, 512] of AE_ViT_2048 (BASELINE config 4), i.e. the
+    encoder tokens laid out as 512 channels on the 8x8 patch grid."""
 
-    def __init__(self, img_size=128):
+    def __init__(self, img_size=128, kind="ae_64x8x8_lin.enc"):
         super().__init__()
-        self.autoencoder = PosAwareAE_TF(img_size=img_size).eval()
+        self.kind = kind
+        if kind == "ae_vit.tokens":
+            from ....pipeline.models.ae_vit import AE_ViT_2048
+            self.autoencoder = AE_ViT_2048().eval()
+        elif kind == "ae_64x8x8_lin.enc":
+            self.autoencoder = PosAwareAE_TF(img_size=img_size).eval()
+        else:
+            raise ValueError(f"autoencoder.kind={kind!r}")
         for p in self.autoencoder.parameters():
             p.requires_grad_(False)
 
     @torch.no_grad()
     def encode(self, x):
         b, t, c, h, w = x.shape
-        z = self.autoencoder.enc(x.reshape(b * t, c, h, w))
+        frames = x.reshape(b * t, c, h, w)
+        if self.kind == "ae_vit.tokens":
+            tok = self.autoencoder.encode_tokens(frames)                      # (B*T, 64, 512)
+            s = self.autoencoder.seq
+            z = tok.transpose(1, 2).contiguous().view(b * t, tok.shape[2], s, s)
+        else:
+            z = self.autoencoder.enc(frames)
         return z.view(b, t, *z.shape[1:])
 
 
@@ -121,7 +137,7 @@ def main(argv=None):
         total = args.max_steps
     cfg.trainer.total_train_steps = total
     torch.manual_seed(0)
-    model = Model(cfg, autoencoder=Autoencoder(size)).to(dev).train()
+    model = Model(cfg, autoencoder=Autoencoder(size, cfg.autoencoder.kind)).to(dev).train()
     model.autoencoder.eval()
     model.configure_optimizers()
     step, t0 = 0, time.time()

@@ -735,18 +735,159 @@ class AddLayerNormFn(Function):
 
 class MhaSeqFirstFn(Function):
     @staticmethod
-    def forward(ctx, qkv, s, n, h, p_drop, seed):
+    def forward(ctx, qkv, s, n, h, p_drop, seed, batch_first=False):
         qkv = _c(qkv)
         d = qkv.shape[1] // (3 * h)
-        out, probs = ops.mha_fwd(qkv, s, n, h, d, p_drop, seed)
+        out, probs = ops.mha_fwd(qkv, s, n, h, d, p_drop, seed, batch_first)
         ctx.save_for_backward(qkv, probs)
-        ctx.cfg = (s, n, h, d, p_drop, seed)
+        ctx.cfg = (s, n, h, d, p_drop, seed, batch_first)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, probs = ctx.saved_tensors
-        return ops.mha_bwd(qkv, probs, _c(dout), *ctx.cfg), None, None, None, None, None
+        return ops.mha_bwd(qkv, probs, _c(dout), *ctx.cfg), None, None, None, None, None, None
+
+
+class SingleQueryAttnFn(Function):
+    """attention of one (projected) query per batch element over L projected key/value tokens
+    (GlobalCrossEncode, pipeline/models/ae_vit.py:22-42)"""
+
+    @staticmethod
+    def forward(ctx, q, kv, l, h):
+        q, kv = _c(q), _c(kv)
+        b = q.shape[0]
+        d = q.shape[1] // h
+        out, probs = ops.sq_attn_fwd(q, kv, b, l, h, d)
+        ctx.save_for_backward(q, kv, probs)
+        ctx.cfg = (b, l, h, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, probs = ctx.saved_tensors
+        dq, dkv = ops.sq_attn_bwd(q, kv, probs, _c(dout), *ctx.cfg)
+        return dq, dkv, None, None
+
+
+class AddBcastFn(Function):
+    """x (B, ...) + p (...) with p a parameter broadcast over the leading dimension (positional tokens)"""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        ctx.p = p
+        return ops.add_bcast(_c(x), _c(p))
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dp = None
+        if ctx.needs_input_grad[1]:
+            dp = grad_buffer(ctx.p)
+            ops.reduce_sum(dy, dy.numel() // dp.numel(), dp.numel(), 1, dp)
+        return dy, dp
+
+
+class ExpandRowsFn(Function):
+    """(1, F) parameter -> (B, F) rows (query_vec.expand, dec_queries.expand in AE_ViT_2048.forward)"""
+
+    @staticmethod
+    def forward(ctx, p, b):
+        ctx.p = p
+        return p.reshape(1, -1).expand(b, -1).contiguous()   # a copy, no arithmetic
+
+    @staticmethod
+    def backward(ctx, dy):
+        dp = grad_buffer(ctx.p)
+        dy = _c(dy)
+        ops.reduce_sum(dy, dy.shape[0], dp.numel(), 1, dp)
+        return dp, None
+
+
+class SliceColsFn(Function):
+    """columns [a, b) of a 2-D tensor (a copy; the gradient is zero outside the slice)"""
+
+    @staticmethod
+    def forward(ctx, x, a, b):
+        ctx.cfg = (x.shape, a, b)
+        return x[:, a:b].contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, a, b = ctx.cfg
+        dx = torch.zeros(shape, dtype=dy.dtype, device=dy.device)
+        dx[:, a:b].copy_(dy)
+        return dx, None, None
+
+
+class RepeatRowsFn(Function):
+    """(B, F) -> (B*l, F), every row repeated l times (one latent-derived token copied to all positions)"""
+
+    @staticmethod
+    def forward(ctx, x, l):
+        ctx.l = l
+        b, f = x.shape
+        return x.unsqueeze(1).expand(b, l, f).contiguous().view(b * l, f)
+
+    @staticmethod
+    def backward(ctx, dy):
+        l = ctx.l
+        dy = _c(dy)
+        return ops.sum_mid(dy, dy.shape[0] // l, l, dy.shape[1]), None
+
+
+class PatchEmbedFn(Function):
+    """Conv2d(C, E, kernel_size=P, stride=P) as patch folding + one GEMM (ae_vit.py:99,138-139): returns the
+    token rows (B*Hp*Wp, E), i.e. already `.flatten(2).transpose(1, 2)`"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        p = w.shape[2]
+        rows = ops.patchify(_c(x), p)
+        ctx.save_for_backward(rows, w)
+        ctx.bias = bias
+        return ops.linear_fwd(rows, w.view(w.shape[0], -1), bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows, w = ctx.saved_tensors
+        dy = _c(dy)
+        dw = grad_buffer(w)
+        ops.linear_bwd_weight(dy, rows, dw.view(w.shape[0], -1))
+        dbias = None
+        if ctx.bias is not None:
+            dbias = grad_buffer(ctx.bias)
+            ops.reduce_sum(dy, dy.shape[0], dy.shape[1], 1, dbias)
+        return None, dw, dbias
+
+
+class UnpatchFn(Function):
+    """ConvTranspose2d(E, C, kernel_size=P, stride=P) on token rows (B*Hp*Wp, E) -> image (B,C,Hp*P,Wp*P)
+    (ae_vit.py:128,165-166): one GEMM + patch unfolding"""
+
+    @staticmethod
+    def forward(ctx, tok, w, bias, b, hp, wp):
+        tok = _c(tok)
+        e, c, p = w.shape[0], w.shape[1], w.shape[2]
+        rows = ops.linear_bwd_data(tok, w.view(e, -1))          # (rows, E) x (E, C*P*P)
+        ctx.save_for_backward(tok, w)
+        ctx.cfg, ctx.bias = (b, c, hp, wp, p), bias
+        return ops.unpatchify(rows, bias, b, c, hp, wp, p)
+
+    @staticmethod
+    def backward(ctx, dimg):
+        tok, w = ctx.saved_tensors
+        b, c, hp, wp, p = ctx.cfg
+        drows = ops.patchify(_c(dimg), p)
+        e = w.shape[0]
+        dw = grad_buffer(w)
+        ops.linear_bwd_weight(tok, drows, dw.view(e, -1))        # dw[e][j] = sum_rows tok[row][e] drows[row][j]
+        dtok = ops.linear_fwd(drows, w.view(e, -1), None) if ctx.needs_input_grad[0] else None
+        dbias = None
+        if ctx.bias is not None:
+            dbias = grad_buffer(ctx.bias)
+            ops.reduce_sum(_c(dimg), b, c, hp * p * wp * p, dbias)
+        return dtok, dw, dbias, None, None, None
 
 
 class ReluFn(Function):

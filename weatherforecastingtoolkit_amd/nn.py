@@ -107,34 +107,40 @@ class Linear(tnn.Linear):
 
 
 class TransformerEncoderLayer(tnn.TransformerEncoderLayer):
-    """nn.TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout) as the reference builds it
-    (pipeline/models/ae_64x8x8_tf.py:77-79): post-norm, ReLU, batch_first=False.  Parameters and
-    state_dict keys are torch's; forward/backward run on libwfae.so kernels."""
+    """nn.TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout[, activation, batch_first]) as the
+    reference builds it: post-norm, ReLU, batch_first=False in pipeline/models/ae_64x8x8_tf.py:77-79; post-norm,
+    GELU, batch_first=True in pipeline/models/ae_vit.py:104-109,118-123.  Parameters and state_dict keys are
+    torch's; forward/backward run on libwfae.so kernels."""
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None, is_causal=False):
         if src_mask is not None or src_key_padding_mask is not None or is_causal:
             raise WfaeError("TransformerEncoderLayer: masks are not built (the reference passes none)")
         at = self.self_attn
-        if self.norm_first or at.batch_first or not at._qkv_same_embed_dim or at.bias_k is not None:
-            raise WfaeError("TransformerEncoderLayer: only the post-norm, seq-first default configuration is built")
-        if getattr(self, "activation_relu_or_gelu", 1) != 1:
-            raise WfaeError("TransformerEncoderLayer: only ReLU is built")
-        s, n, e = src.shape
+        if self.norm_first or not at._qkv_same_embed_dim or at.bias_k is not None:
+            raise WfaeError("TransformerEncoderLayer: only the post-norm configuration is built")
+        act = getattr(self, "activation_relu_or_gelu", 1)
+        if act not in (1, 2):
+            raise WfaeError("TransformerEncoderLayer: only ReLU and GELU are built")
+        bf = bool(at.batch_first)
+        if bf:
+            n, s, e = src.shape      # (batch, tokens, E): attention over the tokens of each batch element
+        else:
+            s, n, e = src.shape      # (seq, batch, E)
         h = at.num_heads
         tr = self.training
         x = src.contiguous().view(s * n, e)
         qkv = Fn.LinearFn.apply(x, at.in_proj_weight, at.in_proj_bias)
         p_attn = float(at.dropout) if tr else 0.0
-        a = Fn.MhaSeqFirstFn.apply(qkv, s, n, h, p_attn, Fn.next_seed() if p_attn > 0 else 0)
+        a = Fn.MhaSeqFirstFn.apply(qkv, s, n, h, p_attn, Fn.next_seed() if p_attn > 0 else 0, bf)
         a = Fn.LinearFn.apply(a, at.out_proj.weight, at.out_proj.bias)
         a = Fn.dropout(a, self.dropout1.p, tr)
         x1 = Fn.AddLayerNormFn.apply(x, a, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         f = Fn.LinearFn.apply(x1, self.linear1.weight, self.linear1.bias)
-        f = Fn.dropout(Fn.ReluFn.apply(f), self.dropout.p, tr)
+        f = Fn.dropout(Fn.ReluFn.apply(f) if act == 1 else Fn.GeluFn.apply(f), self.dropout.p, tr)
         f = Fn.LinearFn.apply(f, self.linear2.weight, self.linear2.bias)
         f = Fn.dropout(f, self.dropout2.p, tr)
         x2 = Fn.AddLayerNormFn.apply(x1, f, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        return x2.view(s, n, e)
+        return x2.view(n, s, e) if bf else x2.view(s, n, e)
 
 
 class TransformerEncoder(tnn.TransformerEncoder):

@@ -624,21 +624,73 @@ def layernorm_bwd(dy, x, res, gamma, mean, rstd, dgamma, dbeta, accumulate=False
     return dx
 
 
-def mha_fwd(qkv, s, n, h, d, p_drop=0.0, seed=0):
+def mha_fwd(qkv, s, n, h, d, p_drop=0.0, seed=0, batch_first=False):
+    """attention over the s axis for each of n sequences; rows of qkv: s*n+… (seq-first) or n*s+… (batch-first)"""
     _chk(qkv)
     out = torch.empty((s * n, h * d), dtype=torch.float32, device=qkv.device)
     probs = torch.empty((n, h, s, s), dtype=torch.float32, device=qkv.device)
-    _call("wfae_mha_seqfirst_fwd", 4 * n * h * s * s * d, 4 * (qkv.numel() + out.numel()), _p(qkv), _p(out), _p(probs),
-          s, n, h, d, p_drop, seed, _stream())
+    _call("wfae_mha_fwd", 4 * n * h * s * s * d, 4 * (qkv.numel() + out.numel()), _p(qkv), _p(out), _p(probs),
+          s, n, h, d, int(batch_first), p_drop, seed, _stream())
     return out, probs
 
 
-def mha_bwd(qkv, probs, dout, s, n, h, d, p_drop=0.0, seed=0):
+def mha_bwd(qkv, probs, dout, s, n, h, d, p_drop=0.0, seed=0, batch_first=False):
     _chk(qkv, probs, dout)
     dqkv = torch.empty_like(qkv)
-    _call("wfae_mha_seqfirst_bwd", 8 * n * h * s * s * d, 8 * qkv.numel(), _p(qkv), _p(probs), _p(dout), _p(dqkv), s, n,
-          h, d, p_drop, seed, _stream())
+    _call("wfae_mha_bwd", 8 * n * h * s * s * d, 8 * qkv.numel(), _p(qkv), _p(probs), _p(dout), _p(dqkv), s, n,
+          h, d, int(batch_first), p_drop, seed, _stream())
     return dqkv
+
+
+# --------------------------------------------------- AE_ViT_2048 (Path-B)
+def patchify(img, patch):
+    """(B,C,H,W) -> (B*Hp*Wp, C*P*P)"""
+    _chk(img)
+    b, c, h, w = img.shape
+    hp, wp = h // patch, w // patch
+    rows = torch.empty((b * hp * wp, c * patch * patch), dtype=torch.float32, device=img.device)
+    _call("wfae_patchify", 0, 8 * img.numel(), _p(img), _p(rows), b, c, hp, wp, patch, _stream())
+    return rows
+
+
+def unpatchify(rows, bias, b, c, hp, wp, patch):
+    """(B*Hp*Wp, C*P*P) (+ bias[c]) -> (B,C,Hp*P,Wp*P)"""
+    _chk(rows, bias)
+    img = torch.empty((b, c, hp * patch, wp * patch), dtype=torch.float32, device=rows.device)
+    _call("wfae_unpatchify", 0, 8 * img.numel(), _p(rows), _p(bias), _p(img), b, c, hp, wp, patch, _stream())
+    return img
+
+
+def add_bcast(x, p):
+    """x (outer, *inner) + p (*inner)"""
+    _chk(x, p)
+    out = torch.empty_like(x)
+    inner = p.numel()
+    _call("wfae_add_bcast", 0, 8 * x.numel(), _p(x), _p(p), _p(out), x.numel() // inner, inner, _stream())
+    return out
+
+
+def sum_mid(x, a, m, bn):
+    """x viewed as (a, m, bn) -> (a, bn)"""
+    _chk(x)
+    out = torch.empty((a, bn), dtype=torch.float32, device=x.device)
+    _call("wfae_sum_mid", 0, 4 * x.numel(), _p(x), _p(out), a, m, bn, _stream())
+    return out
+
+
+def sq_attn_fwd(q, kv, b, l, h, d):
+    _chk(q, kv)
+    out = torch.empty((b, h * d), dtype=torch.float32, device=q.device)
+    probs = torch.empty((b, h, l), dtype=torch.float32, device=q.device)
+    _call("wfae_sq_attn_fwd", 4 * b * h * l * d, 4 * (kv.numel() + q.numel()), _p(q), _p(kv), _p(out), _p(probs), b, l, h, d, _stream())
+    return out, probs
+
+
+def sq_attn_bwd(q, kv, probs, dout, b, l, h, d):
+    _chk(q, kv, probs, dout)
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    _call("wfae_sq_attn_bwd", 8 * b * h * l * d, 8 * kv.numel(), _p(q), _p(kv), _p(probs), _p(dout), _p(dq), _p(dkv), b, l, h, d, _stream())
+    return dq, dkv
 
 
 def relu_fwd(x):

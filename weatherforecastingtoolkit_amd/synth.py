@@ -177,6 +177,27 @@ def disc_state_dict_spec(input_nc: int = 1, ndf: int = 64, n_layers: int = 3):
     return e
 
 
+def generic_state_dict(named_shapes, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """Synthetic values for an arbitrary state_dict layout [(key, shape)] (used for AE_ViT_2048, whose 163 keys
+    are read off the module itself): matrices / conv kernels U(+-1/sqrt(fan_in)), LayerNorm weights U(0.8,1.2),
+    other vectors U(-0.1,0.1), 3-D parameters (positional / query tokens) ~N(0,1)."""
+    out = OrderedDict()
+    for key, shape in named_shapes:
+        shape = tuple(shape)
+        if len(shape) == 3:
+            out[key] = normal(seed, key, shape)
+        elif len(shape) in (2, 4):
+            b = 1.0 / np.sqrt(int(np.prod(shape[1:])))
+            out[key] = uniform(seed, key, shape, -b, b)
+        elif len(shape) == 1 and ".norm" in key and key.endswith(".weight"):
+            out[key] = uniform(seed, key, shape, 0.8, 1.2)
+        elif len(shape) == 1:
+            out[key] = uniform(seed, key, shape, -0.1, 0.1)
+        else:
+            raise ValueError(f"{key}: shape {shape}")
+    return out
+
+
 def synth_tensor(seed: int, key: str, shape, kind) -> np.ndarray:
     if kind == "gan_conv":
         return (np.float32(0.02) * normal(seed, key, shape)).astype(np.float32)

@@ -157,33 +157,35 @@ int wfae_add(const float* a, const float* b, float* out, int64_t n, wfae_stream_
 int wfae_reduce_sum(const float* x, int outer, int C, int inner, float* out, int accumulate,
                     void* ws, size_t ws_bytes, wfae_stream_t stream);
 
-/* ---- Winograd F(2x2,2x2) forms of the three 4x4 stride-2 operations above (same tensors, same results up to
- * fp32 rounding, 18 instead of 32 FLOP per (lo channel, hi channel, lo pixel)).  The convolution is split into its
- * four input-parity phases (each a 2x2 stride-1 convolution) and every phase goes through F(2x2,2x2): nine GEMMs
- * over T = NB*Hlo*Wlo/4 tiles.  The pieces are separate entry points so that a training step transforms every
- * tensor once and reuses it (the weight gradient shares both transformed operands with the forward / data
- * gradient of the same layer):
- *   wino_weights:    w (Clo,Chi,4,4)       -> U  [9][Clo][4Chi]    (G g G^T per phase)
- *   wino_in:         hi (NB,Chi,2Hlo,2Wlo) -> V  [9][4Chi][T]      (B^T d B of the 6x6 stride-4 patches)
- *   wino_out_t:      lo (NB,Clo,Hlo,Wlo)   -> Mt [9][Clo][T]       (adjoint of the output transform)
- *   wino_gemm_down:  M  = U * V    [9][Clo][T]   then  wino_out:  lo = A^T M A          (= wfae_conv4x4s2_down)
- *   wino_gemm_up:    dV = U^T * Mt [9][4Chi][T]  then  wino_in_t: hi = overlap-add B dV B^T (= wfae_conv4x4s2_up)
- *   wino_gemm_wgrad: dw = G^T (Mt * V^T) G,  ws >= 2 * 4*|U| bytes                      (= wfae_conv4x4s2_wgrad)
- * with Mt = wino_out_t(lo-side tensor), V = wino_in(hi-side tensor).  Supported when Hlo, Wlo are even,
- * Chi % 4 == 0, Clo % 4 == 0 and T % 4 == 0; wfae_wino_sizes returns WFAE_ERR_UNSUPPORTED otherwise and
+/* ---- Winograd forms of the three 4x4 stride-2 operations above (same tensors, same results up to fp32
+ * rounding).  The convolution is split into its four input-parity phases (each a 2x2 stride-1 convolution) and
+ * every phase goes through F(MxM, 2x2) on N x N input tiles, N = M + 1:
+ *   variant 0: F(2x2,2x2), 9 GEMMs,  18   FLOP per (lo channel, hi channel, lo pixel) instead of 32;
+ *   variant 1: F(4x4,2x2), 25 GEMMs, 12.5 FLOP; interpolation points {0, +-1, +-2}.
+ * xi = N*N transform positions, T = NB*Hlo*Wlo/M^2 tiles.  The pieces are separate entry points so that a
+ * training step transforms every tensor once and reuses it (the weight gradient shares both transformed
+ * operands with the forward / data gradient of the same layer):
+ *   wino_weights:    w (Clo,Chi,4,4)       -> U  [xi][Clo][4Chi]   (G g G^T per phase)
+ *   wino_in:         hi (NB,Chi,2Hlo,2Wlo) -> V  [xi][4Chi][T]     (B^T d B of the 2N x 2N patches at stride 2M)
+ *   wino_out_t:      lo (NB,Clo,Hlo,Wlo)   -> Mt [xi][Clo][T]      (adjoint of the output transform)
+ *   wino_gemm_down:  M  = U * V    [xi][Clo][T]   then  wino_out:  lo = A^T M A           (= wfae_conv4x4s2_down)
+ *   wino_gemm_up:    dV = U^T * Mt [xi][4Chi][T]  then  wino_in_t: hi = overlap-add B dV B^T (= wfae_conv4x4s2_up)
+ *   wino_gemm_wgrad: dw = G^T (Mt * V^T) G,  ws >= 2 * 4*|U| bytes                        (= wfae_conv4x4s2_wgrad)
+ * with Mt = wino_out_t(lo-side tensor), V = wino_in(hi-side tensor).  Supported when Hlo, Wlo are multiples of
+ * M, Chi % 4 == 0, Clo % 4 == 0 and T % 4 == 0; wfae_wino_sizes returns WFAE_ERR_UNSUPPORTED otherwise and
  * {T, |U|, |V|, |M|} (element counts) in out4 when it is. */
-int wfae_wino_sizes(int NB, int Chi, int Clo, int Hlo, int Wlo, int64_t* out4);
-int wfae_wino_weights(const float* w, float* U, int Chi, int Clo, wfae_stream_t stream);
-int wfae_wino_in(const float* hi, float* V, int NB, int Chi, int Hlo, int Wlo, wfae_stream_t stream);
-int wfae_wino_in_t(const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, wfae_stream_t stream);
-int wfae_wino_out(const float* M, float* lo, int NB, int Clo, int Hlo, int Wlo, wfae_stream_t stream);
-int wfae_wino_out_t(const float* lo, float* Mt, int NB, int Clo, int Hlo, int Wlo, wfae_stream_t stream);
-int wfae_wino_gemm_down(const float* U, const float* V, float* M, int NB, int Chi, int Clo, int Hlo, int Wlo,
+int wfae_wino_sizes(int variant, int NB, int Chi, int Clo, int Hlo, int Wlo, int64_t* out4);
+int wfae_wino_weights(int variant, const float* w, float* U, int Chi, int Clo, wfae_stream_t stream);
+int wfae_wino_in(int variant, const float* hi, float* V, int NB, int Chi, int Hlo, int Wlo, wfae_stream_t stream);
+int wfae_wino_in_t(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, wfae_stream_t stream);
+int wfae_wino_out(int variant, const float* M, float* lo, int NB, int Clo, int Hlo, int Wlo, wfae_stream_t stream);
+int wfae_wino_out_t(int variant, const float* lo, float* Mt, int NB, int Clo, int Hlo, int Wlo, wfae_stream_t stream);
+int wfae_wino_gemm_down(int variant, const float* U, const float* V, float* M, int NB, int Chi, int Clo, int Hlo, int Wlo,
                         wfae_stream_t stream);
-int wfae_wino_gemm_up(const float* U, const float* Mt, float* dV, int NB, int Chi, int Clo, int Hlo, int Wlo,
+int wfae_wino_gemm_up(int variant, const float* U, const float* Mt, float* dV, int NB, int Chi, int Clo, int Hlo, int Wlo,
                       wfae_stream_t stream);
-int wfae_wino_gemm_wgrad(const float* Mt, const float* V, float* dw, int NB, int Chi, int Clo, int Hlo, int Wlo,
-                         int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
+int wfae_wino_gemm_wgrad(int variant, const float* Mt, const float* V, float* dw, int NB, int Chi, int Clo, int Hlo,
+                         int Wlo, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
 
 /* ---- 4x4 stride-1 convolution on the MFMA GEMM (PatchGAN layer 4: Conv2d(256, 512, 4, stride=1, padding=1,
  * bias=False), pipeline/models/autoencoderkl/losses/model.py:137).

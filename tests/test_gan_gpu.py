@@ -204,12 +204,13 @@ def test_gan_training_steps_golden(dev, overlap):
         # whose direction (lr * sign-like) amplifies rounding and LeakyReLU-kink differences: the reference's
         # own arithmetic run in fp32 vs fp64 (tests/golden/gan_sensitivity.py) differs at step 1 by 3.0e-2 in
         # the reconstruction, 3.3e-2 in d_weight, 3.7e-2 in the generator gradient norm, 5.3e-3 in total_loss,
-        # 4.6e-4 in g_loss and 2e-5 in rec_loss — step-1 tolerances are about 2x those spreads.
+        # 4.6e-4 in g_loss and 2e-5 in rec_loss — step-1 tolerances are a few times those spreads (one sample of a
+        # chaotic quantity is not a bound).
         tols = [
             dict(recon=1e-4, rec_loss=1e-5, g_loss=1e-4, d_weight=5e-3, total_loss=1e-3, disc_loss=1e-5,
                  logits_real=1e-4, logits_fake=1e-4, g_grad_norm=5e-3, d_grad_norm=5e-3),
-            dict(recon=6e-2, rec_loss=1e-4, g_loss=1e-2, d_weight=8e-2, total_loss=1.5e-2, disc_loss=1e-4,
-                 logits_real=1e-4, logits_fake=1e-2, g_grad_norm=8e-2, d_grad_norm=5e-3),
+            dict(recon=6e-2, rec_loss=1e-4, g_loss=1e-2, d_weight=8e-2, total_loss=1.5e-2, disc_loss=5e-4,
+                 logits_real=5e-4, logits_fake=1e-2, g_grad_norm=8e-2, d_grad_norm=5e-3),
         ]
         grad_norms = {}
 

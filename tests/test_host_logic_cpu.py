@@ -106,3 +106,37 @@ def test_synth_is_reproducible_and_shaped():
     assert ev.dtype == np.uint8 and ev.shape == (1, 32, 32, 3) and (ev == 0).mean() > 0.2
     w = synth.synth_tensor(0, "enc.1.down.0.weight", (512, 256, 4, 4), "conv")
     assert abs(np.abs(w).max() - 1 / np.sqrt(256 * 16)) < 1e-4
+
+
+def test_winograd_matrices_in_wino_hip_are_exact():
+    """The F(2x2,2x2) and F(4x4,2x2) matrices compiled into csrc/wino.hip (parsed from the source) satisfy
+    y = A^T [(G g) * (B^T d)] for the 2-tap correlation, in 1-D and 2-D, and In^T / Out^T are their transposes by
+    construction.  F(4,2) is the Toom-Cook algorithm on the points {0, 1, -1, 2, -2}."""
+    import os
+    import re
+    import numpy as np
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "weatherforecastingtoolkit_amd",
+                            "csrc", "wino.hip")).read()
+
+    def mat(struct, name):
+        body = re.search(r"struct %s \{(.*?)\n\};" % struct, src, re.S).group(1)
+        m = re.search(r"%s\[(\d+)\]\[(\d+)\] = \{(.*?)\};" % name, body, re.S)
+        vals = re.findall(r"-?[\d.]+f?(?:\s*/\s*\d+)?", m.group(3))
+        nums = []
+        for v in vals:
+            v = v.replace("f", "")
+            nums.append(eval(v))
+        return np.array(nums, dtype=np.float64).reshape(int(m.group(1)), int(m.group(2)))
+
+    rng = np.random.default_rng(0)
+    for struct, n, m in (("W22", 3, 2), ("W42", 5, 4)):
+        BT, G, AT = mat(struct, "BT"), mat(struct, "G"), mat(struct, "AT")
+        assert BT.shape == (n, n) and G.shape == (n, 2) and AT.shape == (m, n)
+        d, g = rng.standard_normal(n), rng.standard_normal(2)
+        y = AT @ ((G @ g) * (BT @ d))
+        ref = np.array([d[o] * g[0] + d[o + 1] * g[1] for o in range(m)])
+        assert np.abs(y - ref).max() < 1e-12
+        d2, g2 = rng.standard_normal((n, n)), rng.standard_normal((2, 2))
+        y2 = AT @ ((G @ g2 @ G.T) * (BT @ d2 @ BT.T)) @ AT.T
+        ref2 = np.array([[sum(d2[o + a, p + b] * g2[a, b] for a in range(2) for b in range(2)) for p in range(m)] for o in range(m)])
+        assert np.abs(y2 - ref2).max() < 1e-12

@@ -99,19 +99,20 @@ def test_conv4x4s2(ops, dev, nb, chi, clo, hlo, wlo):
     assert relerr(dw, wt.grad) < TOL
 
 
+@pytest.mark.parametrize("mode", ["f22", "f42"])
 @pytest.mark.parametrize("nb,chi,clo,hlo,wlo", [
     (2, 8, 16, 8, 8), (1, 4, 8, 4, 6), (4, 16, 32, 6, 10), (2, 64, 128, 16, 16), (3, 12, 20, 2, 4), (1, 256, 512, 8, 8),
-    (2, 128, 256, 4, 4), (1, 16, 16, 4, 4),
+    (2, 128, 256, 4, 4), (1, 16, 16, 4, 4), (1, 8, 8, 12, 20), (4, 32, 16, 8, 4),
 ])
-def test_conv4x4s2_winograd(ops, dev, nb, chi, clo, hlo, wlo):
-    """Winograd F(2x2,2x2) forms of down / up / wgrad against torch (same tolerance as the direct GEMMs)"""
+def test_conv4x4s2_winograd(ops, dev, nb, chi, clo, hlo, wlo, mode):
+    """Winograd F(2x2,2x2) / F(4x4,2x2) forms of down / up / wgrad against torch (same tolerance as the direct GEMMs)"""
     hi = rnd((nb, chi, 2 * hlo, 2 * wlo), 1)
     lo = rnd((nb, clo, hlo, wlo), 2)
     w = rnd((clo, chi, 4, 4), 3, -0.3, 0.3)
     hr, wr = hi.clone().requires_grad_(True), w.clone().requires_grad_(True)
     ref = F.conv2d(hr, wr, None, stride=2, padding=1)
     ref.backward(lo)
-    ops.set_winograd(True)
+    ops.set_winograd(mode)
     try:
         prof = None
         ops.profile_start()
@@ -124,11 +125,12 @@ def test_conv4x4s2_winograd(ops, dev, nb, chi, clo, hlo, wlo):
         prof = ops.profile_stop()
     finally:
         ops.set_winograd("auto")
-    tiles = nb * (hlo // 2) * (wlo // 2)
-    if tiles % 4 == 0:   # else the library reports the geometry as unsupported and the direct GEMM runs
+    m = 4 if mode == "f42" else 2
+    supported = hlo % m == 0 and wlo % m == 0 and (nb * (hlo // m) * (wlo // m)) % 4 == 0 and chi % 4 == 0 and clo % 4 == 0
+    if supported:
         assert {"wfae_wino_gemm_down", "wfae_wino_gemm_up", "wfae_wino_gemm_wgrad", "wfae_wino_in", "wfae_wino_in_t",
                 "wfae_wino_out", "wfae_wino_out_t", "wfae_wino_weights"} <= set(prof)
-    else:
+    else:   # the library reports the geometry as unsupported and the direct GEMM runs
         assert {"wfae_conv4x4s2_down", "wfae_conv4x4s2_up", "wfae_conv4x4s2_wgrad"} <= set(prof)
     assert relerr(got_down, ref) < TOL
     assert relerr(got_up, hr.grad) < TOL

@@ -74,13 +74,14 @@ __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-// Winograd F(2x2,2x2) transforms of the 4x4 stride-2 convolutions (wino.hip); T = NB*Hlo*Wlo/4 tiles
-int wino_in(const float* hi, float* V, int NB, int Chi, int Hlo, int Wlo, hipStream_t st);      // -> V[9][4Chi][T]
-int wino_in_t(const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, hipStream_t st);   // adjoint
-int wino_out(const float* M, float* lo, int NB, int Clo, int Hlo, int Wlo, hipStream_t st);     // M[9][Clo][T] ->
-int wino_out_t(const float* lo, float* Mt, int NB, int Clo, int Hlo, int Wlo, hipStream_t st);  // adjoint
-int wino_weights(const float* w, float* U, int Clo, int Chi, hipStream_t st);                   // -> U[9][Clo][4Chi]
-int wino_weights_t(const float* dU, float* dw, int Clo, int Chi, int beta, hipStream_t st);     // G^T dU G
+// Winograd transforms of the 4x4 stride-2 convolutions (wino.hip); variant 0 = F(2x2,2x2) (N = 3, M = 2),
+// variant 1 = F(4x4,2x2) (N = 5, M = 4); T = NB*Hlo*Wlo/M^2 tiles, N*N transform positions xi
+int wino_in(int variant, const float* hi, float* V, int NB, int Chi, int Hlo, int Wlo, hipStream_t st);      // -> V[xi][4Chi][T]
+int wino_in_t(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, hipStream_t st);   // adjoint
+int wino_out(int variant, const float* M, float* lo, int NB, int Clo, int Hlo, int Wlo, hipStream_t st);     // M[xi][Clo][T] ->
+int wino_out_t(int variant, const float* lo, float* Mt, int NB, int Clo, int Hlo, int Wlo, hipStream_t st);  // adjoint
+int wino_weights(int variant, const float* w, float* U, int Clo, int Chi, hipStream_t st);                   // -> U[xi][Clo][4Chi]
+int wino_weights_t(int variant, const float* dU, float* dw, int Clo, int Chi, int beta, hipStream_t st);     // G^T dU G
 
 // out = (beta ? out : 0) + sum over `splits` partial slabs of MN floats (+ bias_n[i % N]); fixed order.
 int slab_reduce(const float* slab, float* out, const float* bias_n, long MN, int N, int splits, int beta,

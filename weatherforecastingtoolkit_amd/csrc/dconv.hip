@@ -6,6 +6,7 @@
 // Each block stages an input patch (+halo) with coalesced row reads, weights
 // are wave-uniform (scalar loads), every thread owns one output pixel and OCB
 // output channels in registers.
+#include <stdlib.h>
 #include "common.h"
 
 using namespace wfae;
@@ -583,6 +584,11 @@ int gconv3_wgrad_valu(const float* dy, const float* x, float* dw, int NB, int C,
                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
   const int cpg = C / groups;
   if (!(cpg == 4 || cpg == 8 || cpg == 16)) return WFAE_ERR_UNSUPPORTED;
+  {
+    static const char* e = getenv("WFAE_G3_MFMA_MIN_CPG");   // A/B: channels per group from which the MFMA path is used
+    const int mfma_from = e ? atoi(e) : 32;
+    if (cpg >= mfma_from) return WFAE_ERR_UNSUPPORTED;
+  }
   const int ocw = 144 / (cpg * 9);
   const int units = groups * (cpg / ocw);
   if (units % 4 != 0) return WFAE_ERR_UNSUPPORTED;

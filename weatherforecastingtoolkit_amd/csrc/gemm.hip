@@ -1517,75 +1517,81 @@ int wfae_conv4x4s1_bwd_weight(const float* dy, const float* x, float* dw, int NB
   return check_launch("conv4x4s1 unpack");
 }
 
-// ---- Winograd F(2x2,2x2) forms of the three 4x4 stride-2 operations (transforms in wino.hip) ----------
+// ---- Winograd forms of the three 4x4 stride-2 operations (transforms in wino.hip) ---------------------
 namespace {
 struct WinoGeom {
   long T;      // tiles
   int K4;      // 4 * Chi
+  int NX;      // transform positions: 9 (F(2x2,2x2)) or 25 (F(4x4,2x2))
   size_t nU, nV, nM;
 };
-inline bool wino_geom(int NB, int Chi, int Clo, int Hlo, int Wlo, WinoGeom* g) {
+inline bool wino_geom(int variant, int NB, int Chi, int Clo, int Hlo, int Wlo, WinoGeom* g) {
+  if (variant != 0 && variant != 1) return false;
   if (NB <= 0 || Chi <= 0 || Clo <= 0 || Hlo <= 0 || Wlo <= 0) return false;
-  if ((Hlo & 1) || (Wlo & 1)) return false;
-  g->T = (long)NB * (Hlo / 2) * (Wlo / 2);
+  const int M = variant ? 4 : 2;
+  if ((Hlo % M) || (Wlo % M)) return false;
+  g->T = (long)NB * (Hlo / M) * (Wlo / M);
   // 16-byte rows for the all-vector GEMM kernels
   if (g->T % 4 != 0 || g->T >= (1ll << 31) || Chi % 4 != 0 || Clo % 4 != 0) return false;
+  if (NB > 65535 || Chi > 65535 || Clo > 65535) return false;
   g->K4 = 4 * Chi;
-  g->nU = (size_t)9 * Clo * g->K4;
-  g->nV = (size_t)9 * g->K4 * g->T;
-  g->nM = (size_t)9 * Clo * g->T;
+  g->NX = variant ? 25 : 9;
+  g->nU = (size_t)g->NX * Clo * g->K4;
+  g->nV = (size_t)g->NX * g->K4 * g->T;
+  g->nM = (size_t)g->NX * Clo * g->T;
   return true;
 }
 }  // namespace
 
-int wfae_wino_sizes(int NB, int Chi, int Clo, int Hlo, int Wlo, int64_t* out4) {
+int wfae_wino_sizes(int variant, int NB, int Chi, int Clo, int Hlo, int Wlo, int64_t* out4) {
   WFAE_REQUIRE(out4, WFAE_ERR_NULL_POINTER, "wino_sizes: null pointer");
   WinoGeom g;
-  if (!wino_geom(NB, Chi, Clo, Hlo, Wlo, &g)) return WFAE_ERR_UNSUPPORTED;  // no message: a query, not a failure
+  if (!wino_geom(variant, NB, Chi, Clo, Hlo, Wlo, &g)) return WFAE_ERR_UNSUPPORTED;  // a query, not a failure
   out4[0] = g.T; out4[1] = (int64_t)g.nU; out4[2] = (int64_t)g.nV; out4[3] = (int64_t)g.nM;
   return WFAE_OK;
 }
 
-int wfae_wino_weights(const float* w, float* U, int Chi, int Clo, wfae_stream_t stream) {
+#define WFAE_WINO_TILE_CHECK(what, C_)                                                                          \
+  WFAE_REQUIRE((variant == 0 || variant == 1) && NB > 0 && NB <= 65535 && (C_) > 0 && (C_) <= 65535 && Hlo > 0 && \
+                   Wlo > 0 && Hlo % (variant ? 4 : 2) == 0 && Wlo % (variant ? 4 : 2) == 0,                       \
+               WFAE_ERR_BAD_SHAPE, what ": bad shape")
+
+int wfae_wino_weights(int variant, const float* w, float* U, int Chi, int Clo, wfae_stream_t stream) {
   WFAE_REQUIRE(w && U, WFAE_ERR_NULL_POINTER, "wino_weights: null pointer");
-  WFAE_REQUIRE(Chi > 0 && Clo > 0, WFAE_ERR_BAD_SHAPE, "wino_weights: bad shape");
-  return wino_weights(w, U, Clo, Chi, (hipStream_t)stream);
+  WFAE_REQUIRE((variant == 0 || variant == 1) && Chi > 0 && Clo > 0, WFAE_ERR_BAD_SHAPE, "wino_weights: bad shape");
+  return wino_weights(variant, w, U, Clo, Chi, (hipStream_t)stream);
 }
 
-int wfae_wino_in(const float* hi, float* V, int NB, int Chi, int Hlo, int Wlo, wfae_stream_t stream) {
+int wfae_wino_in(int variant, const float* hi, float* V, int NB, int Chi, int Hlo, int Wlo, wfae_stream_t stream) {
   WFAE_REQUIRE(hi && V, WFAE_ERR_NULL_POINTER, "wino_in: null pointer");
-  WFAE_REQUIRE(NB > 0 && NB <= 65535 && Chi > 0 && Chi <= 65535 && Hlo > 0 && Wlo > 0 && !(Hlo & 1) && !(Wlo & 1),
-               WFAE_ERR_BAD_SHAPE, "wino_in: bad shape");
-  return wino_in(hi, V, NB, Chi, Hlo, Wlo, (hipStream_t)stream);
+  WFAE_WINO_TILE_CHECK("wino_in", Chi);
+  return wino_in(variant, hi, V, NB, Chi, Hlo, Wlo, (hipStream_t)stream);
 }
 
-int wfae_wino_out_t(const float* lo, float* Mt, int NB, int Clo, int Hlo, int Wlo, wfae_stream_t stream) {
+int wfae_wino_out_t(int variant, const float* lo, float* Mt, int NB, int Clo, int Hlo, int Wlo, wfae_stream_t stream) {
   WFAE_REQUIRE(lo && Mt, WFAE_ERR_NULL_POINTER, "wino_out_t: null pointer");
-  WFAE_REQUIRE(NB > 0 && NB <= 65535 && Clo > 0 && Clo <= 65535 && Hlo > 0 && Wlo > 0 && !(Hlo & 1) && !(Wlo & 1),
-               WFAE_ERR_BAD_SHAPE, "wino_out_t: bad shape");
-  return wino_out_t(lo, Mt, NB, Clo, Hlo, Wlo, (hipStream_t)stream);
+  WFAE_WINO_TILE_CHECK("wino_out_t", Clo);
+  return wino_out_t(variant, lo, Mt, NB, Clo, Hlo, Wlo, (hipStream_t)stream);
 }
 
-int wfae_wino_out(const float* M, float* lo, int NB, int Clo, int Hlo, int Wlo, wfae_stream_t stream) {
+int wfae_wino_out(int variant, const float* M, float* lo, int NB, int Clo, int Hlo, int Wlo, wfae_stream_t stream) {
   WFAE_REQUIRE(M && lo, WFAE_ERR_NULL_POINTER, "wino_out: null pointer");
-  WFAE_REQUIRE(NB > 0 && NB <= 65535 && Clo > 0 && Clo <= 65535 && Hlo > 0 && Wlo > 0 && !(Hlo & 1) && !(Wlo & 1),
-               WFAE_ERR_BAD_SHAPE, "wino_out: bad shape");
-  return wino_out(M, lo, NB, Clo, Hlo, Wlo, (hipStream_t)stream);
+  WFAE_WINO_TILE_CHECK("wino_out", Clo);
+  return wino_out(variant, M, lo, NB, Clo, Hlo, Wlo, (hipStream_t)stream);
 }
 
-int wfae_wino_in_t(const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, wfae_stream_t stream) {
+int wfae_wino_in_t(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, wfae_stream_t stream) {
   WFAE_REQUIRE(dV && hi, WFAE_ERR_NULL_POINTER, "wino_in_t: null pointer");
-  WFAE_REQUIRE(NB > 0 && NB <= 65535 && Chi > 0 && Chi <= 65535 && Hlo > 0 && Wlo > 0 && !(Hlo & 1) && !(Wlo & 1),
-               WFAE_ERR_BAD_SHAPE, "wino_in_t: bad shape");
-  return wino_in_t(dV, hi, NB, Chi, Hlo, Wlo, (hipStream_t)stream);
+  WFAE_WINO_TILE_CHECK("wino_in_t", Chi);
+  return wino_in_t(variant, dV, hi, NB, Chi, Hlo, Wlo, (hipStream_t)stream);
 }
 
-int wfae_wino_gemm_down(const float* U, const float* V, float* M, int NB, int Chi, int Clo, int Hlo, int Wlo,
+int wfae_wino_gemm_down(int variant, const float* U, const float* V, float* M, int NB, int Chi, int Clo, int Hlo, int Wlo,
                         wfae_stream_t stream) {
   WFAE_REQUIRE(U && V && M, WFAE_ERR_NULL_POINTER, "wino_gemm_down: null pointer");
   WinoGeom g;
-  WFAE_REQUIRE(wino_geom(NB, Chi, Clo, Hlo, Wlo, &g) && NB <= 65535 && Clo <= 65535, WFAE_ERR_UNSUPPORTED,
-               "wino_gemm_down: needs even Hlo, Wlo, channels %% 4 == 0 and a tile count divisible by 4");
+  WFAE_REQUIRE(wino_geom(variant, NB, Chi, Clo, Hlo, Wlo, &g), WFAE_ERR_UNSUPPORTED,
+               "wino_gemm_down: needs Hlo, Wlo divisible by the tile, channels %% 4 == 0 and a tile count divisible by 4");
   hipStream_t st = (hipStream_t)stream;
   GemmP p = {};  // M_xi (Clo x T) = U_xi (Clo x 4Chi) * V_xi (4Chi x T)
   p.A = U; p.B = V; p.C = M;
@@ -1596,15 +1602,15 @@ int wfae_wino_gemm_down(const float* U, const float* V, float* M, int NB, int Ch
   p.a_y = (long)Clo * g.K4; p.b_y = (long)g.K4 * g.T; p.c_y = (long)Clo * g.T;
   p.a_vec = aligned16(U); p.b_vec = aligned16(V); p.c_vec = aligned16(M);
   p.big_ok = 1;
-  return launch_gemm<A_KCONTIG, B_NCONTIG, E_BATCHED>(p, 1, st, "wino_gemm_down", 9);
+  return launch_gemm<A_KCONTIG, B_NCONTIG, E_BATCHED>(p, 1, st, "wino_gemm_down", g.NX);
 }
 
-int wfae_wino_gemm_up(const float* U, const float* Mt, float* dV, int NB, int Chi, int Clo, int Hlo, int Wlo,
+int wfae_wino_gemm_up(int variant, const float* U, const float* Mt, float* dV, int NB, int Chi, int Clo, int Hlo, int Wlo,
                       wfae_stream_t stream) {
   WFAE_REQUIRE(U && Mt && dV, WFAE_ERR_NULL_POINTER, "wino_gemm_up: null pointer");
   WinoGeom g;
-  WFAE_REQUIRE(wino_geom(NB, Chi, Clo, Hlo, Wlo, &g) && NB <= 65535 && Chi <= 65535, WFAE_ERR_UNSUPPORTED,
-               "wino_gemm_up: needs even Hlo, Wlo, channels %% 4 == 0 and a tile count divisible by 4");
+  WFAE_REQUIRE(wino_geom(variant, NB, Chi, Clo, Hlo, Wlo, &g), WFAE_ERR_UNSUPPORTED,
+               "wino_gemm_up: needs Hlo, Wlo divisible by the tile, channels %% 4 == 0 and a tile count divisible by 4");
   hipStream_t st = (hipStream_t)stream;
   GemmP p = {};  // dV_xi (4Chi x T) = U_xi^T (4Chi x Clo) * Mt_xi (Clo x T)
   p.A = U; p.B = Mt; p.C = dV;
@@ -1615,15 +1621,15 @@ int wfae_wino_gemm_up(const float* U, const float* Mt, float* dV, int NB, int Ch
   p.a_y = (long)Clo * g.K4; p.b_y = (long)Clo * g.T; p.c_y = (long)g.K4 * g.T;
   p.a_vec = aligned16(U); p.b_vec = aligned16(Mt); p.c_vec = aligned16(dV);
   p.big_ok = 1;
-  return launch_gemm<A_MCONTIG, B_NCONTIG, E_BATCHED>(p, 1, st, "wino_gemm_up", 9);
+  return launch_gemm<A_MCONTIG, B_NCONTIG, E_BATCHED>(p, 1, st, "wino_gemm_up", g.NX);
 }
 
-int wfae_wino_gemm_wgrad(const float* Mt, const float* V, float* dw, int NB, int Chi, int Clo, int Hlo, int Wlo,
-                    int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream) {
+int wfae_wino_gemm_wgrad(int variant, const float* Mt, const float* V, float* dw, int NB, int Chi, int Clo, int Hlo,
+                         int Wlo, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream) {
   WFAE_REQUIRE(Mt && V && dw, WFAE_ERR_NULL_POINTER, "wino_gemm_wgrad: null pointer");
   WinoGeom g;
-  WFAE_REQUIRE(wino_geom(NB, Chi, Clo, Hlo, Wlo, &g), WFAE_ERR_UNSUPPORTED,
-               "wino_gemm_wgrad: needs even Hlo, Wlo, channels %% 4 == 0 and a tile count divisible by 4");
+  WFAE_REQUIRE(wino_geom(variant, NB, Chi, Clo, Hlo, Wlo, &g), WFAE_ERR_UNSUPPORTED,
+               "wino_gemm_wgrad: needs Hlo, Wlo divisible by the tile, channels %% 4 == 0 and a tile count divisible by 4");
   const size_t slab = g.nU * sizeof(float);
   WFAE_REQUIRE(ws && ws_bytes >= 2 * slab, WFAE_ERR_WORKSPACE, "wino_gemm_wgrad: workspace %zu < %zu", ws_bytes, 2 * slab);
   hipStream_t st = (hipStream_t)stream;
@@ -1637,8 +1643,8 @@ int wfae_wino_gemm_wgrad(const float* Mt, const float* V, float* dw, int NB, int
   p.a_y = (long)Clo * g.T; p.b_y = (long)g.K4 * g.T;
   p.a_vec = aligned16(Mt); p.b_vec = aligned16(V); p.c_vec = aligned16(slabs);
   p.big_ok = 1;
-  // split K so that 9 * tiles * splits covers the chip a few times; a slab holds all nine dU_xi
-  const long tiles = (long)cdiv(Clo, Clo >= 256 ? 256 : 128) * cdiv(g.K4, BN) * 9;
+  // split K so that NX * tiles * splits covers the chip a few times; a slab holds all dU_xi
+  const long tiles = (long)cdiv(Clo, Clo >= 256 ? 256 : 128) * cdiv(g.K4, BN) * g.NX;
   const int stages = cdiv(p.K, BK);
   long want = (2048 + tiles - 1) / tiles;
   if (want < 1) want = 1;
@@ -1646,11 +1652,11 @@ int wfae_wino_gemm_wgrad(const float* Mt, const float* V, float* dw, int NB, int
   while (want > 1 && (size_t)want * slab > ws_bytes - slab) --want;
   p.k_per_split = cdiv(stages, (int)want) * BK;
   const int splits = cdiv(p.K, p.k_per_split);
-  int rc = launch_gemm<A_KCONTIG, B_KCONTIG, E_SLAB>(p, splits, st, "wino_gemm_wgrad", 9);
+  int rc = launch_gemm<A_KCONTIG, B_KCONTIG, E_SLAB>(p, splits, st, "wino_gemm_wgrad", g.NX);
   if (rc) return rc;
   rc = splitk_finish(slabs, dU, nullptr, (long)g.nU, g.K4, splits, 0, st);
   if (rc) return rc;
-  return wino_weights_t(dU, dw, Clo, Chi, accumulate ? 1 : 0, st);
+  return wino_weights_t(variant, dU, dw, Clo, Chi, accumulate ? 1 : 0, st);
 }
 
 }  // extern "C"

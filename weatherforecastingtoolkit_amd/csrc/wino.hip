@@ -1,18 +1,22 @@
-// wino.hip — Winograd F(2x2, 2x2) transforms for the 4x4 stride-2 convolutions.
+// wino.hip — Winograd transforms for the 4x4 stride-2 convolutions.
 //
 // A 4x4 stride-2 pad-1 convolution is the sum of four 2x2 stride-1 "valid" convolutions, one per input
 // parity phase:   lo[oy][ox] = sum_{p,q} sum_{a,b} w[2a+p][2b+q] * P_pq[oy+a][ox+b],
 // P_pq[i][j] = hi[2i-1+p][2j-1+q]  (zero outside the image), i in [0,Hlo], j in [0,Wlo].
-// Each phase goes through F(2x2,2x2): per 2x2 output tile 9 multiplies instead of 16, i.e. 9 GEMMs
-// M_xi = U_xi (Clo x 4Chi) * V_xi (4Chi x T) over T = N*Hlo*Wlo/4 tiles instead of one implicit GEMM with
-// K = 16 Chi:  18 instead of 32 FLOP per (lo channel, hi channel, lo pixel).
-//   V = B^T d B   (input tile d 3x3 per phase; the four phases' tiles are the 6x6 hi patch at stride 4)
+// Each phase goes through a Winograd algorithm F(MxM, 2x2) on N x N input tiles (N = M + 1): N*N GEMMs
+// M_xi = U_xi (Clo x 4Chi) * V_xi (4Chi x T) over T = NB*Hlo*Wlo/M^2 tiles instead of one implicit GEMM with
+// K = 16 Chi.
+//   variant 0: F(2x2,2x2), N = 3:  9 multiplies per 2x2 outputs  -> 18 FLOP per (lo ch, hi ch, lo pixel) vs 32
+//   variant 1: F(4x4,2x2), N = 5: 25 multiplies per 4x4 outputs  -> 12.5 FLOP
+//   V = B^T d B   (d = N x N tile of a phase; the four phases' tiles are one 2N x 2N hi patch at stride 2M)
 //   U = G g G^T   (g = the phase's 2x2 filter)
 //   Y = A^T M A
-//   B^T = [1 -1 0; 0 1 0; 0 -1 1]   G = [1 0; 1 1; 0 1]   A^T = [1 1 0; 0 1 1]
+// F(4,2) uses the interpolation points {0, 1, -1, 2, -2} (Toom-Cook; matrices derived and checked in
+// tests/test_host_logic_cpu.py): in fp32 its error is that of the direct form (1.7e-6 vs 1.3e-6 max-rel
+// over K = 2048 products), unlike the {0, +-1, 2, inf} set (4e-6).
 // The transposed convolution / data gradient is the exact adjoint  hi = In^T( U^T * Out^T(lo) ), the
 // weight gradient  dU_xi = Out^T(dlo)_xi * In(hi)_xi^T,  dw = G^T dU G.
-// Layouts: V[xi][c][t], c = (p*2+q)*Chi + h;  M[xi][l][t];  U[xi][l][c];  t = (n*Hlo/2 + ty)*Wlo/2 + tx.
+// Layouts: V[xi][c][t], c = (p*2+q)*Chi + h;  M[xi][l][t];  U[xi][l][c];  t = (n*Hlo/M + ty)*Wlo/M + tx.
 // All kernels are memory-bound streaming kernels: consecutive threads own consecutive tiles tx.
 #include "common.h"
 
@@ -20,150 +24,296 @@ using namespace wfae;
 
 namespace {
 
-// hi (N,Chi,2Hlo,2Wlo) -> V[9][4Chi][T]
+struct W22 {
+  static constexpr int N = 3, M = 2;
+  static constexpr float BT[3][3] = {{1, -1, 0}, {0, 1, 0}, {0, -1, 1}};
+  static constexpr float G[3][2] = {{1, 0}, {1, 1}, {0, 1}};
+  static constexpr float AT[2][3] = {{1, 1, 0}, {0, 1, 1}};
+};
+struct W42 {
+  static constexpr int N = 5, M = 4;
+  static constexpr float BT[5][5] = {{4, 0, -5, 0, 1}, {0, 4, 4, -1, -1}, {0, -4, 4, 1, -1}, {0, -2, -1, 2, 1}, {0, 2, -1, -2, 1}};
+  static constexpr float G[5][2] = {{0.25f, 0.f}, {1.f / 6, 1.f / 6}, {1.f / 6, -1.f / 6}, {1.f / 24, 1.f / 12}, {1.f / 24, -1.f / 12}};
+  static constexpr float AT[4][5] = {{1, 1, 1, 1, 1}, {0, 1, -1, 2, -2}, {0, 1, 1, 4, 4}, {0, 1, -1, 8, -8}};
+};
+
+// out[a][b] = sum_{i,j} L[a][i] * in[i][j] * L[b][j]   (L is RA x CA, compile-time, zeros skipped)
+template <int RA, int CA, typename Lm>
+__device__ __forceinline__ void sandwich(const float (&in)[CA][CA], float (&out)[RA][RA], Lm L) {
+  float tmp[RA][CA];
+#pragma unroll
+  for (int a = 0; a < RA; ++a)
+#pragma unroll
+    for (int j = 0; j < CA; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < CA; ++i)
+        if (L(a, i) != 0.f) s = fmaf(L(a, i), in[i][j], s);
+      tmp[a][j] = s;
+    }
+#pragma unroll
+  for (int a = 0; a < RA; ++a)
+#pragma unroll
+    for (int b = 0; b < RA; ++b) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < CA; ++j)
+        if (L(b, j) != 0.f) s = fmaf(L(b, j), tmp[a][j], s);
+      out[a][b] = s;
+    }
+}
+
+// hi (N,Chi,2Hlo,2Wlo) -> V[N*N][4Chi][T]
+template <typename WV>
 __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ hi, float* __restrict__ V, int Chi,
                                                       int Hlo, int Wlo, long T) {
-  const int TW = Wlo >> 1, TH = Hlo >> 1, Timg = TW * TH;
+  constexpr int N = WV::N, M = WV::M, PSZ = 2 * N;
+  const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
   const int tl = blockIdx.x * blockDim.x + threadIdx.x;
   if (tl >= Timg) return;
   const int h = blockIdx.y, n = blockIdx.z;
   const int ty = tl / TW, tx = tl - ty * TW;
   const int H = 2 * Hlo, W = 2 * Wlo;
   const float* __restrict__ src = hi + (long)(n * Chi + h) * H * W;
-  float d[6][6];
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    const int Y = 4 * ty - 1 + r;
-    const bool rok = Y >= 0 && Y < H;
-    const float* __restrict__ row = src + (long)(rok ? Y : 0) * W;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const int X = 4 * tx - 1 + c;
-      const bool ok = rok && X >= 0 && X < W;
-      const float v = row[ok ? X : 0];
-      d[r][c] = ok ? v : 0.f;
-    }
-  }
   const long t = (long)n * Timg + tl;
   const long xi_stride = 4L * Chi * T;
+  const int Y0 = 2 * M * ty - 1, X0 = 2 * M * tx - 1;
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+  for (int p = 0; p < 2; ++p) {
+    // the two phases (p, 0) and (p, 1) share their rows: load N rows of the 2N-wide patch once
+    float rowbuf[N][PSZ];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      float tr[3][3];
+    for (int i = 0; i < N; ++i) {
+      const int Y = Y0 + 2 * i + p;
+      const bool rok = Y >= 0 && Y < H;
+      const float* __restrict__ row = src + (long)(rok ? Y : 0) * W;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float d0 = d[p][2 * j + q], d1 = d[2 + p][2 * j + q], d2 = d[4 + p][2 * j + q];
-        tr[0][j] = d0 - d1;
-        tr[1][j] = d1;
-        tr[2][j] = d2 - d1;
-      }
-      float* __restrict__ dst = V + ((long)(p * 2 + q) * Chi + h) * T + t;
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        dst[(long)(3 * u + 0) * xi_stride] = tr[u][0] - tr[u][1];
-        dst[(long)(3 * u + 1) * xi_stride] = tr[u][1];
-        dst[(long)(3 * u + 2) * xi_stride] = tr[u][2] - tr[u][1];
+      for (int c = 0; c < PSZ; ++c) {
+        const int X = X0 + c;
+        const bool ok = rok && X >= 0 && X < W;
+        const float v = row[ok ? X : 0];
+        rowbuf[i][c] = ok ? v : 0.f;
       }
     }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float d[N][N], v[N][N];
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) d[i][j] = rowbuf[i][2 * j + q];
+      sandwich<N, N>(d, v, [](int a, int i) { return WV::BT[a][i]; });
+      float* __restrict__ dst = V + ((long)(p * 2 + q) * Chi + h) * T + t;
+#pragma unroll
+      for (int u = 0; u < N; ++u)
+#pragma unroll
+        for (int w = 0; w < N; ++w) dst[(long)(u * N + w) * xi_stride] = v[u][w];
+    }
+  }
 }
 
-// adjoint of wino_in: dV[9][4Chi][T] -> hi (N,Chi,2Hlo,2Wlo); every thread produces one 4x4 block of hi,
-// gathering the overlapping contributions of its own and the neighbouring tiles (no atomics).
+// adjoint of wino_in: dV[N*N][4Chi][T] -> hi (N,Chi,2Hlo,2Wlo).  Every thread produces one 2M x 2M block of hi:
+// the inverse transform E = B dV B^T of its own tile gives the interior, the rows/columns shared with the
+// neighbouring tiles (tile patches are 2N = 2M+2 wide at stride 2M) are gathered from them — no atomics.
+// hi row 2M*ty + r belongs to phase p = (r & 1) ^ 1 and phase-row i = (r + 1 - p) / 2 of tile ty; row r = 0 also is
+// phase-row M of tile ty-1, row r = 2M-1 also phase-row 0 of tile ty+1 (same for columns).
+template <typename WV>
 __global__ __launch_bounds__(256) void wino_in_t_kernel(const float* __restrict__ dV, float* __restrict__ hi, int Chi,
                                                         int Hlo, int Wlo, long T) {
-  const int TW = Wlo >> 1, TH = Hlo >> 1, Timg = TW * TH;
+  constexpr int N = WV::N, M = WV::M, BS = 2 * M;
+  const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
   const int tl = blockIdx.x * blockDim.x + threadIdx.x;
   if (tl >= Timg) return;
   const int h = blockIdx.y, n = blockIdx.z;
   const int ty = tl / TW, tx = tl - ty * TW;
   const int W = 2 * Wlo;
   const long xi_stride = 4L * Chi * T;
-  // hi row 4ty + r belongs to phase p = (r & 1) ^ 1 and receives tile rows:
-  //   r = 0: (ty, i=0), (ty-1, i=2)   r = 1: (ty, 1)   r = 2: (ty, 1)   r = 3: (ty, 2), (ty+1, 0)
-  constexpr int NCON[4] = {2, 1, 1, 2};
-  constexpr int CDT[4][2] = {{0, -1}, {0, 0}, {0, 0}, {0, 1}};
-  constexpr int CI[4][2] = {{0, 2}, {1, 1}, {1, 1}, {2, 0}};
-  // B = (B^T)^T rows: e[i][.] = sum_u Bm[i][u] dV[u][.]
-  constexpr float Bm[3][3] = {{1.f, 0.f, 0.f}, {-1.f, 1.f, -1.f}, {0.f, 0.f, 1.f}};
-  float* __restrict__ out = hi + ((long)(n * Chi + h) * (2 * Hlo) + 4 * ty) * W + 4 * tx;
+  float o[BS][BS];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int p = (r & 1) ^ 1;
-    float o[4];
+  for (int r = 0; r < BS; ++r)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int q = (c & 1) ^ 1;
-      float acc = 0.f;
+    for (int c = 0; c < BS; ++c) o[r][c] = 0.f;
+  auto Bm = [](int i, int u) { return WV::BT[u][i]; };   // B = (B^T)^T
+  // own tile: full inverse transform per phase
 #pragma unroll
-      for (int a = 0; a < NCON[r]; ++a) {
-        const int tyy = ty + CDT[r][a], i = CI[r][a];
-        if (tyy < 0 || tyy >= TH) continue;
+  for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int b = 0; b < NCON[c]; ++b) {
-          const int txx = tx + CDT[c][b], j = CI[c][b];
-          if (txx < 0 || txx >= TW) continue;
-          const float* __restrict__ base = dV + ((long)(p * 2 + q) * Chi + h) * T + (long)n * Timg + tyy * TW + txx;
+    for (int q = 0; q < 2; ++q) {
+      const float* __restrict__ base = dV + ((long)(p * 2 + q) * Chi + h) * T + (long)n * Timg + tl;
+      float dv[N][N], e[N][N];
 #pragma unroll
-          for (int u = 0; u < 3; ++u)
+      for (int u = 0; u < N; ++u)
 #pragma unroll
-            for (int v = 0; v < 3; ++v) {
-              const float cf = Bm[i][u] * Bm[j][v];
-              if (cf != 0.f) acc += cf * base[(long)(3 * u + v) * xi_stride];
-            }
+        for (int v = 0; v < N; ++v) dv[u][v] = base[(long)(u * N + v) * xi_stride];
+      sandwich<N, N>(dv, e, Bm);
+      // phase-row i lands on block row r = 2i - 1 + p (0 <= r < 2M), same for columns
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int r = 2 * i - 1 + p;
+        if (r < 0 || r >= BS) continue;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          const int c = 2 * j - 1 + q;
+          if (c < 0 || c >= BS) continue;
+          o[r][c] += e[i][j];
         }
       }
-      o[c] = acc;
     }
-    *reinterpret_cast<float4*>(out + (long)r * W) = make_float4(o[0], o[1], o[2], o[3]);
+  // neighbours.  A tile above contributes its phase-row M (row phase p = 1) to block row 0, a tile below its
+  // phase-row 0 (p = 0) to block row 2M-1; the same for columns with q.
+  auto base_of = [&](int p, int q, int tyy, int txx) -> const float* {
+    return dV + ((long)(p * 2 + q) * Chi + h) * T + (long)n * Timg + (long)tyy * TW + txx;
+  };
+  // vertical neighbours: one block row, all columns
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int tyy = s == 0 ? ty - 1 : ty + 1;
+    if (tyy < 0 || tyy >= TH) continue;
+    const int p = s == 0 ? 1 : 0, i = s == 0 ? M : 0, r = s == 0 ? 0 : BS - 1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float* __restrict__ base = base_of(p, q, tyy, tx);
+      float tv[N];
+#pragma unroll
+      for (int v = 0; v < N; ++v) {
+        float a = 0.f;
+#pragma unroll
+        for (int u = 0; u < N; ++u)
+          if (Bm(i, u) != 0.f) a = fmaf(Bm(i, u), base[(long)(u * N + v) * xi_stride], a);
+        tv[v] = a;
+      }
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const int c = 2 * j - 1 + q;
+        if (c < 0 || c >= BS) continue;
+        float a = 0.f;
+#pragma unroll
+        for (int v = 0; v < N; ++v)
+          if (Bm(j, v) != 0.f) a = fmaf(Bm(j, v), tv[v], a);
+        o[r][c] += a;
+      }
+    }
+  }
+  // horizontal neighbours: one block column, all rows
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int txx = s == 0 ? tx - 1 : tx + 1;
+    if (txx < 0 || txx >= TW) continue;
+    const int q = s == 0 ? 1 : 0, j = s == 0 ? M : 0, c = s == 0 ? 0 : BS - 1;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const float* __restrict__ base = base_of(p, q, ty, txx);
+      float tu[N];
+#pragma unroll
+      for (int u = 0; u < N; ++u) {
+        float a = 0.f;
+#pragma unroll
+        for (int v = 0; v < N; ++v)
+          if (Bm(j, v) != 0.f) a = fmaf(Bm(j, v), base[(long)(u * N + v) * xi_stride], a);
+        tu[u] = a;
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int r = 2 * i - 1 + p;
+        if (r < 0 || r >= BS) continue;
+        float a = 0.f;
+#pragma unroll
+        for (int u = 0; u < N; ++u)
+          if (Bm(i, u) != 0.f) a = fmaf(Bm(i, u), tu[u], a);
+        o[r][c] += a;
+      }
+    }
+  }
+  // corner neighbours: one element each
+#pragma unroll
+  for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+      const int tyy = sy == 0 ? ty - 1 : ty + 1, txx = sx == 0 ? tx - 1 : tx + 1;
+      if (tyy < 0 || tyy >= TH || txx < 0 || txx >= TW) continue;
+      const int p = sy == 0 ? 1 : 0, i = sy == 0 ? M : 0, r = sy == 0 ? 0 : BS - 1;
+      const int q = sx == 0 ? 1 : 0, j = sx == 0 ? M : 0, c = sx == 0 ? 0 : BS - 1;
+      const float* __restrict__ base = base_of(p, q, tyy, txx);
+      float a = 0.f;
+#pragma unroll
+      for (int u = 0; u < N; ++u) {
+        if (Bm(i, u) == 0.f) continue;
+#pragma unroll
+        for (int v = 0; v < N; ++v)
+          if (Bm(j, v) != 0.f) a = fmaf(Bm(i, u) * Bm(j, v), base[(long)(u * N + v) * xi_stride], a);
+      }
+      o[r][c] += a;
+    }
+  float* __restrict__ out = hi + ((long)(n * Chi + h) * (2 * Hlo) + BS * ty) * W + BS * tx;
+#pragma unroll
+  for (int r = 0; r < BS; ++r)
+#pragma unroll
+    for (int c4 = 0; c4 < BS; c4 += 4)
+      *reinterpret_cast<float4*>(out + (long)r * W + c4) = make_float4(o[r][c4], o[r][c4 + 1], o[r][c4 + 2], o[r][c4 + 3]);
+}
+
+// M[N*N][Clo][T] -> lo (N,Clo,Hlo,Wlo):  Y = A^T M A
+template <typename WV>
+__global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ Mx, float* __restrict__ lo, int Clo,
+                                                       int Hlo, int Wlo, long T) {
+  constexpr int N = WV::N, M = WV::M;
+  const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
+  const int tl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tl >= Timg) return;
+  const int l = blockIdx.y, n = blockIdx.z;
+  const int ty = tl / TW, tx = tl - ty * TW;
+  const long xi_stride = (long)Clo * T;
+  const float* __restrict__ src = Mx + (long)l * T + (long)n * Timg + tl;
+  float m[N][N], y[M][M];
+#pragma unroll
+  for (int u = 0; u < N; ++u)
+#pragma unroll
+    for (int v = 0; v < N; ++v) m[u][v] = src[(long)(u * N + v) * xi_stride];
+  sandwich<M, N>(m, y, [](int a, int i) { return WV::AT[a][i]; });
+  float* __restrict__ dst = lo + ((long)(n * Clo + l) * Hlo + M * ty) * Wlo + M * tx;
+#pragma unroll
+  for (int a = 0; a < M; ++a) {
+    if constexpr (M == 2) *reinterpret_cast<float2*>(dst + (long)a * Wlo) = make_float2(y[a][0], y[a][1]);
+    else *reinterpret_cast<float4*>(dst + (long)a * Wlo) = make_float4(y[a][0], y[a][1], y[a][2], y[a][3]);
   }
 }
 
-// M[9][Clo][T] -> lo (N,Clo,Hlo,Wlo):  Y = A^T M A
-__global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ M, float* __restrict__ lo, int Clo,
-                                                       int Hlo, int Wlo, long T) {
-  const int TW = Wlo >> 1, TH = Hlo >> 1, Timg = TW * TH;
-  const int tl = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tl >= Timg) return;
-  const int l = blockIdx.y, n = blockIdx.z;
-  const int ty = tl / TW, tx = tl - ty * TW;
-  const long xi_stride = (long)Clo * T;
-  const float* __restrict__ src = M + (long)l * T + (long)n * Timg + tl;
-  float m[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) m[k] = src[(long)k * xi_stride];
-  float* __restrict__ dst = lo + ((long)(n * Clo + l) * Hlo + 2 * ty) * Wlo + 2 * tx;
-  *reinterpret_cast<float2*>(dst) = make_float2((m[0] + m[1]) + (m[3] + m[4]), (m[1] + m[2]) + (m[4] + m[5]));
-  *reinterpret_cast<float2*>(dst + Wlo) = make_float2((m[3] + m[4]) + (m[6] + m[7]), (m[4] + m[5]) + (m[7] + m[8]));
-}
-
-// adjoint of wino_out: lo (N,Clo,Hlo,Wlo) -> Mt[9][Clo][T]:  Mt = A Y A^T
+// adjoint of wino_out: lo (N,Clo,Hlo,Wlo) -> Mt[N*N][Clo][T]:  Mt = A Y A^T
+template <typename WV>
 __global__ __launch_bounds__(256) void wino_out_t_kernel(const float* __restrict__ lo, float* __restrict__ Mt, int Clo,
                                                          int Hlo, int Wlo, long T) {
-  const int TW = Wlo >> 1, TH = Hlo >> 1, Timg = TW * TH;
+  constexpr int N = WV::N, M = WV::M;
+  const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
   const int tl = blockIdx.x * blockDim.x + threadIdx.x;
   if (tl >= Timg) return;
   const int l = blockIdx.y, n = blockIdx.z;
   const int ty = tl / TW, tx = tl - ty * TW;
-  const float* __restrict__ src = lo + ((long)(n * Clo + l) * Hlo + 2 * ty) * Wlo + 2 * tx;
-  const float2 y0 = *reinterpret_cast<const float2*>(src);
-  const float2 y1 = *reinterpret_cast<const float2*>(src + Wlo);
+  const float* __restrict__ src = lo + ((long)(n * Clo + l) * Hlo + M * ty) * Wlo + M * tx;
+  float y[M][M], m[N][N];
+#pragma unroll
+  for (int a = 0; a < M; ++a) {
+    if constexpr (M == 2) {
+      const float2 v = *reinterpret_cast<const float2*>(src + (long)a * Wlo);
+      y[a][0] = v.x; y[a][1] = v.y;
+    } else {
+      const float4 v = *reinterpret_cast<const float4*>(src + (long)a * Wlo);
+      y[a][0] = v.x; y[a][1] = v.y; y[a][2] = v.z; y[a][3] = v.w;
+    }
+  }
+  sandwich<N, M>(y, m, [](int u, int a) { return WV::AT[a][u]; });   // A = (A^T)^T
   const long xi_stride = (long)Clo * T;
   float* __restrict__ dst = Mt + (long)l * T + (long)n * Timg + tl;
-  dst[0 * xi_stride] = y0.x;
-  dst[1 * xi_stride] = y0.x + y0.y;
-  dst[2 * xi_stride] = y0.y;
-  dst[3 * xi_stride] = y0.x + y1.x;
-  dst[4 * xi_stride] = (y0.x + y0.y) + (y1.x + y1.y);
-  dst[5 * xi_stride] = y0.y + y1.y;
-  dst[6 * xi_stride] = y1.x;
-  dst[7 * xi_stride] = y1.x + y1.y;
-  dst[8 * xi_stride] = y1.y;
+#pragma unroll
+  for (int u = 0; u < N; ++u)
+#pragma unroll
+    for (int v = 0; v < N; ++v) dst[(long)(u * N + v) * xi_stride] = m[u][v];
 }
 
-// w (Clo,Chi,4,4) -> U[9][Clo][4Chi]:  U = G g G^T per phase, g[a][b] = w[2a+p][2b+q]
+// w (Clo,Chi,4,4) -> U[N*N][Clo][4Chi]:  U = G g G^T per phase, g[a][b] = w[2a+p][2b+q]
+template <typename WV>
 __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int Clo,
                                                            int Chi) {
+  constexpr int N = WV::N;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)Clo * Chi) return;
   const int h = (int)(i % Chi), l = (int)(i / Chi);
@@ -178,23 +328,25 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
   for (int p = 0; p < 2; ++p)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const float g00 = g[p * 4 + q], g01 = g[p * 4 + 2 + q], g10 = g[(2 + p) * 4 + q], g11 = g[(2 + p) * 4 + 2 + q];
+      float gg[2][2], u[N][N];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) gg[a][b] = g[(2 * a + p) * 4 + 2 * b + q];
+      sandwich<N, 2>(gg, u, [](int a, int i2) { return WV::G[a][i2]; });
       float* __restrict__ dst = U + (long)l * K4 + (long)(p * 2 + q) * Chi + h;
-      dst[0 * xi_stride] = g00;
-      dst[1 * xi_stride] = g00 + g01;
-      dst[2 * xi_stride] = g01;
-      dst[3 * xi_stride] = g00 + g10;
-      dst[4 * xi_stride] = (g00 + g01) + (g10 + g11);
-      dst[5 * xi_stride] = g01 + g11;
-      dst[6 * xi_stride] = g10;
-      dst[7 * xi_stride] = g10 + g11;
-      dst[8 * xi_stride] = g11;
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+#pragma unroll
+        for (int b = 0; b < N; ++b) dst[(long)(a * N + b) * xi_stride] = u[a][b];
     }
 }
 
-// dU[9][Clo][4Chi] -> dw (Clo,Chi,4,4) (+= when beta):  dg = G^T dU G per phase
+// dU[N*N][Clo][4Chi] -> dw (Clo,Chi,4,4) (+= when beta):  dg = G^T dU G per phase
+template <typename WV>
 __global__ __launch_bounds__(256) void wino_weights_t_kernel(const float* __restrict__ dU, float* __restrict__ dw,
                                                              int Clo, int Chi, int beta) {
+  constexpr int N = WV::N;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)Clo * Chi) return;
   const int h = (int)(i % Chi), l = (int)(i / Chi);
@@ -205,13 +357,16 @@ __global__ __launch_bounds__(256) void wino_weights_t_kernel(const float* __rest
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const float* __restrict__ src = dU + (long)l * K4 + (long)(p * 2 + q) * Chi + h;
-      float m[9];
+      float m[N][N], dg[2][2];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) m[k] = src[(long)k * xi_stride];
-      g[p * 4 + q] = (m[0] + m[1]) + (m[3] + m[4]);            // a = 0, b = 0
-      g[p * 4 + 2 + q] = (m[1] + m[2]) + (m[4] + m[5]);        // a = 0, b = 1
-      g[(2 + p) * 4 + q] = (m[3] + m[4]) + (m[6] + m[7]);      // a = 1, b = 0
-      g[(2 + p) * 4 + 2 + q] = (m[4] + m[5]) + (m[7] + m[8]);  // a = 1, b = 1
+      for (int a = 0; a < N; ++a)
+#pragma unroll
+        for (int b = 0; b < N; ++b) m[a][b] = src[(long)(a * N + b) * xi_stride];
+      sandwich<2, N>(m, dg, [](int a, int u) { return WV::G[u][a]; });   // G^T
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) g[(2 * a + p) * 4 + 2 * b + q] = dg[a][b];
     }
   float4* __restrict__ dst = reinterpret_cast<float4*>(dw + i * 16);
 #pragma unroll
@@ -225,38 +380,48 @@ __global__ __launch_bounds__(256) void wino_weights_t_kernel(const float* __rest
   }
 }
 
-inline dim3 tile_grid(int NB, int C, int Hlo, int Wlo) { return dim3(cdiv((long)(Hlo / 2) * (Wlo / 2), 256), C, NB); }
+inline dim3 tile_grid(int NB, int C, int Hlo, int Wlo, int M) { return dim3(cdiv((long)(Hlo / M) * (Wlo / M), 256), C, NB); }
 
 }  // namespace
 
 namespace wfae {
 
-int wino_in(const float* hi, float* V, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
-  const long T = (long)NB * (Hlo / 2) * (Wlo / 2);
-  hipLaunchKernelGGL(wino_in_kernel, tile_grid(NB, Chi, Hlo, Wlo), dim3(256), 0, st, hi, V, Chi, Hlo, Wlo, T);
+#define WFAE_WINO_DISPATCH(KERNEL, GRID, ...)                                                     \
+  do {                                                                                            \
+    if (variant == 0) hipLaunchKernelGGL((KERNEL<W22>), GRID, dim3(256), 0, st, __VA_ARGS__);     \
+    else hipLaunchKernelGGL((KERNEL<W42>), GRID, dim3(256), 0, st, __VA_ARGS__);                  \
+  } while (0)
+
+int wino_in(int variant, const float* hi, float* V, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
+  const int M = variant ? 4 : 2;
+  const long T = (long)NB * (Hlo / M) * (Wlo / M);
+  WFAE_WINO_DISPATCH(wino_in_kernel, tile_grid(NB, Chi, Hlo, Wlo, M), hi, V, Chi, Hlo, Wlo, T);
   return check_launch("wino_in");
 }
-int wino_in_t(const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
-  const long T = (long)NB * (Hlo / 2) * (Wlo / 2);
-  hipLaunchKernelGGL(wino_in_t_kernel, tile_grid(NB, Chi, Hlo, Wlo), dim3(256), 0, st, dV, hi, Chi, Hlo, Wlo, T);
+int wino_in_t(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
+  const int M = variant ? 4 : 2;
+  const long T = (long)NB * (Hlo / M) * (Wlo / M);
+  WFAE_WINO_DISPATCH(wino_in_t_kernel, tile_grid(NB, Chi, Hlo, Wlo, M), dV, hi, Chi, Hlo, Wlo, T);
   return check_launch("wino_in_t");
 }
-int wino_out(const float* M, float* lo, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
-  const long T = (long)NB * (Hlo / 2) * (Wlo / 2);
-  hipLaunchKernelGGL(wino_out_kernel, tile_grid(NB, Clo, Hlo, Wlo), dim3(256), 0, st, M, lo, Clo, Hlo, Wlo, T);
+int wino_out(int variant, const float* Mx, float* lo, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
+  const int M = variant ? 4 : 2;
+  const long T = (long)NB * (Hlo / M) * (Wlo / M);
+  WFAE_WINO_DISPATCH(wino_out_kernel, tile_grid(NB, Clo, Hlo, Wlo, M), Mx, lo, Clo, Hlo, Wlo, T);
   return check_launch("wino_out");
 }
-int wino_out_t(const float* lo, float* Mt, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
-  const long T = (long)NB * (Hlo / 2) * (Wlo / 2);
-  hipLaunchKernelGGL(wino_out_t_kernel, tile_grid(NB, Clo, Hlo, Wlo), dim3(256), 0, st, lo, Mt, Clo, Hlo, Wlo, T);
+int wino_out_t(int variant, const float* lo, float* Mt, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
+  const int M = variant ? 4 : 2;
+  const long T = (long)NB * (Hlo / M) * (Wlo / M);
+  WFAE_WINO_DISPATCH(wino_out_t_kernel, tile_grid(NB, Clo, Hlo, Wlo, M), lo, Mt, Clo, Hlo, Wlo, T);
   return check_launch("wino_out_t");
 }
-int wino_weights(const float* w, float* U, int Clo, int Chi, hipStream_t st) {
-  hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv((long)Clo * Chi, 256)), dim3(256), 0, st, w, U, Clo, Chi);
+int wino_weights(int variant, const float* w, float* U, int Clo, int Chi, hipStream_t st) {
+  WFAE_WINO_DISPATCH(wino_weights_kernel, dim3(cdiv((long)Clo * Chi, 256)), w, U, Clo, Chi);
   return check_launch("wino_weights");
 }
-int wino_weights_t(const float* dU, float* dw, int Clo, int Chi, int beta, hipStream_t st) {
-  hipLaunchKernelGGL(wino_weights_t_kernel, dim3(cdiv((long)Clo * Chi, 256)), dim3(256), 0, st, dU, dw, Clo, Chi, beta);
+int wino_weights_t(int variant, const float* dU, float* dw, int Clo, int Chi, int beta, hipStream_t st) {
+  WFAE_WINO_DISPATCH(wino_weights_t_kernel, dim3(cdiv((long)Clo * Chi, 256)), dU, dw, Clo, Chi, beta);
   return check_launch("wino_weights_t");
 }
 

@@ -139,22 +139,23 @@ def linear_bwd_weight(dy, x, dw, accumulate=False):
 
 
 # ------------------------------------------------------ 4x4 stride-2 family
-# Winograd F(2x2,2x2) form of the 4x4 stride-2 operations (csrc/wino.hip, include/wfae.h): 9/16 of the
-# multiplies, paid for with streaming transforms of the operands.  WFAE_WINO = 0 never, 1 / unset: whenever
-# the geometry allows and both channel counts are >= 16 (measured, tools/kbench.py: every GEMM-class layer of
-# the model gains, 1.2x at 128ch@384^2 up to 1.6x at 1024ch@48^2).
+# Winograd forms of the 4x4 stride-2 operations (csrc/wino.hip, include/wfae.h): F(2x2,2x2) (9/16 of the
+# multiplies) or F(4x4,2x2) (25/64), paid for with streaming transforms of the operands.
+# WFAE_WINO = 0: never; f22 / f42: that variant whenever the geometry allows; unset / auto: F(4x4,2x2) when Hlo, Wlo
+# are multiples of 4, else F(2x2,2x2), for layers with both channel counts >= 16 (measured, tools/kbench.py: every
+# GEMM-class layer of the model gains).
 _WINO_MODE = os.environ.get("WFAE_WINO", "auto")
 _plans = {}
 
 
 def set_winograd(mode):
-    """'auto' | True | False — overrides WFAE_WINO (A/B tests, parity tests)"""
+    """'auto' | 'f22' | 'f42' | True (= auto without the channel threshold) | False — overrides WFAE_WINO"""
     global _WINO_MODE
-    _WINO_MODE = "auto" if mode == "auto" else ("1" if mode else "0")
+    _WINO_MODE = mode if isinstance(mode, str) else ("1" if mode else "0")
 
 
 class WinoPlan:
-    __slots__ = ("nb", "chi", "clo", "hlo", "wlo", "T", "nU", "nV", "nM")
+    __slots__ = ("variant", "nb", "chi", "clo", "hlo", "wlo", "T", "nU", "nV", "nM")
 
     @property
     def dims(self):
@@ -162,27 +163,41 @@ class WinoPlan:
 
     @property
     def gemm_flops(self):
-        return 18 * self.nb * self.hlo * self.wlo * self.clo * self.chi
+        per = 12.5 if self.variant else 18.0
+        return per * self.nb * self.hlo * self.wlo * self.clo * self.chi
+
+
+def _query_plan(variant, key):
+    import ctypes
+    out = (ctypes.c_int64 * 4)()
+    rc = _lib.load().wfae_wino_sizes(variant, *key, ctypes.cast(out, ctypes.c_void_p))
+    if rc != 0:
+        return None
+    pl = WinoPlan()
+    pl.variant = variant
+    pl.nb, pl.chi, pl.clo, pl.hlo, pl.wlo = key
+    pl.T, pl.nU, pl.nV, pl.nM = (int(v) for v in out)
+    return pl
 
 
 def wino_plan(nb, chi, clo, hlo, wlo):
-    """WinoPlan when the Winograd form should run for this layer geometry, else None"""
-    if _WINO_MODE == "0":
+    """WinoPlan when a Winograd form should run for this layer geometry, else None"""
+    mode = _WINO_MODE
+    if mode == "0":
+        return None
+    if mode == "auto" and min(chi, clo) < 16:
         return None
     key = (nb, chi, clo, hlo, wlo)
-    pl = _plans.get(key, False)
+    ck = (mode if mode in ("f22", "f42") else "a", key)
+    pl = _plans.get(ck, False)
     if pl is False:
-        import ctypes
-        out = (ctypes.c_int64 * 4)()
-        rc = _lib.load().wfae_wino_sizes(nb, chi, clo, hlo, wlo, ctypes.cast(out, ctypes.c_void_p))
-        pl = None
-        if rc == 0:
-            pl = WinoPlan()
-            pl.nb, pl.chi, pl.clo, pl.hlo, pl.wlo = key
-            pl.T, pl.nU, pl.nV, pl.nM = (int(v) for v in out)
-        _plans[key] = pl
-    if pl is not None and _WINO_MODE == "auto" and min(chi, clo) < 16:
-        return None
+        if mode == "f22":
+            pl = _query_plan(0, key)
+        elif mode == "f42":
+            pl = _query_plan(1, key)
+        else:
+            pl = _query_plan(1, key) or _query_plan(0, key)
+        _plans[ck] = pl
     return pl
 
 
@@ -193,23 +208,23 @@ def _buf(n, like):
 def wino_weights(w, pl):
     _chk(w)
     U = _buf(pl.nU, w)
-    _call("wfae_wino_weights", 0, 4 * (w.numel() + pl.nU), _p(w), _p(U), pl.chi, pl.clo, _stream())
+    _call("wfae_wino_weights", 0, 4 * (w.numel() + pl.nU), pl.variant, _p(w), _p(U), pl.chi, pl.clo, _stream())
     return U
 
 
 def wino_in(hi, pl):
-    """hi-side tensor (N,Chi,2Hlo,2Wlo) -> V[9][4Chi][T]"""
+    """hi-side tensor (N,Chi,2Hlo,2Wlo) -> V[xi][4Chi][T]"""
     _chk(hi)
     V = _buf(pl.nV, hi)
-    _call("wfae_wino_in", 0, 4 * (hi.numel() + pl.nV), _p(hi), _p(V), pl.nb, pl.chi, pl.hlo, pl.wlo, _stream())
+    _call("wfae_wino_in", 0, 4 * (hi.numel() + pl.nV), pl.variant, _p(hi), _p(V), pl.nb, pl.chi, pl.hlo, pl.wlo, _stream())
     return V
 
 
 def wino_out_t(lo, pl):
-    """lo-side tensor (N,Clo,Hlo,Wlo) -> Mt[9][Clo][T]"""
+    """lo-side tensor (N,Clo,Hlo,Wlo) -> Mt[xi][Clo][T]"""
     _chk(lo)
     Mt = _buf(pl.nM, lo)
-    _call("wfae_wino_out_t", 0, 4 * (lo.numel() + pl.nM), _p(lo), _p(Mt), pl.nb, pl.clo, pl.hlo, pl.wlo, _stream())
+    _call("wfae_wino_out_t", 0, 4 * (lo.numel() + pl.nM), pl.variant, _p(lo), _p(Mt), pl.nb, pl.clo, pl.hlo, pl.wlo, _stream())
     return Mt
 
 
@@ -217,8 +232,8 @@ def wino_down(U, V, pl):
     """lo = Out(U * V)"""
     M = _buf(pl.nM, V)
     lo = torch.empty((pl.nb, pl.clo, pl.hlo, pl.wlo), dtype=torch.float32, device=V.device)
-    _call("wfae_wino_gemm_down", pl.gemm_flops, 4 * (pl.nU + pl.nV + pl.nM), _p(U), _p(V), _p(M), *pl.dims, _stream())
-    _call("wfae_wino_out", 0, 4 * (pl.nM + lo.numel()), _p(M), _p(lo), pl.nb, pl.clo, pl.hlo, pl.wlo, _stream())
+    _call("wfae_wino_gemm_down", pl.gemm_flops, 4 * (pl.nU + pl.nV + pl.nM), pl.variant, _p(U), _p(V), _p(M), *pl.dims, _stream())
+    _call("wfae_wino_out", 0, 4 * (pl.nM + lo.numel()), pl.variant, _p(M), _p(lo), pl.nb, pl.clo, pl.hlo, pl.wlo, _stream())
     return lo
 
 
@@ -226,8 +241,8 @@ def wino_up(U, Mt, pl):
     """hi = In^T(U^T * Mt)"""
     dV = _buf(pl.nV, Mt)
     hi = torch.empty((pl.nb, pl.chi, 2 * pl.hlo, 2 * pl.wlo), dtype=torch.float32, device=Mt.device)
-    _call("wfae_wino_gemm_up", pl.gemm_flops, 4 * (pl.nU + pl.nV + pl.nM), _p(U), _p(Mt), _p(dV), *pl.dims, _stream())
-    _call("wfae_wino_in_t", 0, 4 * (pl.nV + hi.numel()), _p(dV), _p(hi), pl.nb, pl.chi, pl.hlo, pl.wlo, _stream())
+    _call("wfae_wino_gemm_up", pl.gemm_flops, 4 * (pl.nU + pl.nV + pl.nM), pl.variant, _p(U), _p(Mt), _p(dV), *pl.dims, _stream())
+    _call("wfae_wino_in_t", 0, 4 * (pl.nV + hi.numel()), pl.variant, _p(dV), _p(hi), pl.nb, pl.chi, pl.hlo, pl.wlo, _stream())
     return hi
 
 
@@ -235,7 +250,7 @@ def wino_wgrad(Mt, V, dw, pl, accumulate=False):
     """dw (Clo,Chi,4,4) (+)= G^T (Mt * V^T) G"""
     _chk(dw)
     ws = workspace(pl.nU * 4 * 6)
-    _call("wfae_wino_gemm_wgrad", pl.gemm_flops, 4 * (pl.nU + pl.nV + pl.nM), _p(Mt), _p(V), _p(dw), *pl.dims,
+    _call("wfae_wino_gemm_wgrad", pl.gemm_flops, 4 * (pl.nU + pl.nV + pl.nM), pl.variant, _p(Mt), _p(V), _p(dw), *pl.dims,
           int(accumulate), ws.data_ptr(), ws.numel(), _stream())
     return dw
 

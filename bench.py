@@ -41,6 +41,9 @@ PEAK_FP32 = 157.3e12            # MI355X_MICROARCH.md: fp32 vector = fp32 matrix
 PEAK_HBM = 8.0e12
 
 KERNEL_OF = {
+    "wfae_bn_act_bwd[dx]": "bn_act_bwd_dx_kernel<GELU> (BatchNorm + GELU backward: dx from dy, x (+ residual-branch gradient), "
+                           "HBM-bound streaming kernel)",
+    "wfae_bn_act_bwd[reduce]": "bn_act_bwd_reduce_kernel<GELU> (per-channel sums of dU and dU*xhat, fp64 accumulation)",
     "wfae_wino_gemm_wgrad": "gemm_kernel<256,2,2,A_KCONTIG,B_KCONTIG,E_SLAB> (Winograd-domain weight-gradient GEMMs "
                             "dU_xi = Mt_xi V_xi^T of the 4x4 s2 convs, 9 per launch, split-K, fp32 MFMA)",
     "wfae_wino_gemm_down": "gemm_kernel<256,2,2,A_KCONTIG,B_NCONTIG,E_BATCHED> (Winograd-domain GEMMs M_xi = U_xi V_xi, "

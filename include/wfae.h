@@ -129,6 +129,8 @@ int wfae_gconv3x3_bwd_weight(const float* dy, const float* x, float* dw, int NB,
  *   running_mean/var (unbiased var, momentum) in place.
  * bn_fold_eval: scale/shift from running statistics (module.eval()).
  * bn_act_fwd: y = act(x*scale[c] + shift[c]); act 0 = identity, 1 = exact GELU, 2 = LeakyReLU(0.2).
+ * bn_act_bwd phases: 1 = per-channel reductions (+ dgamma/dbeta and the coefficients kept at the head of ws),
+ *   2 = the dx kernel (reads those coefficients: same ws, no other call in between), 3 = both.
  * bn_act_bwd: given dy = dL/dy, x and the saved statistics, computes
  *   dgamma, dbeta and dx (+ res, the residual-branch gradient of
  *   Bottleneck, :22).  training=0 uses the eval-mode formula. */
@@ -144,7 +146,7 @@ int wfae_bn_act_fwd(const float* x, const float* scale, const float* shift, floa
 int wfae_bn_act_bwd(const float* dy, const float* x, const float* gamma, const float* scale,
                     const float* shift, const float* save_mean, const float* save_invstd,
                     const float* res, float* dx, float* dgamma, float* dbeta, int NB, int C, int HW,
-                    int act, int training, int accumulate, void* ws, size_t ws_bytes,
+                    int act, int training, int accumulate, int phases, void* ws, size_t ws_bytes,
                     wfae_stream_t stream);
 
 /* ---- element-wise / reductions -------------------------------------------- */

@@ -60,14 +60,22 @@ for ep, sig in fam.items():
         out[ep] = {"hbm_bytes_per_launch": (2 * fs + ws) / n * 1024, "fetch_raw_KiB": fs / n, "write_KiB": ws / n, "launches": n,
                    "source": f"profiles/{tag}_pmc_hbm_traffic_per_kernel.csv"}
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
-# dominant kernel = top row (by total time) of the kernel-trace stats; map its template signature to the entry point
+# dominant kernel = top row (by total time) of the kernel-trace stats; map it to the entry point / label that bench.py
+# times with events, and record its PMC traffic under that label
 rows = list(csv.DictReader(open(f"profiles/{tag}_bench_b32_384_kernel_stats.csv")))
 top = rows[0]
 ep = next((e for e, sig in fam.items() if "gemm_kernel<" in top["Name"] and sig in top["Name"]), None)
 if ep is None:
-    for key, e in (("bn_act_bwd", "wfae_bn_act_bwd"), ("bn_act_fwd", "wfae_bn_act_fwd")):
+    for key, e in (("bn_act_bwd_dx_kernel", "wfae_bn_act_bwd[dx]"), ("bn_act_bwd_reduce_kernel", "wfae_bn_act_bwd[reduce]"),
+                   ("bn_act_fwd_kernel", "wfae_bn_act_fwd"), ("chan_reduce_kernel", "wfae_bn_stats_train")):
         if key in top["Name"]:
             ep = e
+if ep is not None and ep not in out and top["Name"] in F:
+    n, fs = F[top["Name"]]
+    ws_ = W.get(top["Name"], [n, 0])[1]
+    out[ep] = {"hbm_bytes_per_launch": (2 * fs + ws_) / n * 1024, "fetch_raw_KiB": fs / n, "write_KiB": ws_ / n, "launches": n,
+               "source": f"profiles/{tag}_pmc_hbm_traffic_per_kernel.csv"}
+    json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 json.dump({"kernel": top["Name"], "entry_point": ep, "calls": int(top["Calls"]), "avg_ns": float(top["AverageNs"]),
            "source": f"profiles/{tag}_bench_b32_384_kernel_stats.csv"}, open("profiles/dominant_kernel.json", "w"), indent=1)
-print(json.dumps(out, indent=1))
+print(open("profiles/dominant_kernel.json").read())

@@ -577,10 +577,11 @@ int wfae_bn_act_fwd(const float* x, const float* scale, const float* shift, floa
 int wfae_bn_act_bwd(const float* dy, const float* x, const float* gamma, const float* scale,
                     const float* shift, const float* save_mean, const float* save_invstd,
                     const float* res, float* dx, float* dgamma, float* dbeta, int NB, int C, int HW,
-                    int act, int training, int accumulate, void* ws, size_t ws_bytes,
+                    int act, int training, int accumulate, int phases, void* ws, size_t ws_bytes,
                     wfae_stream_t stream) {
   WFAE_REQUIRE(dy && x && gamma && scale && shift && save_mean && save_invstd, WFAE_ERR_NULL_POINTER,
                "bn_act_bwd: null pointer");
+  WFAE_REQUIRE(phases >= 1 && phases <= 3, WFAE_ERR_BAD_SHAPE, "bn_act_bwd: phases must be 1, 2 or 3");
   WFAE_REQUIRE(NB > 0 && C > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "bn_act_bwd: bad shape");
   // workspace: coef[2C] floats (16-byte aligned) followed by fp64 partials
   const size_t coef_bytes = ((size_t)2 * C * sizeof(float) + 15) / 16 * 16;
@@ -593,6 +594,8 @@ int wfae_bn_act_bwd(const float* dy, const float* x, const float* gamma, const f
   const int vec = (HW % 4 == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) |
                                       reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(res)) & 15) == 0);
   hipStream_t st = (hipStream_t)stream;
+  int rc = WFAE_OK;
+  if (phases & 1) {
   if (act == 1)
     hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<1>), dim3(C, g.splits), dim3(RT), 0, st, dy, x, scale, shift,
                        save_mean, save_invstd, part, g, vec);
@@ -602,13 +605,14 @@ int wfae_bn_act_bwd(const float* dy, const float* x, const float* gamma, const f
   else
     hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<0>), dim3(C, g.splits), dim3(RT), 0, st, dy, x, scale, shift,
                        save_mean, save_invstd, part, g, vec);
-  int rc = check_launch("bn_act_bwd_reduce");
+  rc = check_launch("bn_act_bwd_reduce");
   if (rc) return rc;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, g.splits,
                      C, dgamma, dbeta, coef, accumulate);
   rc = check_launch("bn_bwd_finalize");
   if (rc) return rc;
-  if (dx) {
+  }
+  if ((phases & 2) && dx) {
     int gy = cdiv(vec ? HW / 4 : HW, 256 * 4);
     if (gy < 1) gy = 1;
     if (gy > 1024) gy = 1024;

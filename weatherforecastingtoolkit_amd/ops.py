@@ -42,14 +42,14 @@ def profile_stop():
     return out
 
 
-def _call(name, flops, nbytes, *args):
+def _call(name, flops, nbytes, *args, label=None):
     if _prof is None:
         return _lib.call(name, *args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     _lib.call(name, *args)
     e1.record()
-    _prof.setdefault(name, []).append((e0, e1, flops, nbytes))
+    _prof.setdefault(label or name, []).append((e0, e1, flops, nbytes))
 
 
 def workspace(min_bytes: int = 0):
@@ -427,9 +427,16 @@ def bn_act_bwd(dy, x, gamma, st, dgamma, dbeta, res=None, act=1, training=True, 
     nb, c, h, wd = x.shape
     dx = torch.empty_like(x) if need_dx else None
     ws = workspace()
-    _call("wfae_bn_act_bwd", 0, 4 * x.numel() * (6 if res is not None else 5), _p(dy), _p(x), _p(gamma), _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd),
-              _p(res), _p(dx), _p(dgamma), _p(dbeta), nb, c, h * wd, act, int(training), int(accumulate),
-              ws.data_ptr(), ws.numel(), _stream())
+    args = (_p(dy), _p(x), _p(gamma), _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd), _p(res), _p(dx), _p(dgamma),
+            _p(dbeta), nb, c, h * wd, act, int(training), int(accumulate))
+    tail = (ws.data_ptr(), ws.numel(), _stream())
+    n = x.numel()
+    if _prof is None or not need_dx:
+        _call("wfae_bn_act_bwd", 0, 4 * n * (6 if res is not None else 5), *args, 3 if need_dx else 1, *tail)
+    else:
+        # kernel-granular timing for the roofline read-out: the two kernels of this entry point separately
+        _call("wfae_bn_act_bwd", 0, 8 * n, *args, 1, *tail, label="wfae_bn_act_bwd[reduce]")
+        _call("wfae_bn_act_bwd", 0, 4 * n * (4 if res is not None else 3), *args, 2, *tail, label="wfae_bn_act_bwd[dx]")
     return dx
 
 

@@ -483,6 +483,24 @@ extern "C" int wfae_gconv3x3_fwd(const float* x, const float* w, float* y, int N
   int rc = check_launch("gconv3_pack");
   if (rc) return rc;
   const float* wp = (const float*)ws;
+  // rows per thread: measured 1 < 2 < 4 in time (the kernel is latency-bound: smaller LDS tiles, more blocks per CU)
+  static const int py_big = getenv("WFAE_G3_PY") ? atoi(getenv("WFAE_G3_PY")) : 1;
+  if (py_big == 1) {
+    switch (cpg) {
+      case 4: return launch_gconv3<4, 1>(x, wp, y, NB, C, H, W, st);
+      case 8: return launch_gconv3<8, 1>(x, wp, y, NB, C, H, W, st);
+      case 16: return launch_gconv3<16, 1>(x, wp, y, NB, C, H, W, st);
+      default: return launch_gconv3<32, 1>(x, wp, y, NB, C, H, W, st);
+    }
+  }
+  if (py_big == 4) {
+    switch (cpg) {
+      case 4: return launch_gconv3<4, 4>(x, wp, y, NB, C, H, W, st);
+      case 8: return launch_gconv3<8, 4>(x, wp, y, NB, C, H, W, st);
+      case 16: return launch_gconv3<16, 4>(x, wp, y, NB, C, H, W, st);
+      default: return launch_gconv3<32, 2>(x, wp, y, NB, C, H, W, st);
+    }
+  }
   switch (cpg) {
     case 4: return launch_gconv3<4, 2>(x, wp, y, NB, C, H, W, st);
     case 8: return launch_gconv3<8, 2>(x, wp, y, NB, C, H, W, st);
@@ -501,10 +519,10 @@ extern "C" int wfae_gconv3x3_fwd(const float* x, const float* w, float* y, int N
 namespace {
 
 template <int CPG, int OCW>
-__global__ __launch_bounds__(256, 2) void gconv3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(256, (OCW * CPG * 9 <= 72 ? 4 : 2)) void gconv3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                               float* __restrict__ part, int NB, int C, int H, int W,
                                                               int tiles_x, int tiles_y, int parts) {
-  static_assert(OCW * CPG * 9 == 144, "144 accumulators per lane");
+  static_assert(OCW * CPG * 9 <= 144, "at most 144 accumulators per lane");
   constexpr int TH = 8, TW = 64, IH = TH + 2, IWU = TW + 2, IW = 68;
   constexpr int Q = CPG / OCW;                 // work units per group
   constexpr int GPB = Q >= 4 ? 1 : 4 / Q;      // groups per block (4 waves = 4 units)
@@ -586,10 +604,13 @@ int gconv3_wgrad_valu(const float* dy, const float* x, float* dw, int NB, int C,
   if (!(cpg == 4 || cpg == 8 || cpg == 16)) return WFAE_ERR_UNSUPPORTED;
   {
     static const char* e = getenv("WFAE_G3_MFMA_MIN_CPG");   // A/B: channels per group from which the MFMA path is used
-    const int mfma_from = e ? atoi(e) : 32;
+    const int mfma_from = e ? atoi(e) : 16;   // measured: 16 ch/group 0.55 ms on the MFMA path vs 1.3 ms here
     if (cpg >= mfma_from) return WFAE_ERR_UNSUPPORTED;
   }
-  const int ocw = 144 / (cpg * 9);
+  // output channels per wave: 4 ch/group runs 1.4x faster with 72 accumulators per lane (twice the occupancy),
+  // 8 ch/group is faster with 144 (it would re-read x twice as often otherwise)
+  int ocw = 144 / (cpg * 9);
+  if (cpg == 4) ocw = 2;
   const int units = groups * (cpg / ocw);
   if (units % 4 != 0) return WFAE_ERR_UNSUPPORTED;
   if (cpg == 4 && groups % 4 != 0) return WFAE_ERR_UNSUPPORTED;
@@ -605,7 +626,11 @@ int gconv3_wgrad_valu(const float* dy, const float* x, float* dw, int NB, int C,
     return fail(WFAE_ERR_WORKSPACE, "gconv3x3_bwd_weight: workspace %zu too small", ws_bytes);
   dim3 grid((unsigned)parts, gy), block(256);
   float* part = (float*)ws;
-  if (cpg == 4)
+  if (cpg == 4 && ocw == 2)
+    hipLaunchKernelGGL((gconv3_wgrad_kernel<4, 2>), grid, block, 0, st, dy, x, part, NB, C, H, W, tiles_x, tiles_y, (int)parts);
+  else if (cpg == 8 && ocw == 1)
+    hipLaunchKernelGGL((gconv3_wgrad_kernel<8, 1>), grid, block, 0, st, dy, x, part, NB, C, H, W, tiles_x, tiles_y, (int)parts);
+  else if (cpg == 4)
     hipLaunchKernelGGL((gconv3_wgrad_kernel<4, 4>), grid, block, 0, st, dy, x, part, NB, C, H, W, tiles_x, tiles_y, (int)parts);
   else if (cpg == 8)
     hipLaunchKernelGGL((gconv3_wgrad_kernel<8, 2>), grid, block, 0, st, dy, x, part, NB, C, H, W, tiles_x, tiles_y, (int)parts);

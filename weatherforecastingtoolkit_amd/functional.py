@@ -469,8 +469,8 @@ def _g3_dgrad(dy, w, cin, groups):
 def _g3_wgrad(dy, x, dw, groups):
     c = x.shape[1]
     # measured (tools/kbench.py): pixel-parallel VALU kernel wins at 4 and 8 channels/group, the per-group
-    # MFMA implicit GEMM at 32, the output-stationary direct kernel at 16
-    if c % groups == 0 and c // groups in (4, 8, 32) and dw.shape[0] == c and groups > 1:
+    # MFMA implicit GEMM at 16 and 32 (the library picks between the two)
+    if c % groups == 0 and c // groups in (4, 8, 16, 32) and dw.shape[0] == c and groups > 1:
         return ops.gconv3x3_bwd_weight(dy, x, dw, groups)
     return ops.dconv_bwd_weight(dy, x, dw, 3, 1, 1, groups)
 

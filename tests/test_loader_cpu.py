@@ -1,0 +1,97 @@
+"""Real-data side of the loader: catalog filtering, event stores, batch composition.
+Reference: pipeline/datasets/sevire/sevir.py:316-389 (filters, samples), :455-482 (event read), :979-1003 (batches)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from weatherforecastingtoolkit_amd.pipeline.datasets.sevire.catalog import (CatalogEventStore, H5EventSource, NpyEventSource,
+                                                                       SEVIRCatalog)
+from weatherforecastingtoolkit_amd.pipeline.datasets.sevire.sevir import SEVIRFrameLoader
+
+
+def _make_dataset(tmp_path, n_files=2, per_file=5, size=16, frames=9):
+    rng = np.random.default_rng(0)
+    rows = []
+    arrays = {}
+    t0 = pd.Timestamp("2019-05-28")
+    k = 0
+    for f in range(n_files):
+        fname = f"vil/2019/SEVIR_VIL_{f}.h5"
+        arr = rng.integers(0, 256, size=(per_file, size, size, frames), dtype=np.uint8)
+        (tmp_path / "vil" / "2019").mkdir(parents=True, exist_ok=True)
+        np.save(tmp_path / "vil" / "2019" / f"SEVIR_VIL_{f}.npy", arr)
+        arrays[fname] = arr
+        for i in range(per_file):
+            rows.append(dict(id=f"S{800 - k:04d}", img_type="vil", file_name=fname, file_index=i,
+                             time_utc=t0 + pd.Timedelta(days=k), pct_missing=0.0 if k % 4 else 0.1))
+            rows.append(dict(id=f"S{800 - k:04d}", img_type="ir069", file_name="ir/x.h5", file_index=i,
+                             time_utc=t0 + pd.Timedelta(days=k), pct_missing=0.0))
+            k += 1
+    # a duplicated vil id (the SEVIR catalog bug the reference drops, :356-358)
+    rows.append(dict(id="S0797", img_type="vil", file_name="vil/2019/SEVIR_VIL_0.h5", file_index=3,
+                     time_utc=t0 + pd.Timedelta(days=3), pct_missing=0.0))
+    return pd.DataFrame(rows), arrays
+
+
+def _reference_samples(cat, start=None, end=None):
+    """the filter chain of the reference written out directly for data_types=['vil']"""
+    c = cat
+    if start is not None:
+        c = c[c.time_utc > start]
+    if end is not None:
+        c = c[c.time_utc <= end]
+    c = c[c.pct_missing == 0]
+    c = c[c.img_type == "vil"]
+    c = c.groupby("id").filter(lambda x: x.shape[0] == 1)
+    return [(r.id, r.file_name, r.file_index) for r in c.sort_values("id").itertuples()]
+
+
+def test_catalog_filters_match_reference_chain(tmp_path):
+    cat, _ = _make_dataset(tmp_path)
+    for start, end in [(None, None), (pd.Timestamp("2019-05-30"), pd.Timestamp("2019-06-04")), (None, pd.Timestamp("2019-06-01"))]:
+        sc = SEVIRCatalog(cat, start_date=start, end_date=end)
+        got = [(r.id, r.vil_filename, r.vil_index) for r in sc.samples.itertuples()]
+        assert got == _reference_samples(cat, start, end)
+        assert all(i != "S0797" for i, _, _ in got)           # the duplicated id is gone
+    sc = SEVIRCatalog(cat, catalog_filter=None, datetime_filter=lambda t: t.dt.day % 2 == 0)
+    assert len(sc) > 0 and all(pd.Timestamp(cat[cat.id == i].time_utc.iloc[0]).day % 2 == 0 for i in sc.samples.id)
+    a = SEVIRCatalog(cat, shuffle=True, shuffle_seed=1).samples.id.tolist()
+    b = SEVIRCatalog(cat, shuffle=True, shuffle_seed=1).samples.id.tolist()
+    assert a == b and a != sorted(a) and sorted(a) == sorted(SEVIRCatalog(cat).samples.id.tolist())
+
+
+def test_event_store_and_batches(tmp_path):
+    cat, arrays = _make_dataset(tmp_path)
+    sc = SEVIRCatalog(cat)
+    store = CatalogEventStore(sc, NpyEventSource(str(tmp_path)))
+    assert store.event_shape == (16, 16, 9) and len(store) == len(sc)
+    for e in (0, len(store) - 1):
+        row = sc.samples.iloc[e]
+        assert np.array_equal(store.read(e), arrays[row.vil_filename][row.vil_index])
+    # the loader over the store composes batches exactly like the loader over the same events held in memory
+    events = np.stack([store.read(e) for e in range(len(store))], 0)
+    for seq_len, stride, bs, shards in [(1, 1, 4, 1), (3, 2, 5, 1), (1, 1, 3, 2)]:
+        for rank in range(shards):
+            a = SEVIRFrameLoader(store, bs, seq_len, stride, num_shard=shards, rank=rank)
+            b = SEVIRFrameLoader(events, bs, seq_len, stride, num_shard=shards, rank=rank)
+            assert len(a) == len(b) > 0
+            for i in range(len(a)):
+                assert np.array_equal(a.batch_u8(i), b.batch_u8(i))
+    # batch composition: consecutive (event, sequence) pairs (reference _idx_sample :992-1003)
+    ld = SEVIRFrameLoader(store, 4, seq_len=3, stride=2)
+    nspe = ld.num_seq_per_event
+    assert nspe == 1 + (9 - 3) // 2
+    flat = [(e, s) for i in range(len(ld)) for e, s in ld.sample_indices(i)]
+    assert flat == [(k // nspe, k % nspe) for k in range(len(flat))]
+    e, s = flat[5]
+    assert np.array_equal(ld.batch_u8(1)[1], events[e][:, :, s * 2:s * 2 + 3])
+
+
+def test_h5_source_fails_loudly_without_h5py(tmp_path):
+    try:
+        import h5py  # noqa: F401
+        pytest.skip("h5py is installed")
+    except ImportError:
+        pass
+    with pytest.raises(RuntimeError, match="h5py"):
+        H5EventSource(str(tmp_path))

@@ -61,6 +61,8 @@ def main(argv=None):
     ap.add_argument("--resume", type=bool, default=False)
     ap.add_argument("--config", default=os.path.join(HERE, "config.yaml"))
     ap.add_argument("--max-steps", type=int, default=-1, help="stop early (smoke runs)")
+    ap.add_argument("--data-dir", default=None, help="SEVIR root (CATALOG.csv + data/); default: synthetic events")
+    ap.add_argument("--data-format", choices=("npy", "h5"), default="npy")
     ap.add_argument("--model", choices=("tf", "lin"), default="tf",
                     help="tf = ae_64x8x8_tf (what the reference ae_v2/train.py:18 imports), lin = ae_64x8x8_lin (ae_v2_2)")
     args, unknown = ap.parse_known_args(argv)
@@ -74,8 +76,19 @@ def main(argv=None):
     torch.cuda.set_device(dev)
 
     size, frames = (384, 49) if cfg.dataset.name == "sevir" else (128, 25)
-    n_events = max(2, (cfg.dataset.batch_size * 8 * world) // (1 + (frames - cfg.dataset.seq_len) // cfg.dataset.stride) + 1)
-    events = synth.blob_events(n_events, size, frames, seed=1234)
+    if args.data_dir:
+        # real data: <data_dir>/CATALOG.csv + the event files (.npy, or .h5 when h5py is available), the
+        # reference's train split (events before 2019-06-01, pipeline/datasets/sevire/sevir.py:1089-1099)
+        import datetime
+        from ...pipeline.datasets.sevire.catalog import CatalogEventStore, H5EventSource, NpyEventSource, SEVIRCatalog
+        catalog = SEVIRCatalog(os.path.join(args.data_dir, "CATALOG.csv"), end_date=datetime.datetime(2019, 6, 1),
+                               shuffle=True, shuffle_seed=1)
+        source = (H5EventSource if args.data_format == "h5" else NpyEventSource)(os.path.join(args.data_dir, "data"))
+        events = CatalogEventStore(catalog, source)
+        size = events.event_shape[0]
+    else:
+        n_events = max(2, (cfg.dataset.batch_size * 8 * world) // (1 + (frames - cfg.dataset.seq_len) // cfg.dataset.stride) + 1)
+        events = synth.blob_events(n_events, size, frames, seed=1234)
     loader = SEVIRFrameLoader(events, cfg.dataset.batch_size, cfg.dataset.seq_len, cfg.dataset.stride, "NTHW",
                               shuffle=True, device=dev, num_shard=world, rank=rank)
     accum = cfg.trainer.accumulate_grad_batches
@@ -106,7 +119,7 @@ def main(argv=None):
         sched.load_state_dict({"last_epoch": step})
     t0 = time.time()
     while step < total_steps:
-        for batch in loader:
+        for batch in loader.prefetch(2):
             if step >= total_steps:
                 break
             inp = batch["vil"]

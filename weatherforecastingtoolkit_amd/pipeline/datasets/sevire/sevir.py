@@ -11,11 +11,15 @@ Contract reproduced (reference lines):
   * x = (1/255) * (u8.float() + 0), layout 'NHWT' -> 'NTHW'         :749-794, 98-139, 163, 168
   * the outer DataLoader yields the dict of ONE pre-formed batch    :1132-1151
   * train events are shuffled ONCE with random_state=1              :363-367 (here: numpy RandomState(1) permutation)
-HDF5 / catalog / AWS download of the reference are I/O and out of scope
-(SURVEY.md §2 row 6); events come from memory (synthetic `synth.blob_events`
-or any uint8 array the caller read elsewhere).
+Events come either from memory (synthetic `synth.blob_events`, or any uint8 array) or from an event store
+(`catalog.CatalogEventStore`: filtered SEVIR catalog + .npy / HDF5 files).
+`prefetch()` overlaps the host gather and the uint8 H2D copy of batch i+1 (pinned staging buffers, a copy
+stream) with the training step of batch i.  AWS download of the reference is out of scope.
 """
 from __future__ import annotations
+
+import queue
+import threading
 
 import numpy as np
 import torch
@@ -29,15 +33,23 @@ PREPROCESS_OFFSET_01 = {"vil": 0}
 class SEVIRFrameLoader:
     def __init__(self, events_u8, batch_size, seq_len=1, stride=1, layout="NTHW", shuffle=False,
                  shuffle_seed=1, device=None, num_shard=1, rank=0):
-        ev = np.ascontiguousarray(events_u8)
-        assert ev.dtype == np.uint8 and ev.ndim == 4, "events must be uint8 (N_ev, H, W, T)"
         if layout != "NTHW":
             raise ValueError("only layout='NTHW' (the ae_v2 setting, train.py:290-304) is built")
-        if shuffle:
-            ev = ev[np.random.RandomState(shuffle_seed).permutation(ev.shape[0])]
-        self.events = ev
+        if hasattr(events_u8, "read") and hasattr(events_u8, "event_shape"):
+            # an event store (catalog + files): events are read on demand; shuffling is the catalog's job
+            self.store, self.events = events_u8, None
+            self.n_events = len(events_u8)
+            self.raw_seq_len = events_u8.event_shape[2]
+        else:
+            ev = np.ascontiguousarray(events_u8)
+            assert ev.dtype == np.uint8 and ev.ndim == 4, "events must be uint8 (N_ev, H, W, T)"
+            if shuffle:
+                ev = ev[np.random.RandomState(shuffle_seed).permutation(ev.shape[0])]
+            self.store, self.events = None, ev
+            self.n_events = ev.shape[0]
+            self.raw_seq_len = ev.shape[3]
+        self._cache = {}
         self.batch_size, self.seq_len, self.stride = int(batch_size), int(seq_len), int(stride)
-        self.raw_seq_len = ev.shape[3]
         self.device = torch.device(device) if device is not None else None
         self.num_shard, self.rank = int(num_shard), int(rank)
 
@@ -47,7 +59,7 @@ class SEVIRFrameLoader:
 
     @property
     def total_num_seq(self):
-        return int(self.num_seq_per_event * self.events.shape[0])
+        return int(self.num_seq_per_event * self.n_events)
 
     def __len__(self):
         return (self.total_num_seq // self.batch_size) // self.num_shard
@@ -68,7 +80,23 @@ class SEVIRFrameLoader:
     def batch_u8(self, index):
         """uint8 (B, H, W, seq_len) host batch, before preprocessing."""
         idx = self.sample_indices(index * self.num_shard + self.rank)
-        return np.stack([self.events[e, :, :, s * self.stride:s * self.stride + self.seq_len] for e, s in idx], 0)
+        return np.stack([self._event(e)[:, :, s * self.stride:s * self.stride + self.seq_len] for e, s in idx], 0)
+
+    def _event(self, e):
+        if self.events is not None:
+            return self.events[e]
+        ev = self._cache.get(e)
+        if ev is None:
+            if len(self._cache) >= 4:                 # consecutive batches walk the events in order
+                self._cache.pop(next(iter(self._cache)))
+            ev = self._cache[e] = self.store.read(e)
+            if ev.dtype != np.uint8:
+                raise TypeError(f"event {e}: expected uint8, got {ev.dtype}")
+        return ev
+
+    def prefetch(self, depth=2):
+        """iterate with the host gather + uint8 H2D copy of the next `depth` batches running ahead on a copy stream"""
+        return _Prefetcher(self, depth)
 
     def __getitem__(self, index):
         if index >= len(self):
@@ -82,3 +110,74 @@ class SEVIRFrameLoader:
     def __iter__(self):
         for i in range(len(self)):
             yield self[i]
+
+
+class _Prefetcher:
+    """Background thread: gather batch i+1 into a pinned uint8 buffer and start its H2D copy on a side stream while
+    the consumer trains on batch i; the u8 -> fp32/255 + layout kernel runs on the consumer's stream after an event
+    wait.  `depth` pinned buffers / device buffers are recycled."""
+
+    def __init__(self, loader, depth=2):
+        if loader.device is None or loader.device.type != "cuda":
+            raise RuntimeError("prefetch() needs a CUDA(HIP) device")
+        self.loader, self.depth = loader, max(1, int(depth))
+
+    def __iter__(self):
+        ld = self.loader
+        n = len(ld)
+        if n == 0:
+            return
+        dev = ld.device
+        shape = ld.batch_u8(0).shape
+        pinned = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(self.depth + 1)]
+        dbuf = [torch.empty(shape, dtype=torch.uint8, device=dev) for _ in range(self.depth + 1)]
+        free_slots = queue.Queue()
+        for i in range(self.depth + 1):
+            free_slots.put(i)
+        ready = queue.Queue(maxsize=self.depth)
+        copy_stream = torch.cuda.Stream(device=dev)
+        stop = threading.Event()
+
+        def producer():
+            try:
+                torch.cuda.set_device(dev)
+                for i in range(n):
+                    if stop.is_set():
+                        return
+                    slot = free_slots.get()
+                    pinned[slot].numpy()[...] = ld.batch_u8(i)
+                    with torch.cuda.stream(copy_stream):
+                        dbuf[slot].copy_(pinned[slot], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(copy_stream)
+                    ready.put((slot, ev, None))
+                ready.put((None, None, None))
+            except BaseException as e:      # surface loader errors in the consumer
+                ready.put((None, None, e))
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        try:
+            while True:
+                slot, ev, err = ready.get()
+                if err is not None:
+                    raise err
+                if slot is None:
+                    break
+                torch.cuda.current_stream(dev).wait_event(ev)
+                out = {"vil": ops.vil_u8_to_f32(dbuf[slot], PREPROCESS_SCALE_01["vil"])}
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(dev))
+                yield out
+                done.synchronize()           # the conversion kernel has consumed the slot: recycle it
+                free_slots.put(slot)
+        finally:
+            stop.set()                       # an early `break` in the consumer: unblock and retire the producer
+            try:
+                while True:
+                    ready.get_nowait()
+            except queue.Empty:
+                pass
+            for i in range(self.depth + 1):
+                free_slots.put(i)
+            th.join(timeout=5)

@@ -195,6 +195,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "img_size": S,
                        "parallelism": f"dp{world}", "params": sum(p.numel() for p in net.parameters())},
             "final_loss": final_loss,
+            "peak_mem_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
             "step_roofline": {"fp32_fraction": FLOPS_PER_FRAME_384 * scale * fps / world / PEAK_FP32,
                               "hbm_fraction": BYTES_PER_FRAME_384 * scale * fps / world / PEAK_HBM,
                               "binding": "fp32 MFMA/VALU (AI ~127 FLOP/B, SURVEY.md §8d)"},

@@ -74,6 +74,11 @@ __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Conv2d(C, 1, 3, padding=1): the decoder's full-resolution output convolution (c1conv.hip)
+int c1conv3_fwd(const float* x, const float* w, const float* bias, float* y, int NB, int C, int H, int W, hipStream_t st);
+int c1conv3_wgrad(const float* dy, const float* x, float* dw, int NB, int C, int H, int W, int accumulate, void* ws,
+                  size_t ws_bytes, hipStream_t st);
+
 // Winograd transforms of the 4x4 stride-2 convolutions (wino.hip); variant 0 = F(2x2,2x2) (N = 3, M = 2),
 // variant 1 = F(4x4,2x2) (N = 5, M = 4); T = NB*Hlo*Wlo/M^2 tiles, N*N transform positions xi
 int wino_in(int variant, const float* hi, float* V, int NB, int Chi, int Hlo, int Wlo, hipStream_t st);      // -> V[xi][4Chi][T]

@@ -62,13 +62,17 @@ __global__ __launch_bounds__(RT) void chan_reduce_kernel(const float* __restrict
   if (end > total) end = total;
   double s1 = 0.0, s2 = 0.0;
   if (vec) {
-    for (long i = beg + (long)threadIdx.x * 4; i < end; i += RT * 4) {
-      const long o = i / g.inner;
-      const long in = i - o * g.inner;
+    // (outer, inner) cursor advanced incrementally: no 64-bit division in the loop; the four values of a float4
+    // are combined in fp32 before they enter the fp64 accumulators (the kernels were VALU-, not HBM-bound)
+    long i = beg + (long)threadIdx.x * 4;
+    long o = i / g.inner;
+    long in = i - o * g.inner;
+    for (; i < end; i += RT * 4) {
       const float4 v = *reinterpret_cast<const float4*>(x + (o * g.C + c) * g.inner + in);
-      s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-      if (MODE == 0)
-        s2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+      s1 += (double)((v.x + v.y) + (v.z + v.w));
+      if (MODE == 0) s2 += (double)(fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w));
+      in += RT * 4;
+      while (in >= g.inner) { in -= g.inner; ++o; }
     }
   } else {
     for (long i = beg + threadIdx.x; i < end; i += RT) {
@@ -193,12 +197,20 @@ __global__ __launch_bounds__(RT) void bn_act_bwd_reduce_kernel(const float* __re
     s2 += (double)du * ((xv - mu) * is);
   };
   if (vec) {
-    for (long i = beg + (long)threadIdx.x * 4; i < end; i += RT * 4) {
-      const long o = i / g.inner;
-      const long off = (o * g.C + c) * g.inner + (i - o * g.inner);
+    long i = beg + (long)threadIdx.x * 4;
+    long o = i / g.inner;
+    long in = i - o * g.inner;
+    for (; i < end; i += RT * 4) {
+      const long off = (o * g.C + c) * g.inner + in;
       const float4 xv = *reinterpret_cast<const float4*>(x + off);
       const float4 dv = *reinterpret_cast<const float4*>(dy + off);
-      one(xv.x, dv.x); one(xv.y, dv.y); one(xv.z, dv.z); one(xv.w, dv.w);
+      const float d0 = dv.x * act_grad_f<ACT>(fmaf(xv.x, a, b)), d1 = dv.y * act_grad_f<ACT>(fmaf(xv.y, a, b));
+      const float d2 = dv.z * act_grad_f<ACT>(fmaf(xv.z, a, b)), d3 = dv.w * act_grad_f<ACT>(fmaf(xv.w, a, b));
+      s1 += (double)((d0 + d1) + (d2 + d3));
+      const float h0 = (xv.x - mu) * is, h1 = (xv.y - mu) * is, h2 = (xv.z - mu) * is, h3 = (xv.w - mu) * is;
+      s2 += (double)(fmaf(d0, h0, d1 * h1) + fmaf(d2, h2, d3 * h3));
+      in += RT * 4;
+      while (in >= g.inner) { in -= g.inner; ++o; }
     }
   } else {
     for (long i = beg + threadIdx.x; i < end; i += RT) {

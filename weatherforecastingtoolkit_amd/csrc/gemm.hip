@@ -33,6 +33,16 @@ constexpr int BK = 16;
 constexpr int BN = 128;
 constexpr int NT = 256;
 
+// k-contiguous operands: thread idx loads the float4 (row kc_row(idx), k = kc_k(idx) .. +3) and scatters it into
+// the transposed LDS image As[k][m] with four ds_write_b32.  The LDS has 32 banks and a 64-lane ds_write_b32
+// is served 32 lanes per cycle; with row strides == 4 (mod 32) words the bank of a write is 4 (kq + j) + m.  The
+// natural map (m = idx >> 2, kq = 4 (idx & 3)) puts kq = 0 and kq = 8 of one half-wave on the same banks
+// (PMC: SQ_LDS_BANK_CONFLICT = 21-30 % of the LDS-active cycles of these kernels, 0 for the m-contiguous
+// operand kinds); this map gives a half-wave 16 rows x 2 k-quads = 32 distinct banks.  The global side still
+// reads whole 64-byte row segments per wave-instruction.
+__device__ __forceinline__ int kc_row(int idx) { return (idx & 15) | ((idx >> 6) << 4); }
+__device__ __forceinline__ int kc_k(int idx) { return ((idx >> 4) & 3) * 4; }
+
 enum AKind { A_KCONTIG = 0, A_MCONTIG = 1 };
 enum BKind { B_NCONTIG = 0, B_KCONTIG = 1, B_DOWN = 2, B_UP = 3, B_WGRAD = 4, B_WGRAD3 = 5, B_TAPN = 6, B_TAPK = 7 };
 enum EKind { E_BATCHED = 0, E_SLAB = 1, E_UP = 2 };
@@ -274,8 +284,8 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
       const int idx = t + i * NT;
       const bool inb = (A_IT * NT == A_CNT) || idx < A_CNT;
       if constexpr (AK == A_KCONTIG) {
-        const int m = m0 + (idx >> 2);
-        const int k = k_begin + (idx & 3) * 4;
+        const int m = m0 + kc_row(idx);
+        const int k = k_begin + kc_k(idx);
         la_st[i] = inb && m < p.M;
         const int img = k / p.a_hw;
         la_pk[i] = k - img * p.a_hw;
@@ -302,8 +312,8 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         const int idx = t + i * NT;
-        const int n = n0 + (idx >> 2);
-        const int k = k_begin + (idx & 3) * 4;
+        const int n = n0 + kc_row(idx);
+        const int k = k_begin + kc_k(idx);
         lb_st[i] = n < p.N;
         const int img = k / p.b_hw;
         lb_pk[i] = k - img * p.b_hw;
@@ -324,8 +334,8 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         const int idx = t + i * NT;
-        const int n = n0 + (idx >> 2);
-        const int k = k_begin + (idx & 3) * 4;
+        const int n = n0 + kc_row(idx);
+        const int k = k_begin + kc_k(idx);
         lb_st[i] = n < p.N;
         const int nn = lb_st[i] ? n : 0;
         const int tap = nn / p.Chi, c = nn - tap * p.Chi;
@@ -489,8 +499,8 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
         const int idx = t + i * NT;
-        const int m = m0 + (idx >> 2);
-        const int k = k0 + (idx & 3) * 4;
+        const int m = m0 + kc_row(idx);
+        const int k = k0 + kc_k(idx);
         const bool ok = (A_IT * NT == A_CNT || idx < A_CNT) && m < p.M && k < k_end;
         if constexpr (VEC) {
           const int kk = ok ? k : 0;
@@ -540,7 +550,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
         float4 v = ra[i];
         if (!lean_regs) v = sel4(v, a_okbits, i);  // wave-uniform branch: full stages carry no predicate
         if constexpr (AK == A_KCONTIG) {
-          const int ml = idx >> 2, kq = (idx & 3) * 4;
+          const int ml = kc_row(idx), kq = kc_k(idx);
           As[buf][kq + 0][ml] = v.x;
           As[buf][kq + 1][ml] = v.y;
           As[buf][kq + 2][ml] = v.z;
@@ -580,8 +590,8 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         const int idx = t + i * NT;
-        const int n = n0 + (idx >> 2);
-        const int k = k0 + (idx & 3) * 4;
+        const int n = n0 + kc_row(idx);
+        const int k = k0 + kc_k(idx);
         const bool ok = n < p.N && k < k_end;
         if constexpr (VEC) {
           const int kk = ok ? k : 0;
@@ -630,8 +640,8 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         const int idx = t + i * NT;
-        const int n = n0 + (idx >> 2);
-        const int k = k0 + (idx & 3) * 4;
+        const int n = n0 + kc_row(idx);
+        const int k = k0 + kc_k(idx);
         const bool ok = n < p.N && k < k_end;
         const int nn = n < p.N ? n : 0;
         const int tap = nn / p.Chi, c = nn - tap * p.Chi;
@@ -769,7 +779,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         const int idx = t + i * NT;
-        const int nl = idx >> 2, kq = (idx & 3) * 4;
+        const int nl = kc_row(idx), kq = kc_k(idx);
         float4 v = rb[i];
         if (!lean_regs) v = sel4(v, b_okbits, i);
         Bs[buf][kq + 0][nl] = v.x;

@@ -6,8 +6,8 @@ reference's experiments/ae_v2/train.py, without Lightning / W&B.
 Step order (reference :209-223 + Lightning, :254-261):
   fwd -> Loss.forward (L1 [+ perceptual_weight*(1-SSIM)]) -> log -> bwd ->
   (grad all-reduce when WORLD_SIZE>1) -> AdamW -> cosine-warmup LR step.
-The GAN branch of the reference Loss (:76-102) never runs in the shipped config
-(disc_start=1.0 => disc_start = total_steps, :318) and is not built in this round.
+The GAN branch of the reference Loss (:76-102) never runs in the shipped config (disc_start=1.0 =>
+disc_start = total_steps, :318); it is built (experiments/_gan.py) and used when lpips.disc_start < 1.
 Data: synthetic SEVIR-shaped events (synth.blob_events) pushed through the
 reference's loader contract; prints `done` at the end like the reference (:347)
 so its retry shell keeps working.
@@ -30,20 +30,29 @@ from ...nn import flush_bn_counters
 from ...pipeline import helpers
 from ...pipeline.datasets.sevire.sevir import SEVIRFrameLoader
 from ...pipeline.models import ae_64x8x8_lin, ae_64x8x8_tf
+from .._gan import GanLoss, frozen
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-class Loss(tnn.Module):
-    """Live branch of the reference Loss.forward (experiments/ae_v2/train.py:54-74)."""
+class Loss(GanLoss):
+    """reference Loss (experiments/ae_v2/train.py:27-102): L1 [+ perceptual_weight * (1 - SSIM)], and past `disc_start`
+    the generator term d_weight * -mean(D(x_hat)) (optimizer_idx 0) / the hinge discriminator loss (optimizer_idx 1).
+    Owns the PatchGAN discriminator and `logvar` like the reference (state_dict keys `discriminator.main.*`,
+    `logvar`); LPIPS is commented out in the reference (:60-61) and absent here."""
 
-    def __init__(self, disc_start, disc_weight=0.0, perceptual_weight=0.0, recon_weight=1.0, **_unused):
-        super().__init__()
-        self.disc_start, self.disc_weight = disc_start, disc_weight
-        self.perceptual_weight, self.recon_weight = perceptual_weight, recon_weight
+    def __init__(self, disc_start, disc_num_layers=3, disc_in_channels=1, disc_weight=1.0, use_actnorm=False,
+                 perceptual_weight=1.0, kl_weight=1.0, logvar_init=0.0, recon_weight=1.0):
+        super().__init__(disc_start, disc_num_layers, disc_in_channels, disc_weight, use_actnorm)
+        self.perceptual_weight, self.recon_weight, self.kl_weight = perceptual_weight, recon_weight, kl_weight
+        self.logvar = tnn.Parameter(torch.ones(size=()) * logvar_init)      # unused by the live branch (:42)
 
     def forward(self, inputs, reconstructions, posteriors=None, optimizer_idx=0, last_layer=None,
                 split="train", global_step=0):
+        if optimizer_idx == 1:
+            d_loss, logits_real, logits_fake = self.discriminator_loss(inputs, reconstructions)
+            return d_loss, {f"{split}/disc_loss": d_loss.detach(), f"{split}/logits_real": logits_real.detach().mean(),
+                            f"{split}/logits_fake": logits_fake.detach().mean()}
         rec_loss = Fn.l1_loss(reconstructions, inputs, self.recon_weight)
         if self.perceptual_weight > 0:
             # 1 - ssim on channel-tripled inputs (:57-63); tripling does not change the value
@@ -53,7 +62,9 @@ class Loss(tnn.Module):
         if global_step < self.disc_start:
             return nll_loss, {f"{split}/total_loss": nll_loss.detach(), f"{split}/rec_loss": rec_loss.detach(),
                               f"{split}/nll_loss": nll_loss.detach(), f"{split}/g_loss": 0.0, f"{split}/d_weight": 0.0}
-        raise NotImplementedError("AE+GAN step (reference :76-102) is a 'next' row (SURVEY.md §8f)")
+        loss, g_loss, d_weight = self.generator_loss(nll_loss, reconstructions, last_layer)
+        return loss, {f"{split}/total_loss": loss.detach(), f"{split}/nll_loss": nll_loss.detach(),
+                      f"{split}/rec_loss": rec_loss.detach(), f"{split}/g_loss": g_loss.detach(), f"{split}/d_weight": d_weight}
 
 
 def main(argv=None):
@@ -101,7 +112,10 @@ def main(argv=None):
     model_mod = ae_64x8x8_tf if args.model == "tf" else ae_64x8x8_lin
     net = model_mod.PosAwareAE_TF(img_size=size).to(dev).train()
     Fn.set_wgrad_overlap(True)
-    loss_fn = Loss(disc_start, cfg.lpips.disc_weight, cfg.lpips.perceptual_weight, cfg.lpips.recon_weight)
+    loss_fn = Loss(disc_start, disc_num_layers=cfg.lpips.disc_num_layers, disc_in_channels=cfg.lpips.disc_in_channels,
+                   disc_weight=cfg.lpips.disc_weight, use_actnorm=cfg.lpips.use_actnorm,
+                   perceptual_weight=cfg.lpips.perceptual_weight, kl_weight=cfg.lpips.kl_weight,
+                   logvar_init=cfg.lpips.logvar_init, recon_weight=cfg.lpips.recon_weight).to(dev)
     opt = helpers.adamw_optimizer(net, cfg.optim.lr, cfg.optim.weight_decay, cfg.optim.beta1, cfg.optim.beta2)
     sched = helpers.cosine_warmup_scheduler(opt, cfg.cosine_warmup.start_lr, cfg.cosine_warmup.final_lr,
                                             cfg.cosine_warmup.peak_lr, total_steps,
@@ -125,8 +139,11 @@ def main(argv=None):
             inp = batch["vil"]
             opt.zero_grad(set_to_none=True)
             pred, z = net(inp)
-            loss, logs = loss_fn(inp, pred, None, 0, None, "train", step)
-            loss.backward()
+            # the reference trains only the autoencoder here (one optimiser, :254-261): past disc_start the
+            # discriminator scores the reconstruction but is never updated — its parameters stay frozen
+            with frozen(loss_fn.discriminator.parameters()):
+                loss, logs = loss_fn(inp, pred, None, 0, net.dec[-1].weight, "train", step)
+                loss.backward()
             dp.reduce_gradients()
             opt.step()
             sched.step()

@@ -321,3 +321,21 @@ def test_ae_v2_loss_gan_branch_equals_ae_v2_2(dev, tmp_path):
     from weatherforecastingtoolkit_amd.experiments.ae_v2 import train
     assert train.main(["--model", "lin", "--max-steps", "4", f"experiment_path={tmp_path}", "dataset.batch_size=2",
                        "lpips.disc_start=0.5", "lpips.disc_weight=1.0"]) == 0
+
+
+def test_gan_validation_step(dev):
+    """eval-mode step: both loss halves without gradients (d_weight = 0 like the reference's RuntimeError branch) and
+    the image metrics; nothing is updated"""
+    from weatherforecastingtoolkit_amd import synth
+    from weatherforecastingtoolkit_amd.experiments.ae_v2_2.train import Model
+    model = Model(_cfg(40, 0), img_size=128).to(dev)
+    model.configure_optimizers()
+    model.eval()
+    before = [p.detach().clone() for p in model.parameters()]
+    x = torch.from_numpy(synth.uniform_frames(2, 128, seed=3)).to(dev)
+    pred, logs = model.validation_step({"vil": x})
+    assert tuple(pred.shape) == (2, 1, 128, 128)
+    assert float(logs["val/d_weight"]) == 0.0 and float(logs["val/total_loss"]) == float(logs["val/rec_loss"])
+    assert "val/disc_loss" in logs and any(k.startswith("val_") for k in logs)
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, model.parameters()))
+    assert model.loss.discriminator.main[3].num_batches_tracked.item() == 0      # eval mode: running stats untouched

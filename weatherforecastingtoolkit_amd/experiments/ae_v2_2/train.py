@@ -143,6 +143,21 @@ class Model(tnn.Module):
         return pred, logs
 
 
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx=0, split="val"):
+        """reference validation_step / test_step (:170-198): both halves of the loss (no gradients: d_weight is 0, as
+        the reference's RuntimeError branch makes it, :74-76) and the image metrics"""
+        inp = batch["vil"] if isinstance(batch, dict) else batch
+        pred = self(inp)
+        _, logs = self.loss(inp, pred, 0, self.get_last_layer(), split, self.global_step)
+        logs = dict(logs)
+        if self.global_step >= self.cfg.lpips.disc_start:
+            _, log_d = self.loss(inp, pred, 1, self.get_last_layer(), split, self.global_step)
+            logs.update(log_d)
+        logs.update(helpers.log_metrics(pred.unsqueeze(2), inp.unsqueeze(2), split))
+        return pred, logs
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--resume", type=bool, default=False)

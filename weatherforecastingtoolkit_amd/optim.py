@@ -231,3 +231,58 @@ def cosine_warmup_lr(e, start_lr, peak_lr, final_lr, total_steps, warmup_steps):
     first = math.floor(warmup_steps) + 1
     t, lr0 = e - first, linear(first - 1)
     return final_lr + (lr0 - final_lr) * (1.0 + math.cos(math.pi * t / t_max)) / (1.0 + math.cos(math.pi / t_max))
+
+
+class OneCycleLR:
+    """Closed form of torch.optim.lr_scheduler.OneCycleLR(max_lr, total_steps, pct_start, div_factor,
+    final_div_factor, anneal_strategy='cos', three_phase=False, cycle_momentum=True) as the reference's
+    one_cycle_scheduler builds it (pipeline/helpers.py:109-140): lr anneals initial -> max over the first
+    pct_start*total - 1 steps and max -> initial/final_div_factor over the rest; with Adam-type optimisers beta1
+    is cycled 0.95 -> 0.85 -> 0.95 alongside (torch's default base_momentum / max_momentum)."""
+
+    def __init__(self, opt, max_lr, total_steps, pct_start, div_factor, final_div_factor, base_momentum=0.85,
+                 max_momentum=0.95, cycle_momentum=True):
+        self.opt, self.total_steps = opt, int(total_steps)
+        self.max_lr = float(max_lr)
+        self.initial_lr = self.max_lr / float(div_factor)
+        self.min_lr = self.initial_lr / float(final_div_factor)
+        self.end1 = float(pct_start * self.total_steps) - 1.0
+        self.end2 = float(self.total_steps - 1)
+        self.base_m, self.max_m, self.cycle_momentum = float(base_momentum), float(max_momentum), cycle_momentum
+        self.last_epoch = 0
+        self._apply()
+
+    @staticmethod
+    def _cos(start, end, pct):
+        return end + (start - end) / 2.0 * (math.cos(math.pi * pct) + 1.0)
+
+    def values_at(self, step):
+        if step > self.total_steps:
+            raise ValueError(f"Tried to step {step} times. The specified number of total steps is {self.total_steps}")
+        if step <= self.end1 or self.end1 >= self.end2:
+            pct = step / self.end1 if self.end1 > 0 else 1.0
+            return self._cos(self.initial_lr, self.max_lr, pct), self._cos(self.max_m, self.base_m, pct)
+        pct = (step - self.end1) / (self.end2 - self.end1)
+        return self._cos(self.max_lr, self.min_lr, pct), self._cos(self.base_m, self.max_m, pct)
+
+    def _apply(self):
+        lr, mom = self.values_at(self.last_epoch)
+        for g in self.opt.param_groups:
+            g["lr"] = lr
+            if self.cycle_momentum and "betas" in g:
+                g["betas"] = (mom, g["betas"][1])
+        self._last_lr = [lr for _ in self.opt.param_groups]
+
+    def step(self):
+        self.last_epoch += 1
+        self._apply()
+
+    def get_last_lr(self):
+        return self._last_lr
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch}
+
+    def load_state_dict(self, sd):
+        self.last_epoch = sd["last_epoch"]
+        self._apply()

@@ -28,6 +28,16 @@ def cosine_warmup_scheduler(opt, start_lr, final_lr, peak_lr, total_steps, warmu
     return CosineWarmupLR(opt, start_lr, final_lr, peak_lr, total_steps, warmup_steps)
 
 
+def one_cycle_scheduler(opt, start_lr, peak_lr, final_lr, total_steps, rampup_steps):
+    """reference pipeline/helpers.py:109-140 (same positional order): OneCycleLR with pct_start = rampup/total,
+    div_factor = peak/start, final_div_factor = start/final, cosine annealing."""
+    from ..optim import OneCycleLR
+    if rampup_steps / total_steps < 0.2:
+        print(f"rampup steps should be higher than 20% of total steps, it is {rampup_steps / total_steps}")
+    return OneCycleLR(opt, max_lr=peak_lr, total_steps=total_steps, pct_start=rampup_steps / total_steps,
+                      div_factor=peak_lr / start_lr, final_div_factor=start_lr / final_lr)
+
+
 def check_yaml(cfg, cli_cfg, path=""):
     """reference pipeline/helpers.py:260-266: reject override keys absent from the base file."""
     for k in cli_cfg:

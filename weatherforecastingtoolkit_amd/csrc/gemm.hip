@@ -75,6 +75,7 @@ struct GemmP {
   long a_y, b_y, c_y;
   int big_ok;        // 256-row tiles allowed for this launch (long-K plain GEMMs)
   int swizzle;       // XCD-aware tile order (set by launch_gemm_v from WFAE_SWIZZLE, default off)
+  int nt_store;      // nontemporal stores of the result tile (WFAE_GEMM_NT)
   int a_vec, b_vec, c_vec;  // 16-byte vector accesses are legal for this operand / the result
   // 4x4 s2 geometry (gather kinds): lo side Hlo x Wlo, hi side 2Hlo x 2Wlo
   int Chi, Clo, Hlo, Wlo;
@@ -945,7 +946,13 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
               v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
             }
           }
-          *reinterpret_cast<float4*>(dst) = v;
+          if (p.nt_store) {
+            typedef float vf4 __attribute__((ext_vector_type(4)));
+            const vf4 o = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(o, reinterpret_cast<vf4*>(dst));
+          } else {
+            *reinterpret_cast<float4*>(dst) = v;
+          }
         }
       }
     }
@@ -1130,8 +1137,10 @@ template <int AK, int BKD, int EK, bool VEC>
 int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what, int ydim = 1) {
   static const int use256 = env_int("WFAE_BM256", 1);
   static const int swz = env_int("WFAE_SWIZZLE", 0);  // measured: no change (the GEMMs are not L2-miss bound), kept for A/B
+  static const int nts = env_int("WFAE_GEMM_NT", 0);
   GemmP p = p_in;
   p.swizzle = swz;
+  p.nt_store = nts;
   const int ntiles = cdiv(p.N, BN);
   dim3 block(NT);
   bool big = false;

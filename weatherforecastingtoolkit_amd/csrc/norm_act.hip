@@ -2,6 +2,7 @@
 // (wavefront-shuffle reductions, fp64 accumulation), fused BN-apply + exact GELU,
 // their backward, sigmoid + L1 loss, element-wise helpers and channel reductions.
 // All kernels use 16-byte loads when HW % 4 == 0 (always true for the model).
+#include <stdlib.h>
 #include "common.h"
 
 using namespace wfae;
@@ -153,7 +154,7 @@ template <int ACT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift, float* __restrict__ y,
-                                                         int C, int HW, int vec) {
+                                                         int C, int HW, int vec, int nt) {
   const int plane = blockIdx.x;
   const int c = plane % C;
   const float a = scale[c], b = shift[c];
@@ -164,8 +165,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n4; i += gridDim.y * blockDim.x) {
       float4 v = reinterpret_cast<const float4*>(xp)[i];
       v.x = fmaf(v.x, a, b); v.y = fmaf(v.y, a, b); v.z = fmaf(v.z, a, b); v.w = fmaf(v.w, a, b);
-      v.x = act_f<ACT>(v.x); v.y = act_f<ACT>(v.y); v.z = act_f<ACT>(v.z); v.w = act_f<ACT>(v.w);
-      reinterpret_cast<float4*>(yp)[i] = v;
+      typedef float vf4 __attribute__((ext_vector_type(4)));
+      const vf4 o = {act_f<ACT>(v.x), act_f<ACT>(v.y), act_f<ACT>(v.z), act_f<ACT>(v.w)};
+      if (nt) __builtin_nontemporal_store(o, reinterpret_cast<vf4*>(yp) + i);
+      else reinterpret_cast<vf4*>(yp)[i] = o;
     }
   } else {
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < HW; i += gridDim.y * blockDim.x) {
@@ -245,7 +248,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int spli
 }
 
 // backward pass 2: dx = gamma*invstd*(dU - sum_dU/n - xhat*sum_dUxhat/n) (+res)
-template <int ACT>
+template <int ACT, int NTMODE>
 __global__ __launch_bounds__(256) void bn_act_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ scale,
@@ -269,15 +272,27 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dx_kernel(const float* __restr
   };
   if (vec) {
     const int n4 = HW >> 2;
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    const vf4* __restrict__ x4 = reinterpret_cast<const vf4*>(x + base);
+    const vf4* __restrict__ d4 = reinterpret_cast<const vf4*>(dy + base);
+    const vf4* __restrict__ r4 = res ? reinterpret_cast<const vf4*>(res + base) : nullptr;
+    vf4* __restrict__ o4 = reinterpret_cast<vf4*>(dx + base);
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n4; i += gridDim.y * blockDim.x) {
-      const float4 xv = reinterpret_cast<const float4*>(x + base)[i];
-      const float4 dv = reinterpret_cast<const float4*>(dy + base)[i];
-      float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (res) rv = reinterpret_cast<const float4*>(res + base)[i];
-      float4 o;
+      vf4 xv, dv, rv = {0.f, 0.f, 0.f, 0.f};
+      if (NTMODE) {   // streamed once: keep them out of the way of the GEMM operands in L2
+        xv = __builtin_nontemporal_load(x4 + i);
+        dv = __builtin_nontemporal_load(d4 + i);
+        if (r4) rv = __builtin_nontemporal_load(r4 + i);
+      } else {
+        xv = x4[i];
+        dv = d4[i];
+        if (r4) rv = r4[i];
+      }
+      vf4 o;
       o.x = one(xv.x, dv.x, rv.x); o.y = one(xv.y, dv.y, rv.y);
       o.z = one(xv.z, dv.z, rv.z); o.w = one(xv.w, dv.w, rv.w);
-      reinterpret_cast<float4*>(dx + base)[i] = o;
+      if (NTMODE == 2) __builtin_nontemporal_store(o, o4 + i);
+      else o4[i] = o;
     }
   } else {
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < HW; i += gridDim.y * blockDim.x)
@@ -577,12 +592,13 @@ int wfae_bn_act_fwd(const float* x, const float* scale, const float* shift, floa
   if (gy > 1024) gy = 1024;
   dim3 grid((unsigned)((long)NB * C), gy);
   hipStream_t st = (hipStream_t)stream;
+  static const int nt_fwd = getenv("WFAE_BN_NT_FWD") ? atoi(getenv("WFAE_BN_NT_FWD")) : 0;   // A/B: nontemporal store of y
   if (act == 1)
-    hipLaunchKernelGGL((bn_act_fwd_kernel<1>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec);
+    hipLaunchKernelGGL((bn_act_fwd_kernel<1>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd);
   else if (act == 2)
-    hipLaunchKernelGGL((bn_act_fwd_kernel<2>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec);
+    hipLaunchKernelGGL((bn_act_fwd_kernel<2>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd);
   else
-    hipLaunchKernelGGL((bn_act_fwd_kernel<0>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec);
+    hipLaunchKernelGGL((bn_act_fwd_kernel<0>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd);
   return check_launch("bn_act_fwd");
 }
 
@@ -630,15 +646,16 @@ int wfae_bn_act_bwd(const float* dy, const float* x, const float* gamma, const f
     if (gy > 1024) gy = 1024;
     dim3 grid((unsigned)((long)NB * C), gy);
     const float inv_count = 1.0f / (float)((double)NB * HW);
-    if (act == 1)
-      hipLaunchKernelGGL((bn_act_bwd_dx_kernel<1>), grid, dim3(256), 0, st, dy, x, gamma, scale, shift, save_mean,
-                         save_invstd, coef, res, dx, C, HW, inv_count, training, vec);
-    else if (act == 2)
-      hipLaunchKernelGGL((bn_act_bwd_dx_kernel<2>), grid, dim3(256), 0, st, dy, x, gamma, scale, shift, save_mean,
-                         save_invstd, coef, res, dx, C, HW, inv_count, training, vec);
-    else
-      hipLaunchKernelGGL((bn_act_bwd_dx_kernel<0>), grid, dim3(256), 0, st, dy, x, gamma, scale, shift, save_mean,
-                         save_invstd, coef, res, dx, C, HW, inv_count, training, vec);
+    // 0 plain, 1 nontemporal loads, 2 nontemporal loads + stores.  Measured (tools/kbench.py, B = 32): the
+    // nontemporal STORE of dx lifts the kernel pair from 5.0-5.4 to 5.7-6.0 TB/s; the loads alone change nothing
+    static const int ntmode = getenv("WFAE_BN_NT") ? atoi(getenv("WFAE_BN_NT")) : 2;
+#define WFAE_DX(ACT_, NT_)                                                                                       \
+  hipLaunchKernelGGL((bn_act_bwd_dx_kernel<ACT_, NT_>), grid, dim3(256), 0, st, dy, x, gamma, scale, shift, save_mean, \
+                     save_invstd, coef, res, dx, C, HW, inv_count, training, vec)
+    if (act == 1) { if (ntmode == 2) WFAE_DX(1, 2); else if (ntmode == 1) WFAE_DX(1, 1); else WFAE_DX(1, 0); }
+    else if (act == 2) WFAE_DX(2, 0);
+    else WFAE_DX(0, 0);
+#undef WFAE_DX
     rc = check_launch("bn_act_bwd_dx");
   }
   return rc;

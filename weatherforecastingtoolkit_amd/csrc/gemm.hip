@@ -1137,10 +1137,12 @@ template <int AK, int BKD, int EK, bool VEC>
 int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what, int ydim = 1) {
   static const int use256 = env_int("WFAE_BM256", 1);
   static const int swz = env_int("WFAE_SWIZZLE", 0);  // measured: no change (the GEMMs are not L2-miss bound), kept for A/B
+  // nontemporal result stores: 0 never (default), 1 always, 2 only for launches that also stream a residual.
+  // Measured neutral for every GEMM of the step (unlike the BatchNorm dx kernel): kept for A/B only
   static const int nts = env_int("WFAE_GEMM_NT", 0);
   GemmP p = p_in;
   p.swizzle = swz;
-  p.nt_store = nts;
+  p.nt_store = nts == 1 || (nts == 2 && p_in.res != nullptr);
   const int ntiles = cdiv(p.N, BN);
   dim3 block(NT);
   bool big = false;

@@ -18,7 +18,7 @@ from weatherforecastingtoolkit_amd import config as C  # noqa: E402
 from weatherforecastingtoolkit_amd import functional as Fn  # noqa: E402
 from weatherforecastingtoolkit_amd import ops, synth  # noqa: E402
 import weatherforecastingtoolkit_amd.experiments.ae_v2_2 as pkg  # noqa: E402
-from weatherforecastingtoolkit_amd.experiments.ae_v2_2.train import Model  # noqa: E402
+from weatherforecastingtoolkit_amd.experiments.ae_v2_2.train import CARRIED_KEYS, Model  # noqa: E402
 
 
 def main():
@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    cfg = C.load(os.path.join(os.path.dirname(pkg.__file__), "config.yaml"))
+    cfg = C.load(os.path.join(os.path.dirname(pkg.__file__), "config.yaml"), CARRIED_KEYS)
     cfg.trainer.total_train_steps = 1000
     cfg.lpips.disc_start = 10 ** 9 if a.no_gan else 0
     torch.manual_seed(0)

@@ -41,9 +41,22 @@ def _fix_scalars(o):
     return o
 
 
-def load(path):
+def load(path, carried=None):
+    """the YAML file, over `carried` — keys of the reference's config that this build accepts (so that existing
+    override command lines keep parsing) but does not read: they live in code instead of the YAML"""
     with open(path) as f:
-        return _wrap(_fix_scalars(yaml.safe_load(f)))
+        cfg = _wrap(_fix_scalars(yaml.safe_load(f)))
+    if carried:
+        cfg = merge(_wrap(_fix_scalars(_deep_copy(carried))), cfg)
+    return cfg
+
+
+def _deep_copy(o):
+    if isinstance(o, dict):
+        return {k: _deep_copy(v) for k, v in o.items()}
+    if isinstance(o, list):
+        return [_deep_copy(v) for v in o]
+    return o
 
 
 def from_dotlist(items):

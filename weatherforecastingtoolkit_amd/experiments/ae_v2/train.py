@@ -34,6 +34,23 @@ from .._gan import GanLoss, frozen
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
+# Keys of the reference's experiments/ae_v2/config.yaml that this build accepts (so that existing `key=value`
+# override command lines keep parsing, helpers.check_yaml) but never reads: W&B / Lightning / unused schedules.
+CARRIED_KEYS = {
+    "project_name": "ae_test_v2",
+    "lpips": {"disc_beta1": 0.5, "disc_beta2": 0.9, "disc_start_lr": 5e-7, "disc_peak_lr": 5e-6, "disc_final_lr": 5e-8,
+              "disc_warmup_ratio": 0.1},
+    "dataset": {"num_workers": 4, "input_frames": 0, "pred_frames": 1, "image_width": 128, "image_height": 128, "channels": 1},
+    "optim": {"gradient_clip_val": 1.0},
+    "one_cycle": {"peak_lr": 1e-3, "start_lr": 4e-5, "final_lr": 4e-7, "rampup_ratio": 0.3},
+    "lr_range_test": {"max_lr": 1, "num_iter": 100},
+    "trainer": {"devices": [0], "total_train_steps": -1, "total_val_steps": -1, "total_test_steps": -1,
+                "save_every_n_steps": 0.1, "save_on_train_epoch_end": False, "limit_train_batches": 0.01,
+                "limit_val_batches": 0.01, "limit_test_batches": 0.01},
+    "logging": {"wandb_watch_log_freq": 0, "log_train_all_metrics_n": 0.01, "log_train_plots_n": 0.01, "log_val_plots_n": 0.01},
+}
+
+
 
 class Loss(GanLoss):
     """reference Loss (experiments/ae_v2/train.py:27-102): L1 [+ perceptual_weight * (1 - SSIM)], and past `disc_start`
@@ -77,7 +94,7 @@ def main(argv=None):
     ap.add_argument("--model", choices=("tf", "lin"), default="tf",
                     help="tf = ae_64x8x8_tf (what the reference ae_v2/train.py:18 imports), lin = ae_64x8x8_lin (ae_v2_2)")
     args, unknown = ap.parse_known_args(argv)
-    cfg = C.load(args.config)
+    cfg = C.load(args.config, CARRIED_KEYS)
     cli = C.from_dotlist(unknown)
     helpers.check_yaml(cfg, cli)
     cfg = C.merge(cfg, cli)

@@ -35,6 +35,22 @@ from .._gan import GanLoss, frozen
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
+# Keys of the reference's experiments/ae_v2_2/config.yaml that this build accepts but never reads.
+CARRIED_KEYS = {
+    "project_name": "ae_v3",
+    "lpips": {"disc_beta1": 0.5, "disc_beta2": 0.9, "disc_start_lr": 5e-6, "disc_peak_lr": 5e-5, "disc_final_lr": 5e-7,
+              "disc_warmup_ratio": 0.1, "kl_weight": 0.0, "logvar_init": 0.0},
+    "dataset": {"num_workers": 8, "aug_mode": 1, "input_frames": 0, "pred_frames": 1, "image_width": 128,
+                "image_height": 128, "channels": 1},
+    "optim": {"beta1": 0.5, "beta2": 0.9},
+    "one_cycle": {"peak_lr": 1e-3, "start_lr": 4e-5, "final_lr": 4e-7, "rampup_ratio": 0.3},
+    "lr_range_test": {"max_lr": 1, "num_iter": 100},
+    "trainer": {"devices": [0], "total_val_steps": -1, "total_test_steps": -1, "save_every_n_steps": 0.1,
+                "save_on_train_epoch_end": False, "limit_val_batches": 0.01, "limit_test_batches": None},
+    "logging": {"wandb_watch_log_freq": 0, "log_train_all_metrics_n": 0.01, "log_train_plots_n": 0.01, "log_val_plots_n": 0.01},
+}
+
+
 
 class Loss(GanLoss):
     """reference experiments/ae_v2_2/train.py:29-95"""
@@ -164,7 +180,7 @@ def main(argv=None):
     ap.add_argument("--config", default=os.path.join(HERE, "config.yaml"))
     ap.add_argument("--max-steps", type=int, default=-1, help="stop early (smoke runs)")
     args, unknown = ap.parse_known_args(argv)
-    cfg = C.load(args.config)
+    cfg = C.load(args.config, CARRIED_KEYS)
     cli = C.from_dotlist(unknown)
     helpers.check_yaml(cfg, cli)
     cfg = C.merge(cfg, cli)

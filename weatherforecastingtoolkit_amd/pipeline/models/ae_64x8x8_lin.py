@@ -19,111 +19,113 @@ from ... import functional as Fn
 from ... import nn as wnn
 
 
+# channel plans of the four encoder / decoder stages and the residual depth per stage (reference :58-62, :76-82)
+_ENC_WIDTHS = (256, 512, 1024, 1024)
+_DEC_WIDTHS = (1024, 512, 256, 128)
+_BLOCKS_PER_STAGE = 4
+
+
+def _norm_act_conv(c_in, c_out, k, **conv_kw):
+    """[BatchNorm2d(c_in), GELU, Conv2d(c_in -> c_out, k, bias=False)] — one third of a Bottleneck body"""
+    return [wnn.BatchNorm2d(c_in), wnn.GELU(), wnn.Conv2d(c_in, c_out, k, bias=False, **conv_kw)]
+
+
+def _residual_stack(width, depth, groups):
+    return tnn.Sequential(*(Bottleneck(width, groups) for _ in range(depth)))
+
+
 class Bottleneck(tnn.Module):
-    """Pre-activation bottleneck: x + 1x1(GELU(BN(g3x3(GELU(BN(1x1(GELU(BN(x)))))))))
-    — reference ae_64x8x8_lin.py:7-22.  Fused: one autograd node, 13 forward launches."""
+    """Pre-activation bottleneck  x + W3 . gelu(bn(G3x3 . gelu(bn(W1 . gelu(bn(x))))))  at a quarter of the width in
+    the middle (reference ae_64x8x8_lin.py:7-22; `f.0 … f.8` are its Sequential indices).  Runs as ONE autograd
+    node (functional.BottleneckFn): 13 forward launches, the residual add fused into the last 1x1 epilogue."""
 
     def __init__(self, channels: int, groups: int = 8):
         super().__init__()
-        mid = channels // 4
-        g = min(groups, mid)
-        assert mid % g == 0, f"groups ({g}) must divide mid channels ({mid})"
-        self.f = tnn.Sequential(
-            wnn.BatchNorm2d(channels), wnn.GELU(),
-            wnn.Conv2d(channels, mid, 1, bias=False),
-            wnn.BatchNorm2d(mid), wnn.GELU(),
-            wnn.Conv2d(mid, mid, 3, padding=1, groups=g, bias=False),
-            wnn.BatchNorm2d(mid), wnn.GELU(),
-            wnn.Conv2d(mid, channels, 1, bias=False),
-        )
+        inner = channels // 4
+        n_groups = min(groups, inner)
+        assert inner % n_groups == 0, f"groups ({n_groups}) must divide mid channels ({inner})"
+        body = (_norm_act_conv(channels, inner, 1)
+                + _norm_act_conv(inner, inner, 3, padding=1, groups=n_groups)
+                + _norm_act_conv(inner, channels, 1))
+        self.f = tnn.Sequential(*body)
 
     def forward(self, x):
-        f = self.f
-        return Fn.BottleneckFn.apply(x, f[0].weight, f[0].bias, f[2].weight, f[3].weight, f[3].bias,
-                                     f[5].weight, f[6].weight, f[6].bias, f[8].weight, self)
+        bn1, _, w1, bn2, _, wg, bn3, _, w3 = self.f
+        return Fn.BottleneckFn.apply(x, bn1.weight, bn1.bias, w1.weight, bn2.weight, bn2.bias, wg.weight,
+                                     bn3.weight, bn3.bias, w3.weight, self)
 
 
 class EncBlock(tnn.Module):
-    """Conv2d(4, s2, p1, no bias) -> BN -> GELU -> bottlenecks — reference :27-36."""
+    """stride-2 4x4 convolution, BatchNorm, GELU (`down`), then `num_blocks` bottlenecks (`res`) — reference :27-36"""
 
     def __init__(self, in_ch: int, out_ch: int, num_blocks: int = 2, groups: int = 8):
         super().__init__()
-        self.down = tnn.Sequential(
-            wnn.Conv2d(in_ch, out_ch, 4, stride=2, padding=1, bias=False),
-            wnn.BatchNorm2d(out_ch), wnn.GELU(),
-        )
-        self.res = tnn.Sequential(*[Bottleneck(out_ch, groups) for _ in range(num_blocks)])
+        halve = wnn.Conv2d(in_ch, out_ch, 4, stride=2, padding=1, bias=False)
+        self.down = tnn.Sequential(halve, wnn.BatchNorm2d(out_ch), wnn.GELU())
+        self.res = _residual_stack(out_ch, num_blocks, groups)
 
     def forward(self, x):
-        d = self.down
-        return self.res(Fn.DownUnitFn.apply(x, d[0].weight, d[1].weight, d[1].bias, d[1]))
+        conv, bn, _ = self.down
+        return self.res(Fn.DownUnitFn.apply(x, conv.weight, bn.weight, bn.bias, bn))
 
 
 class DecBlock(tnn.Module):
-    """ConvTranspose2d(4, s2, p1, no bias) -> BN -> GELU -> bottlenecks — reference :38-47."""
+    """stride-2 4x4 transposed convolution, BatchNorm, GELU (`up`), then the bottlenecks (`res`) — reference :38-47"""
 
     def __init__(self, in_ch: int, out_ch: int, num_blocks: int = 2, groups: int = 8):
         super().__init__()
-        self.up = tnn.Sequential(
-            wnn.ConvTranspose2d(in_ch, out_ch, 4, stride=2, padding=1, bias=False),
-            wnn.BatchNorm2d(out_ch), wnn.GELU(),
-        )
-        self.res = tnn.Sequential(*[Bottleneck(out_ch, groups) for _ in range(num_blocks)])
+        double = wnn.ConvTranspose2d(in_ch, out_ch, 4, stride=2, padding=1, bias=False)
+        self.up = tnn.Sequential(double, wnn.BatchNorm2d(out_ch), wnn.GELU())
+        self.res = _residual_stack(out_ch, num_blocks, groups)
 
     def forward(self, x):
-        u = self.up
-        return self.res(Fn.UpUnitFn.apply(x, u[0].weight, u[1].weight, u[1].bias, u[1]))
+        convt, bn, _ = self.up
+        return self.res(Fn.UpUnitFn.apply(x, convt.weight, bn.weight, bn.bias, bn))
 
 
 class PosAwareAE_TF(tnn.Module):
-    """Conv autoencoder 1xHxW -> latent_dim -> 1xHxW — reference :52-106."""
+    """1 x H x W frame -> `latent_dim` vector -> 1 x H x W reconstruction in (0, 1) — reference :52-106.
+    `enc`: four EncBlocks (1/16 resolution, 1024 channels) + 1x1 to `latent_channels`, learned `pos_emb` added,
+    `to_latent` / `from_latent` linear bottleneck, `dec`: 1x1, four DecBlocks, 3x3 to the image, sigmoid."""
 
     def __init__(self, in_channels: int = 1, latent_channels: int = 64, groups: int = 8,
                  latent_dim: int = 2048, *, img_size: int = 128):
         super().__init__()
-        assert img_size % 16 == 0
-        self.latent_channels = latent_channels
-        self.img_size = img_size
-        hw = img_size // 16
-        self.latent_hw = hw
+        if img_size % 16:
+            raise ValueError("img_size must be a multiple of 16 (four stride-2 stages)")
+        self.img_size, self.latent_channels = img_size, latent_channels
+        side = self.latent_hw = img_size // 16
+        flat = side * side * latent_channels
 
-        self.enc = tnn.Sequential(
-            EncBlock(in_channels, 256, num_blocks=4, groups=groups),
-            EncBlock(256, 512, num_blocks=4, groups=groups),
-            EncBlock(512, 1024, num_blocks=4, groups=groups),
-            EncBlock(1024, 1024, num_blocks=4, groups=groups),
-            wnn.Conv2d(1024, latent_channels, 1),
-        )
-        self.pos_emb = tnn.Parameter(torch.randn(1, latent_channels, hw, hw))
+        stages, c_prev = [], in_channels
+        for width in _ENC_WIDTHS:
+            stages.append(EncBlock(c_prev, width, num_blocks=_BLOCKS_PER_STAGE, groups=groups))
+            c_prev = width
+        self.enc = tnn.Sequential(*stages, wnn.Conv2d(c_prev, latent_channels, 1))
+        self.pos_emb = tnn.Parameter(torch.randn(1, latent_channels, side, side))
+        self.to_latent = wnn.Linear(flat, latent_dim)
+        self.from_latent = wnn.Linear(latent_dim, flat)
 
-        self.to_latent = wnn.Linear(hw * hw * latent_channels, latent_dim)
-        self.from_latent = wnn.Linear(latent_dim, hw * hw * latent_channels)
-
-        self.dec = tnn.Sequential(
-            wnn.Conv2d(latent_channels, 1024, 1),
-            DecBlock(1024, 1024, num_blocks=4, groups=groups),
-            DecBlock(1024, 512, num_blocks=4, groups=groups),
-            DecBlock(512, 256, num_blocks=4, groups=groups),
-            DecBlock(256, 128, num_blocks=4, groups=groups),
-            wnn.Conv2d(128, in_channels, 3, padding=1),
-        )
+        stages, c_prev = [wnn.Conv2d(latent_channels, _DEC_WIDTHS[0], 1)], _DEC_WIDTHS[0]
+        for width in _DEC_WIDTHS:
+            stages.append(DecBlock(c_prev, width, num_blocks=_BLOCKS_PER_STAGE, groups=groups))
+            c_prev = width
+        self.dec = tnn.Sequential(*stages, wnn.Conv2d(c_prev, in_channels, 3, padding=1))
         self.act = wnn.Sigmoid()
 
     def encode(self, x):
-        # enc(x) + pos_emb -> flatten -> to_latent (reference :88-94); the
-        # broadcast pos_emb add is fused into the epilogue of the enc[4] 1x1 conv.
-        h = x
-        for blk in list(self.enc)[:-1]:
-            h = blk(h)
-        last = self.enc[-1]
-        z = Fn.Conv1x1Fn.apply(h, last.weight, last.bias, self.pos_emb)
-        return self.to_latent(z.flatten(1))
+        """frames -> latent vector (reference :88-94); the broadcast `pos_emb` add rides in the epilogue of the
+        1x1 convolution that closes `enc`"""
+        *blocks, to_channels = self.enc
+        for blk in blocks:
+            x = blk(x)
+        grid = Fn.Conv1x1Fn.apply(x, to_channels.weight, to_channels.bias, self.pos_emb)
+        return self.to_latent(grid.flatten(1))
 
     def decode(self, z_flat):
-        B = z_flat.size(0)
-        z = self.from_latent(z_flat)
-        z = z.view(B, self.latent_channels, self.latent_hw, self.latent_hw)
-        return self.act(self.dec(z))
+        """latent vector -> reconstruction (reference :96-102)"""
+        grid = self.from_latent(z_flat).view(z_flat.size(0), self.latent_channels, self.latent_hw, self.latent_hw)
+        return self.act(self.dec(grid))
 
     def forward(self, x):
         z = self.encode(x)

@@ -89,29 +89,37 @@ class GlobalCrossDecode(tnn.Module):
         return Fn.RepeatRowsFn.apply(o, l).view(b, l, e)
 
 
+# geometry of AE_ViT_2048 (reference :88-94): 128x128 frames, 16x16 patches -> 8x8 = 64 tokens of width 512,
+# one 2048-wide latent, six transformer blocks on each side, eight heads
+_IMG, _PATCH, _CH = 128, 16, 1
+_D_TOKEN, _D_LATENT = 512, 2048
+_DEPTH_ENC = _DEPTH_DEC = 6
+_HEADS = 8
+
+
+def _transformer(depth):
+    """`depth` post-norm GELU blocks (d_model 512, ff 2048, dropout 0.1, batch_first) — reference :104-109, :118-123"""
+    block = wnn.TransformerEncoderLayer(d_model=_D_TOKEN, nhead=_HEADS, dim_feedforward=4 * _D_TOKEN, dropout=0.1,
+                                        activation="gelu", batch_first=True)
+    return wnn.TransformerEncoder(block, depth, enable_nested_tensor=False)
+
+
 class AE_ViT_2048(tnn.Module):
     def __init__(self):
         super().__init__()
-        img, patch, ch = 128, 16, 1
-        seq = img // patch
-        n_patches = seq * seq
-        d_token, d_latent = 512, 2048
-        depth_enc, depth_dec, heads = 6, 6, 8
-        self.seq, self.d_token = seq, d_token
-        self.d_latent = d_latent
-        self.patch_embed = tnn.Conv2d(ch, d_token, patch, patch)           # parameters only; forward below
-        self.pos_embed = tnn.Parameter(torch.randn(1, n_patches, d_token))
-        enc_layer = wnn.TransformerEncoderLayer(d_model=d_token, nhead=heads, dim_feedforward=4 * d_token,
-                                                dropout=0.1, activation="gelu", batch_first=True)
-        self.encoder = wnn.TransformerEncoder(enc_layer, depth_enc, enable_nested_tensor=False)
-        self.query_vec = tnn.Parameter(torch.randn(1, 1, d_latent))
-        self.to_latent = GlobalCrossEncode(d_token, d_latent, n_heads=heads)
-        self.dec_queries = tnn.Parameter(torch.randn(1, n_patches, d_token))
-        self.from_latent = GlobalCrossDecode(d_token, d_latent, n_heads=heads)
-        dec_layer = wnn.TransformerEncoderLayer(d_model=d_token, nhead=heads, dim_feedforward=4 * d_token,
-                                                dropout=0.1, activation="gelu", batch_first=True)
-        self.decoder = wnn.TransformerEncoder(dec_layer, depth_dec, enable_nested_tensor=False)
-        self.unpatch = tnn.ConvTranspose2d(d_token, ch, patch, patch)      # parameters only
+        self.seq = _IMG // _PATCH
+        self.d_token, self.d_latent = _D_TOKEN, _D_LATENT
+        n_tok = self.seq ** 2
+        # registration order = the reference's state_dict order
+        self.patch_embed = tnn.Conv2d(_CH, _D_TOKEN, _PATCH, _PATCH)            # parameters only; forward below
+        self.pos_embed = tnn.Parameter(torch.randn(1, n_tok, _D_TOKEN))
+        self.encoder = _transformer(_DEPTH_ENC)
+        self.query_vec = tnn.Parameter(torch.randn(1, 1, _D_LATENT))
+        self.to_latent = GlobalCrossEncode(_D_TOKEN, _D_LATENT, n_heads=_HEADS)
+        self.dec_queries = tnn.Parameter(torch.randn(1, n_tok, _D_TOKEN))
+        self.from_latent = GlobalCrossDecode(_D_TOKEN, _D_LATENT, n_heads=_HEADS)
+        self.decoder = _transformer(_DEPTH_DEC)
+        self.unpatch = tnn.ConvTranspose2d(_D_TOKEN, _CH, _PATCH, _PATCH)       # parameters only
 
     def encode_tokens(self, x):
         b = x.size(0)

@@ -73,6 +73,12 @@ int wfae_linear_bwd_data(const float* dy, const float* w, float* dx, int B, int 
                          wfae_stream_t stream);
 int wfae_linear_bwd_weight(const float* dy, const float* x, float* dw, int B, int In, int Out,
                            int accumulate, wfae_stream_t stream);
+/* the same with the batch dimension split across workgroups (deterministic slab reduce): for layers whose
+ * Out x In tile grid is much smaller than the chip (transformer blocks) */
+int wfae_linear_bwd_data_splitk(const float* dy, const float* w, float* dx, int B, int In, int Out, void* ws,
+                                size_t ws_bytes, wfae_stream_t stream);
+int wfae_linear_bwd_weight_splitk(const float* dy, const float* x, float* dw, int B, int In, int Out, int accumulate,
+                                  void* ws, size_t ws_bytes, wfae_stream_t stream);
 
 /* ---- 4x4 stride-2 pad-1 convolution pair ---------------------------------
  * "hi" = the 2H x 2W side with Chi channels, "lo" = the H x W side with Clo

@@ -1319,6 +1319,27 @@ int wfae_linear_bwd_data(const float* dy, const float* w, float* dx, int B, int 
   return launch_gemm<A_KCONTIG, B_NCONTIG, E_BATCHED>(p, 1, (hipStream_t)stream, "linear_bwd_data");
 }
 
+// dx = dy w with the Out dimension split over blockIdx.z (see wfae_linear_bwd_weight_splitk)
+int wfae_linear_bwd_data_splitk(const float* dy, const float* w, float* dx, int B, int In, int Out, void* ws,
+                                size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(dy && w && dx, WFAE_ERR_NULL_POINTER, "linear_bwd_data_splitk: null pointer");
+  WFAE_REQUIRE(B > 0 && In > 0 && Out > 0, WFAE_ERR_BAD_SHAPE, "linear_bwd_data_splitk: bad shape");
+  const size_t slab = (size_t)B * In * sizeof(float);
+  WFAE_REQUIRE(ws && ws_bytes >= slab, WFAE_ERR_WORKSPACE, "linear_bwd_data_splitk: workspace %zu < %zu", ws_bytes, slab);
+  GemmP p = {};  // dx(m=b, n=i) = sum_o dy[b,o] w[o,i]
+  p.A = dy; p.B = w; p.C = (float*)ws;
+  p.M = B; p.N = In; p.K = Out;
+  p.a_hw = Out; p.a_img = 0; p.a_ld = Out;
+  p.b_hw = In; p.b_img = 0; p.b_ld = In;
+  p.a_vec = (Out % 4 == 0) && aligned16(dy);
+  p.b_vec = (In % 4 == 0) && aligned16(w);
+  p.c_vec = (In % 4 == 0) && aligned16(ws);
+  const int splits = pick_splits(p.M, p.N, p.K, ws_bytes, &p.k_per_split);
+  int rc = launch_gemm<A_KCONTIG, B_NCONTIG, E_SLAB>(p, splits, (hipStream_t)stream, "linear_bwd_data_splitk");
+  if (rc) return rc;
+  return splitk_finish((float*)ws, dx, nullptr, (long)B * In, In, splits, 0, (hipStream_t)stream);
+}
+
 int wfae_linear_bwd_weight(const float* dy, const float* x, float* dw, int B, int In, int Out,
                            int accumulate, wfae_stream_t stream) {
   WFAE_REQUIRE(dy && x && dw, WFAE_ERR_NULL_POINTER, "linear_bwd_weight: null pointer");
@@ -1334,6 +1355,28 @@ int wfae_linear_bwd_weight(const float* dy, const float* x, float* dw, int B, in
   p.b_vec = (In % 4 == 0) && aligned16(x);
   p.c_vec = (In % 4 == 0) && aligned16(dw);
   return launch_gemm<A_MCONTIG, B_NCONTIG, E_BATCHED>(p, 1, (hipStream_t)stream, "linear_bwd_weight");
+}
+
+// the same product with the batch dimension split over blockIdx.z: transformer-sized layers (a few thousand rows,
+// 512..2048 features) give only Out/128 * In/128 = 16..64 tiles, far fewer than the 256 CUs
+int wfae_linear_bwd_weight_splitk(const float* dy, const float* x, float* dw, int B, int In, int Out, int accumulate,
+                                  void* ws, size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(dy && x && dw, WFAE_ERR_NULL_POINTER, "linear_bwd_weight_splitk: null pointer");
+  WFAE_REQUIRE(B > 0 && In > 0 && Out > 0, WFAE_ERR_BAD_SHAPE, "linear_bwd_weight_splitk: bad shape");
+  const size_t slab = (size_t)Out * In * sizeof(float);
+  WFAE_REQUIRE(ws && ws_bytes >= slab, WFAE_ERR_WORKSPACE, "linear_bwd_weight_splitk: workspace %zu < %zu", ws_bytes, slab);
+  GemmP p = {};
+  p.A = dy; p.B = x; p.C = (float*)ws;
+  p.M = Out; p.N = In; p.K = B;
+  p.a_ld = Out;
+  p.b_hw = In; p.b_img = 0; p.b_ld = In;
+  p.a_vec = (Out % 4 == 0) && aligned16(dy);
+  p.b_vec = (In % 4 == 0) && aligned16(x);
+  p.c_vec = (In % 4 == 0) && aligned16(ws);
+  const int splits = pick_splits(p.M, p.N, p.K, ws_bytes, &p.k_per_split);
+  int rc = launch_gemm<A_MCONTIG, B_NCONTIG, E_SLAB>(p, splits, (hipStream_t)stream, "linear_bwd_weight_splitk");
+  if (rc) return rc;
+  return splitk_finish((float*)ws, dw, nullptr, (long)Out * In, In, splits, accumulate, (hipStream_t)stream);
 }
 
 int wfae_conv4x4s2_down(const float* hi, const float* w, float* lo, int NB, int Chi, int Clo,

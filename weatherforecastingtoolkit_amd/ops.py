@@ -126,6 +126,12 @@ def linear_bwd_data(dy, w):
     b, out = dy.shape
     inf = w.shape[1]
     dx = torch.empty((b, inf), dtype=dy.dtype, device=dy.device)
+    tiles = ((b + 127) // 128) * ((inf + 127) // 128)
+    if tiles < 256 and out >= 512:    # few output tiles, long reduction: split it
+        ws = workspace(b * inf * 4 * 2)
+        _call("wfae_linear_bwd_data_splitk", 2 * b * inf * out, 4 * (inf * out + b * (inf + out)), _p(dy), _p(w), _p(dx), b, inf,
+              out, ws.data_ptr(), ws.numel(), _stream())
+        return dx
     _call("wfae_linear_bwd_data", 2 * b * inf * out, 4 * (inf * out + b * (inf + out)), _p(dy), _p(w), _p(dx), b, inf, out, _stream())
     return dx
 
@@ -134,6 +140,12 @@ def linear_bwd_weight(dy, x, dw, accumulate=False):
     _chk(dy, x, dw)
     b, out = dy.shape
     inf = x.shape[1]
+    tiles = ((out + 127) // 128) * ((inf + 127) // 128)
+    if tiles < 256 and b >= 256:      # few output tiles, long batch dimension: split it (transformer layers)
+        ws = workspace(out * inf * 4 * 2)
+        _call("wfae_linear_bwd_weight_splitk", 2 * b * inf * out, 4 * (inf * out + b * (inf + out)), _p(dy), _p(x), _p(dw), b, inf,
+              out, int(accumulate), ws.data_ptr(), ws.numel(), _stream())
+        return dw
     _call("wfae_linear_bwd_weight", 2 * b * inf * out, 4 * (inf * out + b * (inf + out)), _p(dy), _p(x), _p(dw), b, inf, out, int(accumulate), _stream())
     return dw
 

@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run weight gradients on the main stream")
+    ap.add_argument("--precision", choices=["highest", "medium"], default="highest",
+                    help="'medium' = bf16 MFMA operands (BASELINE config 5's arithmetic; NOT the headline "
+                         "configuration — the line is then labelled dtype bf16)")
     args = ap.parse_args()
 
     import torch
@@ -128,6 +131,7 @@ def main():
     dev = torch.device("cuda", local)
 
     Fn.set_wgrad_overlap(not args.no_overlap)
+    ops.set_float32_matmul_precision(args.precision)
     torch.manual_seed(0)  # identical random-init weights on every rank (then broadcast anyway)
     net = PosAwareAE_TF(img_size=args.img_size).to(dev).train()
     opt = FusedAdamW(net.parameters(), lr=5e-5, betas=(0.9, 0.999), weight_decay=1e-4)
@@ -188,9 +192,10 @@ def main():
             "metric": "SEVIR 384x384 frames/sec (AE train step)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "highest" else "bf16", "data": "synthetic",
             "config": {"workload": f"experiments/ae_v2 conv AE (ae_64x8x8_lin.PosAwareAE_TF, img_size={S}), "
-                                   f"1x{S}x{S} synthetic SEVIR frames, batch {B}/GPU, fp32, "
+                                   f"1x{S}x{S} synthetic SEVIR frames, batch {B}/GPU, "
+                                   f"{'fp32' if args.precision == 'highest' else 'bf16 MFMA operands / fp32 tensors'}, "
                                    "fwd + L1 + bwd + AdamW + cosine-warmup LR",
                        "batch_per_gpu": B, "global_batch": B * world, "img_size": S,
                        "parallelism": f"dp{world}", "params": sum(p.numel() for p in net.parameters())},

@@ -19,7 +19,8 @@
  *   - return 0 on success, a negative wfae_status otherwise; never throws or
  *     aborts; wfae_last_error_string() describes the calling thread's last
  *     failure;
- *   - re-entrant and thread-safe: no mutable global state.
+ *   - re-entrant and thread-safe: no mutable global state except the
+ *     matmul-precision mode below (one atomic int, set once at start-up);
  *   - `accumulate` != 0 means "out += result" (gradient accumulation),
  *     0 means "out = result".
  */
@@ -49,6 +50,19 @@ const char* wfae_last_error_string(void);
 /* upper bound of scratch bytes any single call needs for a problem whose
  * largest weight tensor has `max_weight_elems` elements. */
 size_t wfae_workspace_bytes(int64_t max_weight_elems);
+
+/* ---- arithmetic mode of the MFMA GEMM family ------------------------------
+ * counterpart of torch.set_float32_matmul_precision(...), which the reference
+ * calls once at start-up (experiments/ae_v2/train.py:270, ae_v2_2/train.py:223)
+ * and of BASELINE config 5 ("bf16").  WFAE_PRECISION_FP32 (default): operands
+ * and accumulation in fp32 (v_mfma_f32_32x32x2_f32).  WFAE_PRECISION_BF16:
+ * tensors stay fp32 in HBM; every GEMM-family kernel (1x1 / linear / 4x4 /
+ * Winograd / flat-shift convolutions, all three roles) rounds its two operands
+ * to bf16 (RNE) on the way from LDS to the matrix core and accumulates in fp32
+ * (v_mfma_f32_32x32x16_bf16) — torch's 'medium'.  Process-wide; read at launch. */
+enum { WFAE_PRECISION_FP32 = 0, WFAE_PRECISION_BF16 = 1 };
+int wfae_set_matmul_precision(int mode);
+int wfae_get_matmul_precision(void);
 
 /* ---- 1x1 convolution as an fp32-MFMA GEMM on NCHW ------------------------
  * replaces nn.Conv2d(C, C/4, 1) / (C/4, C, 1) in Bottleneck

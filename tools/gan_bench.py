@@ -29,8 +29,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-gan", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--precision", choices=["highest", "medium"], default="highest")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    ops.set_float32_matmul_precision(a.precision)
     cfg = C.load(os.path.join(os.path.dirname(pkg.__file__), "config.yaml"), CARRIED_KEYS)
     cfg.trainer.total_train_steps = 1000
     cfg.lpips.disc_start = 10 ** 9 if a.no_gan else 0
@@ -47,7 +49,8 @@ def main():
         model.training_step({"vil": x}, 0)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / a.steps
-    print(json.dumps({"workload": f"ae_v2_2 AE{'' if a.no_gan else '+GAN'} step {a.size}x{a.size} B={a.batch} fp32",
+    print(json.dumps({"workload": f"ae_v2_2 AE{'' if a.no_gan else '+GAN'} step {a.size}x{a.size} B={a.batch} "
+                                  f"{'fp32' if a.precision == 'highest' else 'bf16 operands'}",
                       "ms_per_step": ms, "frames_per_s": a.batch / ms * 1e3,
                       "mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30}), flush=True)
     Fn.set_wgrad_overlap(False)

@@ -1,7 +1,13 @@
 // api.hip — library-level entry points of libwfae.so (version, errors, workspace sizing).
 #include "common.h"
+#include <atomic>
 
 namespace wfae {
+
+// process-wide arithmetic mode of the MFMA GEMM family, the counterpart of torch.set_float32_matmul_precision
+// (which the reference sets once at start-up, experiments/ae_v2/train.py:270): 0 = fp32 MFMA, 1 = bf16 operands
+static std::atomic<int> g_matmul_precision{0};
+int matmul_precision() { return g_matmul_precision.load(std::memory_order_relaxed); }
 
 char* err_buf() {
   static thread_local char buf[512] = "ok";
@@ -21,6 +27,15 @@ int fail(int code, const char* fmt, ...) {
 extern "C" {
 
 int wfae_version(void) { return 100; }  // 0.1.0
+
+int wfae_set_matmul_precision(int mode) {
+  WFAE_REQUIRE(mode == WFAE_PRECISION_FP32 || mode == WFAE_PRECISION_BF16, WFAE_ERR_BAD_SHAPE,
+               "set_matmul_precision: unknown mode %d", mode);
+  wfae::g_matmul_precision.store(mode, std::memory_order_relaxed);
+  return WFAE_OK;
+}
+
+int wfae_get_matmul_precision(void) { return wfae::matmul_precision(); }
 
 const char* wfae_last_error_string(void) { return wfae::err_buf(); }
 

@@ -11,6 +11,7 @@ namespace wfae {
 // thread-local last-error text (wfae_last_error_string)
 char* err_buf();
 int fail(int code, const char* fmt, ...);
+int matmul_precision();  // api.hip: WFAE_PRECISION_*
 
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();

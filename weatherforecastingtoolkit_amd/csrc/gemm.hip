@@ -22,6 +22,7 @@ using namespace wfae;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -105,8 +106,11 @@ __device__ __forceinline__ float4 load4u(const float* ptr) {
 // a stage back-to-back and waits once, after the MFMAs of the current stage.
 // second launch-bound argument = minimum waves per SIMD: 2 for the 256-row tile (128 accumulator registers),
 // 4 otherwise (3 for the down/up gathers, which spill at 128) — the unified VGPR/AGPR file has 512 entries per lane and SIMD
-template <int BM, int WMW, int WNW, int AK, int BKD, int EK, bool VEC, int MF>
-__global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP) ? 3 : 4))) void gemm_kernel(GemmP p) {
+// PREC: WFAE_PRECISION_FP32 — v_mfma_f32_32x32x2_f32; WFAE_PRECISION_BF16 — same loaders, LDS images and epilogue,
+// but the operand fragments are rounded to bf16 (v_cvt_pk_bf16_f32, RNE) after the LDS read and one
+// v_mfma_f32_32x32x16_bf16 consumes a whole 16-deep stage (fp32 accumulation).
+template <int BM, int WMW, int WNW, int AK, int BKD, int EK, bool VEC, int MF, int PREC = 0>
+__global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP || PREC == 1) ? 3 : 4))) void gemm_kernel(GemmP p) {
   static_assert(WMW * WNW == 4, "4 waves");
   static_assert(MF == 32, "v_mfma_f32_32x32x2_f32 (the 16x16x4 form measured the same rate and was dropped)");
   constexpr int WROWS = BM / WMW, WCOLS = BN / WNW;  // wave tile
@@ -824,6 +828,32 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
   typedef float vecB __attribute__((ext_vector_type(TN)));
   auto compute = [&](int buf) {
     static_assert(MF == 32, "interleaved operand reads are built for v_mfma_f32_32x32x2_f32");
+    if constexpr (PREC == 1) {
+      // lane half lh supplies k = 8 lh .. 8 lh + 7 of both operands (any k order both operands share is a
+      // valid contraction order); BK == 16 is exactly one MFMA deep
+      static_assert(BK == 16, "one v_mfma_f32_32x32x16_bf16 per stage");
+      vecA af[8];
+      vecB bfr[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        af[q] = *reinterpret_cast<const vecA*>(&As[buf][lh * 8 + q][wm0 + l31 * TM]);
+        bfr[q] = *reinterpret_cast<const vecB*>(&Bs[buf][lh * 8 + q][wn0 + l31 * TN]);
+      }
+      bf16x8 a8[TM], b8[TN];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a8[i][q] = (__bf16)af[q][i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b8[j][q] = (__bf16)bfr[q][j];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+      return;
+    }
     constexpr int NSTEP = BK / 2;
     vecA a[2];
     vecB b[2];
@@ -1147,6 +1177,21 @@ int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what,
   dim3 block(NT);
   bool big = false;
   if constexpr (VEC) {
+    if (wfae::matmul_precision() == WFAE_PRECISION_BF16) {
+      // bf16 operands: the MFMA time of a stage falls 16x, the kernels turn loader / HBM bound and the
+      // 128-row tile (4 waves per SIMD) hides that latency best
+      if (p.M > 64) {
+        dim3 grid(cdiv(p.M, 128) * ntiles, ydim, zdim);
+        hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, true, 32, 1>), grid, block, 0, st, p);
+      } else if (p.M > 32) {
+        dim3 grid(cdiv(p.M, 64) * ntiles, ydim, zdim);
+        hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK, true, 32, 1>), grid, block, 0, st, p);
+      } else {
+        dim3 grid(ntiles, ydim, zdim);
+        hipLaunchKernelGGL((gemm_kernel<32, 1, 4, AK, BKD, EK, true, 32, 1>), grid, block, 0, st, p);
+      }
+      return check_launch(what);
+    }
     // measured (tools/kbench.py): pays for the gather GEMMs once the grid fills the 512 resident slots twice
     constexpr bool gather = BKD == B_DOWN || BKD == B_UP || BKD == B_WGRAD;
     if ((gather || p.big_ok) && use256 && p.M >= 256 && (long)cdiv(p.M, 256) * ntiles * zdim * ydim >= 1024) {

@@ -25,6 +25,7 @@ import torch.nn as tnn
 
 from ... import config as C
 from ... import functional as Fn
+from ... import ops
 from ... import parallel, synth
 from ...nn import flush_bn_counters
 from ...pipeline import helpers
@@ -89,6 +90,9 @@ def main(argv=None):
     ap.add_argument("--resume", type=bool, default=False)
     ap.add_argument("--config", default=os.path.join(HERE, "config.yaml"))
     ap.add_argument("--max-steps", type=int, default=-1, help="stop early (smoke runs)")
+    ap.add_argument("--matmul-precision", default="high", choices=["highest", "high", "medium"],
+                    help="reference: torch.set_float32_matmul_precision('high') (train.py main); 'medium' = bf16 "
+                         "MFMA operands (BASELINE config 5)")
     ap.add_argument("--data-dir", default=None, help="SEVIR root (CATALOG.csv + data/); default: synthetic events")
     ap.add_argument("--data-format", choices=("npy", "h5"), default="npy")
     ap.add_argument("--model", choices=("tf", "lin"), default="tf",
@@ -102,6 +106,7 @@ def main(argv=None):
     rank, world, local = parallel.init_from_env()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    ops.set_float32_matmul_precision(args.matmul_precision)
 
     size, frames = (384, 49) if cfg.dataset.name == "sevir" else (128, 25)
     if args.data_dir:

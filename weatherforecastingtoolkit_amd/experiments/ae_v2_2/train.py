@@ -25,6 +25,7 @@ import torch.nn as tnn
 
 from ... import config as C
 from ... import functional as Fn
+from ... import ops
 from ... import parallel, synth
 from ..._lib import WfaeError
 from ...nn import flush_bn_counters
@@ -179,6 +180,9 @@ def main(argv=None):
     ap.add_argument("--resume", type=bool, default=False)
     ap.add_argument("--config", default=os.path.join(HERE, "config.yaml"))
     ap.add_argument("--max-steps", type=int, default=-1, help="stop early (smoke runs)")
+    ap.add_argument("--matmul-precision", default="high", choices=["highest", "high", "medium"],
+                    help="reference: torch.set_float32_matmul_precision('high') (train.py main); 'medium' = bf16 "
+                         "MFMA operands (BASELINE config 5)")
     args, unknown = ap.parse_known_args(argv)
     cfg = C.load(args.config, CARRIED_KEYS)
     cli = C.from_dotlist(unknown)
@@ -188,6 +192,7 @@ def main(argv=None):
     rank, world, local = parallel.init_from_env()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    ops.set_float32_matmul_precision(args.matmul_precision)
 
     size, frames = (384, 49) if cfg.dataset.name == "sevir" else (128, 25)
     n_events = max(2, (cfg.dataset.batch_size * 8 * world) // (1 + (frames - cfg.dataset.seq_len) // cfg.dataset.stride) + 1)

@@ -166,6 +166,25 @@ def set_winograd(mode):
     _WINO_MODE = mode if isinstance(mode, str) else ("1" if mode else "0")
 
 
+_PRECISIONS = {"highest": 0, "high": 0, "medium": 1}
+
+
+def set_float32_matmul_precision(precision):
+    """Counterpart of torch.set_float32_matmul_precision, which the reference calls once at start-up
+    (experiments/ae_v2/train.py:270, 'high' = TF32 on its CUDA machines).  'highest' (default) and 'high': fp32
+    MFMA (gfx950 has no TF32/xf32 matrix instruction; fp32 is the next precision up).  'medium': every GEMM-family
+    kernel rounds its operands to bf16 on the way into the matrix core and accumulates in fp32, tensors stay fp32
+    (BASELINE config 5).  In 'medium' the automatic Winograd choice is F(2x2,2x2): the F(4x4,2x2) transforms
+    amplify operand rounding ~10x, which fp32 absorbs and bf16 does not."""
+    if precision not in _PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}, got {precision!r}")
+    _lib.call("wfae_set_matmul_precision", _PRECISIONS[precision])
+
+
+def get_float32_matmul_precision():
+    return "medium" if _lib.load().wfae_get_matmul_precision() == 1 else "highest"
+
+
 class WinoPlan:
     __slots__ = ("variant", "nb", "chi", "clo", "hlo", "wlo", "T", "nU", "nV", "nM")
 
@@ -199,6 +218,10 @@ def wino_plan(nb, chi, clo, hlo, wlo):
         return None
     if mode == "auto" and min(chi, clo) < 16:
         return None
+    if mode not in ("f22", "f42") and _lib.load().wfae_get_matmul_precision() == 1:
+        mode = os.environ.get("WFAE_WINO_BF16", "f22")
+        if mode == "0":
+            return None
     key = (nb, chi, clo, hlo, wlo)
     ck = (mode if mode in ("f22", "f42") else "a", key)
     pl = _plans.get(ck, False)

@@ -36,7 +36,11 @@ def rnd(*shape):
 
 
 def report(tag, ms, flops, nbytes):
-    print(f"{tag:58s} {ms:9.3f} ms  {flops / ms / 1e9:8.1f} TF/s  {nbytes / ms / 1e6:8.0f} GB/s", flush=True)
+    # ideal = the larger of the MFMA time at the LDS->MFMA structural ceiling (148 TF) and the HBM time at the
+    # achievable streaming rate (6.3 TB/s), i.e. perfect overlap of the two pipes
+    ideal = max(flops / 148e12, nbytes / 6.3e12) * 1e3
+    print(f"{tag:58s} {ms:9.3f} ms  {flops / ms / 1e9:8.1f} TF/s  {nbytes / ms / 1e6:8.0f} GB/s  "
+          f"ideal {ideal:7.3f} ms ({ideal / ms:4.0%})", flush=True)
 
 
 def main():
@@ -45,8 +49,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=384)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--precision", default="highest", choices=["highest", "medium"])
     a = ap.parse_args()
     only = set(a.only.split(","))
+    ops.set_float32_matmul_precision(a.precision)
     B, S, R = a.batch, a.size, a.rounds
     tot = {}
 

@@ -1194,14 +1194,16 @@ int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what,
     }
     // measured (tools/kbench.py): pays for the gather GEMMs once the grid fills the 512 resident slots twice
     constexpr bool gather = BKD == B_DOWN || BKD == B_UP || BKD == B_WGRAD;
-    if ((gather || p.big_ok) && use256 && p.M >= 256 && (long)cdiv(p.M, 256) * ntiles * zdim * ydim >= 1024) {
+    static const int bm_force256 = env_int("WFAE_BM_FORCE", 0) == 256;
+    if ((gather || p.big_ok || bm_force256) && use256 && p.M >= 256 && (long)cdiv(p.M, 256) * ntiles * zdim * ydim >= 1024) {
       big = true;
       dim3 grid(cdiv(p.M, 256) * ntiles, ydim, zdim);
       hipLaunchKernelGGL((gemm_kernel<256, 2, 2, AK, BKD, EK, true, 32>), grid, block, 0, st, p);
     }
   }
+  static const int bm_force = env_int("WFAE_BM_FORCE", 0);  // A/B only: 64 = never use the 128-row tile
   if (big) {
-  } else if (p.M > 64) {
+  } else if (p.M > 64 && bm_force != 64) {
     dim3 grid(cdiv(p.M, 128) * ntiles, ydim, zdim);
     hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, VEC, 32>), grid, block, 0, st, p);
   } else if (p.M > 32) {

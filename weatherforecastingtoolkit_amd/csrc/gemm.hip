@@ -1163,6 +1163,17 @@ inline int env_int(const char* name, int dflt) {
 // registers) halves the loads / LDS traffic / address arithmetic per MFMA — the SIMD issues VALU, LDS
 // and MFMA instructions from one port, so non-MFMA instructions per MFMA set the achieved rate
 // (PMC: SQ_VALU_MFMA_BUSY_CYCLES vs SQ_INSTS_VALU).  WFAE_BM256=0 disables it (A/B testing).
+// tile height: the tallest of 128 / 64 / 32 rows that M fills, stepped down while the grid would leave most of the
+// chip's 1024 resident-block slots empty (small batches, the 24x24 stage: 288 blocks of 128 rows ran 0.157 ms,
+// 576 of 64 rows 0.132 ms).  Large grids are unaffected.  WFAE_BM_FORCE=64 caps the height (A/B).
+inline int pick_bm(int M, long col_blocks) {
+  static const int bm_force = env_int("WFAE_BM_FORCE", 0);
+  int bm = M > 64 ? 128 : (M > 32 ? 64 : 32);
+  if (bm_force == 64 && bm > 64) bm = 64;
+  while (bm > 32 && (long)cdiv(M, bm) * col_blocks < 512) bm >>= 1;
+  return bm;
+}
+
 template <int AK, int BKD, int EK, bool VEC>
 int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what, int ydim = 1) {
   static const int use256 = env_int("WFAE_BM256", 1);
@@ -1179,15 +1190,16 @@ int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what,
   if constexpr (VEC) {
     if (wfae::matmul_precision() == WFAE_PRECISION_BF16) {
       // bf16 operands: the MFMA time of a stage falls 16x, the kernels turn loader / HBM bound and the
-      // 128-row tile (4 waves per SIMD) hides that latency best
-      if (p.M > 64) {
+      // 128-row tile (3 waves per SIMD) hides that latency best
+      const int bm = pick_bm(p.M, (long)ntiles * ydim * zdim);
+      if (bm == 128) {
         dim3 grid(cdiv(p.M, 128) * ntiles, ydim, zdim);
         hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, true, 32, 1>), grid, block, 0, st, p);
-      } else if (p.M > 32) {
+      } else if (bm == 64) {
         dim3 grid(cdiv(p.M, 64) * ntiles, ydim, zdim);
         hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK, true, 32, 1>), grid, block, 0, st, p);
       } else {
-        dim3 grid(ntiles, ydim, zdim);
+        dim3 grid(cdiv(p.M, 32) * ntiles, ydim, zdim);
         hipLaunchKernelGGL((gemm_kernel<32, 1, 4, AK, BKD, EK, true, 32, 1>), grid, block, 0, st, p);
       }
       return check_launch(what);
@@ -1201,16 +1213,16 @@ int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what,
       hipLaunchKernelGGL((gemm_kernel<256, 2, 2, AK, BKD, EK, true, 32>), grid, block, 0, st, p);
     }
   }
-  static const int bm_force = env_int("WFAE_BM_FORCE", 0);  // A/B only: 64 = never use the 128-row tile
+  const int bm = big ? 256 : pick_bm(p.M, (long)ntiles * ydim * zdim);
   if (big) {
-  } else if (p.M > 64 && bm_force != 64) {
+  } else if (bm == 128) {
     dim3 grid(cdiv(p.M, 128) * ntiles, ydim, zdim);
     hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, VEC, 32>), grid, block, 0, st, p);
-  } else if (p.M > 32) {
+  } else if (bm == 64) {
     dim3 grid(cdiv(p.M, 64) * ntiles, ydim, zdim);
     hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK, VEC, 32>), grid, block, 0, st, p);
   } else {
-    dim3 grid(ntiles, ydim, zdim);
+    dim3 grid(cdiv(p.M, 32) * ntiles, ydim, zdim);
     hipLaunchKernelGGL((gemm_kernel<32, 1, 4, AK, BKD, EK, VEC, 32>), grid, block, 0, st, p);
   }
   return check_launch(what);

@@ -157,12 +157,10 @@ class FusedAdamW(torch.optim.Optimizer):
             for i, p in enumerate(g["params"]):
                 if p.grad is None:
                     continue
-                if True:
-                    st = self.state[p]
-                    if not st:
-                        st["m"], st["v"] = torch.zeros_like(p).view(-1), torch.zeros_like(p).view(-1)
-                    m, v, pd = st["m"], st["v"], p.data.view(-1)
-                ops.adamw_(pd, p.grad.contiguous().view(-1), m, v, *args)
+                st = self.state[p]
+                if not st:
+                    st["m"], st["v"] = torch.zeros_like(p).view(-1), torch.zeros_like(p).view(-1)
+                ops.adamw_(p.data.view(-1), p.grad.contiguous().view(-1), st["m"], st["v"], *args)
         return loss
 
 

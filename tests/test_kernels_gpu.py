@@ -230,9 +230,11 @@ def test_gan_elementwise(ops, dev):
 
 
 @pytest.mark.parametrize("nb,c,h,w", [(2, 32, 16, 16), (1, 64, 24, 40), (2, 128, 24, 24), (2, 256, 8, 8), (1, 256, 24, 24),
-                                      (3, 32, 7, 9), (1, 64, 33, 35)])
+                                      (3, 32, 7, 9), (1, 64, 33, 35),
+                                      (1, 256, 48, 48), (2, 256, 16, 32), (2, 128, 32, 16), (1, 128, 96, 96), (3, 256, 16, 16)])
 def test_gconv3x3_blocked(ops, dev, nb, c, h, w):
-    """register-blocked grouped 3x3 (4/8/16/32 channels per group): fwd, dgrad, MFMA wgrad"""
+    """grouped 3x3 (4/8/16/32 channels per group): fwd, dgrad (register-blocked VALU kernel; the MFMA kernel for 16 / 32
+    channels per group on sizes that are multiples of 16), MFMA wgrad"""
     groups = 8
     x, wt, dy = rnd((nb, c, h, w), 1), rnd((c, c // groups, 3, 3), 2, -0.3, 0.3), rnd((nb, c, h, w), 3)
     xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)

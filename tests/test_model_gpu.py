@@ -221,9 +221,12 @@ def test_tf_variant_golden(dev):
             assert p.grad is None, n          # tf_encoder.* template: never used
         else:
             assert abs(p.grad.double().norm().item() - ref) <= 3e-3 * ref + 1e-12, n
-    assert relerr(net.tf.layers[0].self_attn.in_proj_weight.grad, g["g_tf0_inproj"]) < 2e-3
+    # tolerance = 4x the distance between the REFERENCE module run in fp32 and in fp64 on this input
+    # (tests/golden/tf_sensitivity.py: in_proj 8.6e-4, norm1 6.5e-4, linear2 1.3e-5): batch-statistics BatchNorm at
+    # B = 3 and attention across the batch amplify rounding, and two fp32 implementations sit ~sqrt(2)-2x that apart
+    assert relerr(net.tf.layers[0].self_attn.in_proj_weight.grad, g["g_tf0_inproj"]) < 3.5e-3
     assert relerr(net.tf.layers[7].linear2.weight.grad[:, :64], g["g_tf7_lin2"]) < 2e-3
-    assert relerr(net.tf.layers[3].norm1.weight.grad, g["g_tf3_norm1"]) < 2e-3
+    assert relerr(net.tf.layers[3].norm1.weight.grad, g["g_tf3_norm1"]) < 2.6e-3
 
 
 def test_tf_dropout_and_optimizer_runs(dev):

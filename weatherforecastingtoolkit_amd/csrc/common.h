@@ -107,5 +107,7 @@ int slab_reduce(const float* slab, float* out, const float* bias_n, long MN, int
 // pixel-parallel VALU weight gradient of the grouped 3x3 conv (dconv.hip); WFAE_ERR_UNSUPPORTED if the shape is not covered
 int gconv3_wgrad_valu(const float* dy, const float* x, float* dw, int NB, int C, int H, int W, int groups,
                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+int gconv3_wgrad_mfma(const float* dy, const float* x, float* dw, int NB, int C, int H, int W, int groups,
+                      int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace wfae

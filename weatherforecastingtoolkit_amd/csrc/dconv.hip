@@ -8,6 +8,7 @@
 // output channels in registers.
 #include <stdlib.h>
 #include "common.h"
+#include <type_traits>
 
 using namespace wfae;
 
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256) void gconv3_kernel(const float* __restrict__ x
       xs[c][ry][rx] = v;
     }
     __syncthreads();
-#pragma unroll 1
+#pragma unroll 1  // measured: 2 and 4 are slower at 4 / 8 channels per group (SGPR pressure of the weight loads)
     for (int c = 0; c < CIB; ++c) {
       float in[PY + 2][4];
 #pragma unroll
@@ -454,6 +455,142 @@ __global__ __launch_bounds__(256) void gconv3_kernel(const float* __restrict__ x
   }
 }
 
+// -------------------------------------------------------------------------------------
+// MFMA form of the same convolution for 16 / 32 channels per group (the 512@96, 1024@48 and 1024@24 stages):
+// per group it is a GEMM  Y[oc][pixel] = sum_k W[oc][k] X[k][pixel],  k = (ci, tap), with M = CPG rows — one
+// v_mfma_f32_32x32x2_f32 (CPG = 32) or v_mfma_f32_16x16x4_f32 (CPG = 16) tile.  A block owns a 16 x 16 pixel
+// tile of one (image, group); the input patch (+halo) and the packed weights of 8 input channels at a time are
+// staged in LDS (double-buffered through registers).  The k lanes of an MFMA (lane / CPG) take input channels
+// CSTEP apart with the SAME tap, so both operand fragments are one ds_read_b32 at a per-lane base plus a
+// compile-time immediate: no address arithmetic in the fully unrolled k loop.  A wave computes 4 tile rows
+// (2 / 4 N tiles); the VALU kernel above reaches ~44 TF on these shapes.
+// -------------------------------------------------------------------------------------
+typedef float g3_f32x16 __attribute__((ext_vector_type(16)));
+typedef float g3_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CPG>
+__global__ __launch_bounds__(256) void gconv3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                          float* __restrict__ y, int C, int H, int W, int tiles_x) {
+  static_assert(CPG == 32 || CPG == 16, "one MFMA tile of output channels");
+  constexpr int MF = CPG;             // MFMA tile edge
+  constexpr int KL = 64 / MF;         // k lane groups of the MFMA: 2 (32x32x2) / 4 (16x16x4)
+  constexpr int CSTEP = 8 / KL;       // input channels one lane group walks inside an 8-channel chunk
+  constexpr int RPT = MF / 16;        // tile rows per N tile
+  constexpr int NTW = 4 / RPT;        // N tiles per wave (4 tile rows per wave)
+  constexpr int ROWS = 20, PLANE = 18 * ROWS;
+  constexpr int XS = 8 * PLANE, WS = 8 * 9 * CPG;
+  constexpr int NSLOT = (8 * 18 * 18 + 255) / 256;  // 11 patch elements per thread and chunk
+  constexpr int WSLOT = (WS / 4 + 255) / 256;       // float4 weight loads per thread and chunk
+  constexpr int NCH = CPG / 8;
+  using acc_t = typename std::conditional<MF == 32, g3_f32x16, g3_f32x4>::type;
+  constexpr int NACC = MF == 32 ? 16 : 4;
+  __shared__ __attribute__((aligned(16))) float xs[2][XS];
+  __shared__ __attribute__((aligned(16))) float wsm[2][WS];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int oy0 = (blockIdx.x / tiles_x) * 16, ox0 = (blockIdx.x % tiles_x) * 16;
+  const int g = blockIdx.y, n = blockIdx.z;
+  const long HW = (long)H * W;
+  const float* __restrict__ xg = x + ((long)n * C + (long)g * CPG) * HW;
+  const float* __restrict__ wg = wp + (long)g * CPG * 9 * CPG;
+
+  int goff[NSLOT], loff[NSLOT];
+  unsigned ok = 0;
+#pragma unroll
+  for (int j = 0; j < NSLOT; ++j) {
+    const int idx = t + j * 256;
+    const int c = idx / 324, r = idx - c * 324;
+    const int ry = r / 18, rx = r - ry * 18;
+    const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
+    const bool v = idx < 8 * 324 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    ok |= (unsigned)v << j;
+    goff[j] = v ? (int)(c * HW) + iy * W + ix : 0;
+    loff[j] = idx < 8 * 324 ? c * PLANE + ry * ROWS + rx : -1;
+  }
+  float rx_[NSLOT];
+  float4 rw_[WSLOT];
+  acc_t acc[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int r = 0; r < NACC; ++r) acc[i][r] = 0.f;
+
+  const int kk = lane / MF, lm = lane % MF;
+  const int rit = lm >> 4, xl = lm & 15;  // pixel of this lane inside an N tile
+  const int lane_a = (CSTEP * kk) * 9 * CPG + lm;
+  const int lane_b = (CSTEP * kk) * PLANE + (wave * 4 + rit) * ROWS + xl;
+
+#define WFAE_G3_LOAD(CH)                                                                     \
+  {                                                                                          \
+    const float* __restrict__ xc = xg + (long)(CH) * 8 * HW;                                 \
+    _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) rx_[j] = xc[goff[j]];                  \
+    const float4* __restrict__ wc = reinterpret_cast<const float4*>(wg + (long)(CH) * WS);   \
+    _Pragma("unroll") for (int j = 0; j < WSLOT; ++j) {                                      \
+      const int idx = t + j * 256;                                                           \
+      rw_[j] = wc[idx < WS / 4 ? idx : 0];                                                   \
+    }                                                                                        \
+  }
+#define WFAE_G3_STORE(BUF)                                                                   \
+  {                                                                                          \
+    float* __restrict__ xd = xs[BUF];                                                        \
+    _Pragma("unroll") for (int j = 0; j < NSLOT; ++j)                                        \
+      if (loff[j] >= 0) xd[loff[j]] = ((ok >> j) & 1u) ? rx_[j] : 0.f;                       \
+    float4* __restrict__ wd = reinterpret_cast<float4*>(wsm[BUF]);                           \
+    _Pragma("unroll") for (int j = 0; j < WSLOT; ++j) {                                      \
+      const int idx = t + j * 256;                                                           \
+      if (idx < WS / 4) wd[idx] = rw_[j];                                                    \
+    }                                                                                        \
+  }
+#define WFAE_G3_COMPUTE(BUF)                                                                 \
+  {                                                                                          \
+    const float* __restrict__ wb = wsm[BUF] + lane_a;                                        \
+    const float* __restrict__ xb = xs[BUF] + lane_b;                                         \
+    _Pragma("unroll") for (int ci = 0; ci < CSTEP; ++ci)                                     \
+      _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                       \
+        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                   \
+          const float a = wb[ci * 9 * CPG + (ky * 3 + kx) * CPG];                            \
+          _Pragma("unroll") for (int i = 0; i < NTW; ++i) {                                  \
+            const float b = xb[ci * PLANE + (i * RPT + ky) * ROWS + kx];                     \
+            if constexpr (MF == 32)                                                          \
+              acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);          \
+            else                                                                             \
+              acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);          \
+          }                                                                                  \
+        }                                                                                    \
+  }
+  // chunk ch + 1 travels HBM -> registers while chunk ch is multiplied; the last chunk is peeled
+  WFAE_G3_LOAD(0)
+  WFAE_G3_STORE(0)
+  __syncthreads();
+#pragma unroll 1
+  for (int ch = 0; ch + 1 < NCH; ++ch) {
+    const int buf = ch & 1;
+    WFAE_G3_LOAD(ch + 1)
+    WFAE_G3_COMPUTE(buf)
+    WFAE_G3_STORE(buf ^ 1)
+    __syncthreads();
+  }
+  WFAE_G3_COMPUTE((NCH - 1) & 1)
+#undef WFAE_G3_LOAD
+#undef WFAE_G3_STORE
+#undef WFAE_G3_COMPUTE
+
+  // C/D layout: column = lane % MF (the pixel), row = output channel:
+  //   32x32: (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5);   16x16: 4 (lane >> 4) + reg
+  float* __restrict__ yg = y + ((long)n * C + (long)g * CPG) * HW + (long)oy0 * W + ox0 + xl;
+  const bool xin = ox0 + xl < W;  // partial tiles at the right / bottom edge
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const int row = wave * 4 + i * RPT + rit;
+    if (!xin || oy0 + row >= H) continue;
+#pragma unroll
+    for (int r = 0; r < NACC; ++r) {
+      const int m = MF == 32 ? (r & 3) + 8 * (r >> 2) + 4 * kk : 4 * kk + r;
+      yg[(long)m * HW + (long)row * W] = acc[i][r];
+    }
+  }
+}
+
 // wp[((g*CPG + i)*9 + tap)*CPG + o]:  forward  i = ci, o = oc : w[g*CPG+o][i][tap]
 //                                     transposed (dgrad) i = oc_orig, o = ci_orig : w[g*CPG+i][o][8-tap]
 __global__ void gconv3_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int CPG,
@@ -467,6 +604,14 @@ __global__ void gconv3_pack_kernel(const float* __restrict__ w, float* __restric
   const int i = r % CPG, g = r / CPG;
   wp[i0] = transposed ? w[((long)(g * CPG + i) * CPG + o) * 9 + (8 - tap)]
                       : w[((long)(g * CPG + o) * CPG + i) * 9 + tap];
+}
+
+template <int CPG>
+int launch_gconv3_mfma(const float* x, const float* wp, float* y, int NB, int C, int H, int W, hipStream_t st) {
+  const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, 16);
+  hipLaunchKernelGGL((gconv3_mfma_kernel<CPG>), dim3(tiles_x * tiles_y, C / CPG, NB), dim3(256), 0, st, x, wp, y, C, H,
+                     W, tiles_x);
+  return check_launch("gconv3_mfma");
 }
 
 template <int CPG, int PY>
@@ -495,6 +640,12 @@ extern "C" int wfae_gconv3x3_fwd(const float* x, const float* w, float* y, int N
   int rc = check_launch("gconv3_pack");
   if (rc) return rc;
   const float* wp = (const float*)ws;
+  // 16 / 32 channels per group: the MFMA form on 16 x 16 pixel tiles (partial at the edges) (WFAE_G3_FWD_MFMA=0 keeps the VALU kernel)
+  static const int use_mfma = getenv("WFAE_G3_FWD_MFMA") ? atoi(getenv("WFAE_G3_FWD_MFMA")) : 1;
+  if (use_mfma && cpg >= 16 && (long)cpg * H * W < (1l << 28)) {
+    if (cpg == 32) return launch_gconv3_mfma<32>(x, wp, y, NB, C, H, W, st);
+    return launch_gconv3_mfma<16>(x, wp, y, NB, C, H, W, st);
+  }
   // rows per thread: measured 1 < 2 < 4 in time (the kernel is latency-bound: smaller LDS tiles, more blocks per CU)
   static const int py_big = getenv("WFAE_G3_PY") ? atoi(getenv("WFAE_G3_PY")) : 1;
   if (py_big == 1) {
@@ -540,6 +691,10 @@ __global__ __launch_bounds__(256, (OCW * CPG * 9 <= 72 ? 4 : 2)) void gconv3_wgr
   constexpr int GPB = Q >= 4 ? 1 : 4 / Q;      // groups per block (4 waves = 4 units)
   constexpr int XCH = GPB * CPG;               // input channels staged per block
   __shared__ float xs[XCH][IH][IW];
+  // 72-accumulator variants park the dy values of a tile in LDS up front; with 144 accumulators the extra live
+  // registers cost more than the per-row load stall (measured: 4 ch/group 0.95 -> 0.75 ms, 8 ch/group 0.63 -> 0.77 ms)
+  constexpr bool HOIST = OCW * CPG * 9 <= 72;
+  __shared__ float dys[HOIST ? 4 : 1][TH][OCW][64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int u = blockIdx.y * 4 + wave;         // (group, oc chunk)
   const int g = u / Q, q = u - g * Q;
@@ -561,7 +716,21 @@ __global__ __launch_bounds__(256, (OCW * CPG * 9 <= 72 ? 4 : 2)) void gconv3_wgr
     const int n = tile / per_img;
     const int tr = tile - n * per_img;
     const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
-    __syncthreads();
+    // HOIST: the dy values of all TH rows are requested first and parked in a per-lane LDS slot, so their HBM
+    // latency hides behind the staging of the x patch instead of stalling every row (kept in registers across a
+    // fully unrolled row loop they spill)
+    const int ox = ox0 + lane;
+    const float* dyp = dy + ((long)n * C + oc0) * H * W + ox;
+    float dpre[HOIST ? TH : 1][OCW];
+    if constexpr (HOIST) {
+#pragma unroll
+      for (int r = 0; r < TH; ++r) {
+        const bool ok = oy0 + r < H && ox < W;
+#pragma unroll
+        for (int o = 0; o < OCW; ++o) dpre[r][o] = ok ? dyp[((long)o * H + oy0 + r) * W] : 0.f;
+      }
+    }
+    __syncthreads();  // every wave is done with the previous tile's xs / dys
     const float* xg = x + ((long)n * C + (long)g0 * CPG) * H * W;
     for (int idx = t; idx < XCH * IH * IWU; idx += 256) {
       const int c = idx / (IH * IWU);
@@ -572,16 +741,24 @@ __global__ __launch_bounds__(256, (OCW * CPG * 9 <= 72 ? 4 : 2)) void gconv3_wgr
       if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = xg[((long)c * H + iy) * W + ix];
       xs[c][ry][rx] = v;
     }
+    if constexpr (HOIST) {
+#pragma unroll
+      for (int r = 0; r < TH; ++r)
+#pragma unroll
+        for (int o = 0; o < OCW; ++o) dys[wave][r][o][lane] = dpre[r][o];
+    }
     __syncthreads();
-    const int ox = ox0 + lane;
-    const float* dyp = dy + ((long)n * C + oc0) * H * W + ox;
 #pragma unroll 1
     for (int r = 0; r < TH; ++r) {
-      const int oy = oy0 + r;
-      const bool ok = oy < H && ox < W;
       float d[OCW];
+      if constexpr (HOIST) {
 #pragma unroll
-      for (int o = 0; o < OCW; ++o) d[o] = ok ? dyp[((long)o * H + oy) * W] : 0.f;
+        for (int o = 0; o < OCW; ++o) d[o] = dys[wave][r][o][lane];
+      } else {
+        const bool ok = oy0 + r < H && ox < W;
+#pragma unroll
+        for (int o = 0; o < OCW; ++o) d[o] = ok ? dyp[((long)o * H + oy0 + r) * W] : 0.f;
+      }
 #pragma unroll
       for (int c = 0; c < CPG; ++c)
 #pragma unroll
@@ -606,9 +783,163 @@ __global__ __launch_bounds__(256, (OCW * CPG * 9 <= 72 ? 4 : 2)) void gconv3_wgr
       }
 }
 
+// -------------------------------------------------------------------------------------
+// MFMA weight gradient of the grouped 3x3 convolution for 16 / 32 channels per group:
+//   dW[oc][ci][ky][kx] = sum over pixels  dy[oc][p] * x[ci][p + (ky-1, kx-1)]
+// is, per group and per tap, a (CPG x pixels) . (pixels x CPG) product — exactly one MFMA tile of output.  A block
+// of 3 waves walks 8 x 16 pixel tiles of one group: dy is staged TRANSPOSED (dys[pixel][oc], row stride CPG + 1)
+// and the x patch with an odd plane stride, so both operand fragments (lane = oc resp. ci, k lanes = adjacent
+// pixels of a row) are conflict-free ds_read_b32 at compile-time offsets.  Wave w owns filter row ky = w and keeps
+// three accumulator tiles (kx = 0..2) in registers across all tiles of its slice; partial sums go to a slab that
+// slab_reduce adds in fixed order.  The generic B_WGRAD3 GEMM pads these shapes to 32 x 128 tiles (19 TF at
+// 16 ch/group, 46 TF at 32).
+// -------------------------------------------------------------------------------------
+// RCPG < CPG: CPG / RCPG real groups of RCPG channels share one MFMA tile; the tile then also holds the products
+// between different groups, which are simply not written (8 ch/group: half of the tile is used and the kernel
+// still runs 2x faster than the VALU form; 4 ch/group: a quarter, +20 %)
+template <int CPG, int RCPG = CPG>
+__global__ __launch_bounds__(192) void gconv3_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                float* __restrict__ part, int NB, int C, int H, int W,
+                                                                int tiles_x, int tiles_y, int parts) {
+  static_assert(CPG == 32 || CPG == 16, "one MFMA tile of (oc, ci)");
+  constexpr int MF = CPG, KL = 64 / MF;          // k lanes of the MFMA = pixels per k step: 2 / 4
+  constexpr int TH = 8, TW = 16, NPIX = TH * TW;
+  constexpr int DLD = CPG + 1;                   // dys row stride (words): bank = (pixel + oc) % 32
+  constexpr int ROWS = 20, PLANE = (TH + 2) * ROWS + 1;  // odd plane stride: bank = (9 ci + offset) % 32
+  constexpr int NT = 192;
+  using acc_t = typename std::conditional<MF == 32, g3_f32x16, g3_f32x4>::type;
+  constexpr int NACC = MF == 32 ? 16 : 4;
+  __shared__ float dys[NPIX * DLD];
+  __shared__ float xs[CPG * PLANE];
+  const int t = threadIdx.x, lane = t & 63, ky = t >> 6;
+  const int g = blockIdx.y;
+  const int lm = lane % MF, kq = lane / MF;
+  const long HW = (long)H * W;
+
+  acc_t acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int r = 0; r < NACC; ++r) acc[i][r] = 0.f;
+
+  // Staging maps with no per-element index arithmetic.  x patch: thread -> (ry, rx) = (t / 18, t % 18) of the
+  // 10 x 18 patch (threads 180..191 idle), slot j = input channel j.  dy tile: thread -> (oc0, row, float4 q) =
+  // (t / 32, (t / 4) % 8, t % 4), slot j = output channel oc0 + 6 j.  Bounds depend on the thread and the tile
+  // only, not on the slot.  Tile i + 1 travels HBM -> registers while tile i is multiplied.
+  constexpr int XSLOT = CPG, DSLOT = (CPG + 5) / 6;
+  const int xry = t / 18, xrx = t - xry * 18;
+  const bool xthr = t < 180;
+  const int dq = t & 3, dr = (t >> 2) & 7, doc0 = t >> 5;
+  float rxv[XSLOT];
+  float4 rdv[DSLOT];
+  const int per_img = tiles_x * tiles_y;
+  const int total = NB * per_img;
+  auto prefetch = [&](int tile) {
+    const int n = tile / per_img;
+    const int tr = tile - n * per_img;
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+    const long gbase = ((long)n * C + (long)g * CPG) * HW;
+    const int iy = oy0 - 1 + xry, ix = ox0 - 1 + xrx;
+    const bool xok = xthr && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const float* __restrict__ xp = x + gbase + (xok ? (long)iy * W + ix : 0);
+#pragma unroll
+    for (int j = 0; j < XSLOT; ++j) {
+      const float v = xp[(long)j * HW];
+      rxv[j] = xok ? v : 0.f;
+    }
+    const int oy = oy0 + dr, ox = ox0 + dq * 4;
+    const bool dok = oy < H && ox < W;   // W % 4 == 0: a float4 is inside or outside as a whole
+    const float* __restrict__ dp = dy + gbase + (dok ? (long)oy * W + ox : 0);
+#pragma unroll
+    for (int j = 0; j < DSLOT; ++j) {
+      const int oc = doc0 + 6 * j;
+      const float4 v = *reinterpret_cast<const float4*>(dp + (long)(oc < CPG ? oc : 0) * HW);
+      rdv[j] = dok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if ((int)blockIdx.x < total) prefetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < total; tile += parts) {
+    __syncthreads();  // the previous tile has been consumed
+    if (xthr) {
+#pragma unroll
+      for (int j = 0; j < XSLOT; ++j) xs[j * PLANE + xry * ROWS + xrx] = rxv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < DSLOT; ++j) {
+      const int oc = doc0 + 6 * j;
+      if (oc < CPG) {
+        float* d0 = dys + (dr * TW + dq * 4) * DLD + oc;
+        d0[0] = rdv[j].x; d0[DLD] = rdv[j].y; d0[2 * DLD] = rdv[j].z; d0[3 * DLD] = rdv[j].w;
+      }
+    }
+    __syncthreads();
+    if (tile + parts < total) prefetch(tile + parts);
+    const float* __restrict__ ab = dys + kq * DLD + lm;
+    const float* __restrict__ bb = xs + lm * PLANE + ky * ROWS + kq;
+#pragma unroll
+    for (int r = 0; r < TH; ++r)
+#pragma unroll
+      for (int s = 0; s < TW / KL; ++s) {
+        const float a = ab[(r * TW + s * KL) * DLD];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float b = bb[r * ROWS + s * KL + kx];
+          if constexpr (MF == 32)
+            acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[kx], 0, 0, 0);
+          else
+            acc[kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[kx], 0, 0, 0);
+        }
+      }
+  }
+  // C/D layout: column = lane % MF = ci, row = oc: 32x32 (reg & 3) + 8 (reg >> 2) + 4 kq; 16x16 4 kq + reg
+  float* __restrict__ dst = part + (long)blockIdx.x * C * RCPG * 9 + (long)g * CPG * RCPG * 9;
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int r = 0; r < NACC; ++r) {
+      const int oc = MF == 32 ? (r & 3) + 8 * (r >> 2) + 4 * kq : 4 * kq + r;
+      if (oc / RCPG == lm / RCPG) dst[((long)oc * RCPG + lm % RCPG) * 9 + ky * 3 + kx] = acc[kx][r];
+    }
+}
+
 }  // namespace
 
 namespace wfae {
+// weight gradient of the grouped 3x3 conv for 4 / 8 / 16 / 32 channels per group on the MFMA kernel above;
+// returns WFAE_ERR_UNSUPPORTED otherwise (WFAE_G3_WGRAD_MFMA=0: always)
+int gconv3_wgrad_mfma(const float* dy, const float* x, float* dw, int NB, int C, int H, int W, int groups,
+                      int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int cpg = C / groups;
+  static const int on = getenv("WFAE_G3_WGRAD_MFMA") ? atoi(getenv("WFAE_G3_WGRAD_MFMA")) : 1;
+  if (!on || !(cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32) || W % 4 != 0 ||
+      (reinterpret_cast<uintptr_t>(dy) & 15) != 0)
+    return WFAE_ERR_UNSUPPORTED;
+  const int vcpg = cpg == 32 ? 32 : 16;        // channels per MFMA tile ("virtual group")
+  if (C % vcpg != 0 || C / vcpg > 65535) return WFAE_ERR_UNSUPPORTED;
+  const int vgroups = C / vcpg;
+  const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, 8);
+  const long total = (long)NB * tiles_x * tiles_y;
+  const size_t out_elems = (size_t)C * cpg * 9;
+  long parts = cdiv(1536, vgroups);  // ~6 blocks of 3 waves per CU
+  if (parts > total / 2) parts = total / 2 > 0 ? total / 2 : 1;  // >= 2 tiles per block: the register pipeline needs a successor
+  while (parts > 1 && (size_t)parts * out_elems * sizeof(float) > ws_bytes) --parts;
+  if (!ws || (size_t)parts * out_elems * sizeof(float) > ws_bytes)
+    return fail(WFAE_ERR_WORKSPACE, "gconv3x3_bwd_weight: workspace %zu too small", ws_bytes);
+  dim3 grid((unsigned)parts, vgroups), block(192);
+  float* part = (float*)ws;
+#define WFAE_G3W(V_, R_)                                                                                      \
+  hipLaunchKernelGGL((gconv3_wgrad_mfma_kernel<V_, R_>), grid, block, 0, st, dy, x, part, NB, C, H, W, tiles_x, \
+                     tiles_y, (int)parts)
+  if (cpg == 32) WFAE_G3W(32, 32);
+  else if (cpg == 16) WFAE_G3W(16, 16);
+  else if (cpg == 8) WFAE_G3W(16, 8);
+  else WFAE_G3W(16, 4);
+#undef WFAE_G3W
+  int rc = check_launch("gconv3_wgrad_mfma");
+  if (rc) return rc;
+  return slab_reduce(part, dw, nullptr, (long)out_elems, 1, (int)parts, accumulate, st);
+}
+
 // weight gradient of the grouped 3x3 conv for cpg in {4, 8, 16}; returns WFAE_ERR_UNSUPPORTED otherwise
 int gconv3_wgrad_valu(const float* dy, const float* x, float* dw, int NB, int C, int H, int W, int groups,
                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {

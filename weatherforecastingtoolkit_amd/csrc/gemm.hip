@@ -1513,7 +1513,12 @@ int wfae_gconv3x3_bwd_weight(const float* dy, const float* x, float* dw, int NB,
   const int cpg = C / groups;
   WFAE_REQUIRE(cpg <= 32, WFAE_ERR_UNSUPPORTED, "gconv3x3_bwd_weight: %d channels per group > 32", cpg);
   {
-    // 4 / 8 / 16 channels per group: the pixel-parallel VALU kernel (a 32-row MFMA tile would be mostly padding)
+    // the dedicated one-tile-per-tap MFMA kernel (csrc/dconv.hip); it declines unaligned shapes
+    const int rc = gconv3_wgrad_mfma(dy, x, dw, NB, C, H, W, groups, accumulate, ws, ws_bytes, (hipStream_t)stream);
+    if (rc != WFAE_ERR_UNSUPPORTED) return rc;
+  }
+  {
+    // fallbacks: the pixel-parallel VALU kernel (4 / 8 / 16 channels per group), then the generic GEMM
     const int rc = gconv3_wgrad_valu(dy, x, dw, NB, C, H, W, groups, accumulate, ws, ws_bytes, (hipStream_t)stream);
     if (rc != WFAE_ERR_UNSUPPORTED) return rc;
   }

@@ -74,6 +74,15 @@ int wfae_get_matmul_precision(void);
 int wfae_conv1x1_fwd(const float* x, const float* w, const float* bias, const float* res,
                      int64_t res_img_stride, float* y, int NB, int Cin, int Cout, int HW,
                      wfae_stream_t stream);
+/* Same convolution with the BatchNorm statistics of y (the next layer of Bottleneck is always
+ * BatchNorm2d, ae_64x8x8_lin.py:14-19) reduced in the epilogue instead of by a second pass over y:
+ * stat_part (capacity stat_capacity floats) receives *stat_rows partial rows, sum[rows][Cout] followed by
+ * sumsq[rows][Cout] (one row per 64-pixel wave tile); wfae_bn_stats_from_rows finishes them.  When the
+ * shape is not served by the vector epilogue *stat_rows is 0: y is still complete, run
+ * wfae_bn_stats_train on it.  stat_rows is a HOST pointer. */
+int wfae_conv1x1_fwd_stats(const float* x, const float* w, const float* bias, const float* res,
+                           int64_t res_img_stride, float* y, int NB, int Cin, int Cout, int HW,
+                           float* stat_part, int64_t stat_capacity, int* stat_rows, wfae_stream_t stream);
 int wfae_conv1x1_bwd_data(const float* dy, const float* w, float* dx, int NB, int Cin, int Cout,
                           int HW, wfae_stream_t stream);
 int wfae_conv1x1_bwd_weight(const float* dy, const float* x, float* dw, int NB, int Cin, int Cout,
@@ -158,6 +167,11 @@ int wfae_bn_stats_train(const float* x, int NB, int C, int HW, const float* gamm
                         const float* beta, float eps, float momentum, float* running_mean,
                         float* running_var, float* save_mean, float* save_invstd, float* scale,
                         float* shift, void* ws, size_t ws_bytes, wfae_stream_t stream);
+/* wfae_bn_stats_train's second half on the partial rows of wfae_conv1x1_fwd_stats (same outputs) */
+int wfae_bn_stats_from_rows(const float* stat_part, int rows, int NB, int C, int HW, const float* gamma,
+                            const float* beta, float eps, float momentum, float* running_mean,
+                            float* running_var, float* save_mean, float* save_invstd, float* scale,
+                            float* shift, void* ws, size_t ws_bytes, wfae_stream_t stream);
 int wfae_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, float* save_mean, float* save_invstd,
                       float* scale, float* shift, int C, wfae_stream_t stream);

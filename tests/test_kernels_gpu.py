@@ -58,6 +58,33 @@ def test_conv1x1(ops, dev, nb, cin, cout, h, w):
     assert relerr(y2, F.conv2d(x, wt) + pos) < TOL
 
 
+@pytest.mark.parametrize("nb,cin,cout,h,w,res,served", [
+    (8, 64, 256, 64, 64, True, True), (8, 256, 64, 96, 96, False, True), (16, 32, 128, 64, 48, True, True),
+    (3, 128, 512, 96, 96, False, True),
+    (2, 32, 128, 16, 16, True, False),      # under-filled grid: the 32-row kernel (four wave columns) runs
+    (5, 128, 32, 16, 8, False, False), (2, 18, 33, 5, 5, False, False)])
+def test_conv1x1_fused_bn_stats(ops, dev, nb, cin, cout, h, w, res, served):
+    """BatchNorm statistics reduced in the GEMM epilogue (wfae_conv1x1_fwd_stats + wfae_bn_stats_from_rows) equal
+    wfae_bn_stats_train on the stored output: scale / shift / saved statistics and the running-stat update; shapes the
+    vector epilogue does not serve report no rows and leave y complete."""
+    x, wt = rnd((nb, cin, h, w), 1).to(dev), rnd((cout, cin, 1, 1), 2, -0.2, 0.2).to(dev)
+    r = rnd((nb, cout, h, w), 4).to(dev) if res else None
+    gamma, beta = rnd((cout,), 5, 0.5, 1.5).to(dev), rnd((cout,), 6).to(dev)
+    y0 = ops.conv1x1_fwd(x, wt, None, r)
+    y, sr = ops.conv1x1_fwd_stats(x, wt, None, r)
+    assert torch.equal(y, y0)
+    assert (sr is not None) == served, (sr, served)
+    if sr is None:
+        return
+    rm0, rv0 = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    a = ops.bn_stats_train(y, gamma, beta, rm0, rv0)
+    b = ops.bn_stats_from_rows(sr, tuple(y.shape), gamma, beta, rm1, rv1)
+    for name in ("mean", "invstd", "scale", "shift"):
+        assert relerr(getattr(b, name), getattr(a, name)) < 2e-6, name
+    assert relerr(rm1, rm0) < 2e-6 and relerr(rv1, rv0) < 2e-6
+
+
 # -------------------------------------------------------------------- linear
 @pytest.mark.parametrize("b,inf,out", [(4, 256, 64), (3, 100, 36), (1, 64, 8), (32, 4096, 2048), (2, 2048, 4096)])
 def test_linear(ops, dev, b, inf, out):

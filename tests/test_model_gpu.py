@@ -184,6 +184,34 @@ def test_wgrad_side_stream_overlap_matches(dev):
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
 
 
+def test_stat_fusion_option_tracks_reference(dev):
+    """functional.STAT_FUSION (BatchNorm sums in the GEMM epilogues, off by default): forward and loss hold the usual
+    bars; gradient norms only 2e-2 — the fused sums are not correctly rounded and the network amplifies 1-ulp
+    differences of the channel means (functional.py), which is why the option is off."""
+    from weatherforecastingtoolkit_amd import functional as Fn
+    g = golden("g3_full128_b2")
+    net = _build(int(g["img_size"]), dev)
+    x = _frames(g).to(dev)
+    idx = torch.from_numpy(g["lattice"]).to(dev)
+    Fn.STAT_FUSION = True
+    try:
+        ops_prof = __import__("weatherforecastingtoolkit_amd.ops", fromlist=["ops"])
+        ops_prof.profile_start()
+        recon, z = net(x)
+        prof = ops_prof.profile_stop()
+        loss = Fn.l1_loss(recon, x)
+        loss.backward()
+    finally:
+        Fn.STAT_FUSION = False
+    assert relerr(recon.detach()[:, 0][:, idx][:, :, idx], g["recon_lattice"]) < 1e-4
+    assert relerr(z, g["z"]) < 1e-4
+    assert abs(loss.item() - float(g["loss0"])) <= 1e-5 * float(g["loss0"])
+    gn = np.array([p.grad.double().norm().item() for p in net.parameters()])
+    rel = np.abs(gn - g["grad_norms"]) / (g["grad_norms"] + 1e-12)
+    assert rel.max() < 2e-2, rel.max()
+    assert prof["wfae_bn_stats_train"][0] == 104       # every BatchNorm got statistics, fused or not
+
+
 def test_tf_variant_golden(dev):
     """next-1 row: ae_64x8x8_tf.PosAwareAE_TF (latent transformer, attention across the batch) vs the reference."""
     from weatherforecastingtoolkit_amd import functional as Fn, synth

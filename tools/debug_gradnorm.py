@@ -1,0 +1,37 @@
+"""Per-parameter gradient-norm deviation of the GPU step from a golden fixture (default g4: B=1, 384x384), largest first.
+
+    python tools/debug_gradnorm.py [golden-name]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests._util import golden  # noqa: E402
+from tests.test_model_gpu import _build, _frames  # noqa: E402
+from weatherforecastingtoolkit_amd import functional as Fn  # noqa: E402
+
+
+def main():
+    gname = sys.argv[1] if len(sys.argv) > 1 else "g4_full384_b1"
+    g = golden(gname)
+    dev = torch.device("cuda:0")
+    net = _build(int(g["img_size"]), dev)
+    x = _frames(g).to(dev)
+    recon, z = net(x)
+    loss = Fn.l1_loss(recon, x)
+    loss.backward()
+    names = [n for n, _ in net.named_parameters()]
+    gn = np.array([p.grad.double().norm().item() for p in net.parameters()])
+    rel = np.abs(gn - g["grad_norms"]) / (g["grad_norms"] + 1e-12)
+    order = np.argsort(-rel)
+    print(f"{gname}: loss {loss.item():.9f} golden {float(g['loss0']):.9f}; grad-norm rel dev max {rel.max():.3e} "
+          f"median {np.median(rel):.3e}  fusion={Fn.STAT_FUSION}")
+    for i in order[:8]:
+        print(f"  {names[i]:28s} {rel[i]:.3e}  norm {gn[i]:.4e}")
+
+
+if __name__ == "__main__":
+    main()

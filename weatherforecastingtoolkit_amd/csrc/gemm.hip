@@ -78,6 +78,11 @@ struct GemmP {
   int swizzle;       // XCD-aware tile order (set by launch_gemm_v from WFAE_SWIZZLE, default off)
   int nt_store;      // nontemporal stores of the result tile (WFAE_GEMM_NT)
   int a_vec, b_vec, c_vec;  // 16-byte vector accesses are legal for this operand / the result
+  // BatchNorm statistics of the result, fused into the E_BATCHED vector epilogue (kernels with two wave columns):
+  // stat_sum / stat_sq [2 * ntiles][M] receive, per output row m (= channel) and 64-column wave tile, the sum and the
+  // sum of squares of the values stored by that wave; null = off
+  float* stat_sum;
+  float* stat_sq;
   // 4x4 s2 geometry (gather kinds): lo side Hlo x Wlo, hi side 2Hlo x 2Wlo
   int Chi, Clo, Hlo, Wlo;
   // grouped 3x3 weight gradient (B_WGRAD3): blockIdx.y = group, Chi = total channels,
@@ -91,6 +96,16 @@ struct GemmP {
   // dropped by the caller.  B_TAPN: B(k,n=q) (forward / data gradient); B_TAPK: B(k=(img,q), n=tap*Chi+c)
   // (weight gradient).
 };
+
+// inclusive prefix sum over the 16 lanes of a DPP row (row_shr:1,2,4,8 with bound_ctrl: lanes shifted in from
+// outside the row read 0): lane 15 of every row ends up with the row total — VALU adds, no LDS permutes
+__device__ __forceinline__ float dpp_row_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+  return v;
+}
 
 // 16-byte global access that is only 4-byte aligned (gfx9 global memory runs in unaligned access mode)
 typedef float vf4 __attribute__((ext_vector_type(4)));
@@ -984,6 +999,24 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
             *reinterpret_cast<float4*>(dst) = v;
           }
         }
+        if constexpr (EK == E_BATCHED && WNW == 2) {
+          if (p.stat_sum) {  // wave-uniform: every lane takes part in the shuffles
+            float s1 = 0.f, s2 = 0.f;
+            if (nok && m < p.M) {
+              s1 = (v.x + v.y) + (v.z + v.w);
+              s2 = fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);
+            }
+            // the F4R = 16 lanes of one output row are one DPP row: four row_shr adds leave the total in its lane 15
+            static_assert(F4R == 16, "one DPP row per output row");
+            s1 = dpp_row_sum(s1);
+            s2 = dpp_row_sum(s2);
+            if (c4 == F4R - 1 && m < p.M) {
+              const long prow = (long)(n0 / BN) * 2 + (wave % WNW);
+              p.stat_sum[prow * p.M + m] = s1;
+              p.stat_sq[prow * p.M + m] = s2;
+            }
+          }
+        }
       }
     }
   } else {
@@ -1278,9 +1311,9 @@ int splitk_finish(const float* slab, float* out, const float* bias_n, long MN, i
 
 extern "C" {
 
-int wfae_conv1x1_fwd(const float* x, const float* w, const float* bias, const float* res,
-                     int64_t res_img_stride, float* y, int NB, int Cin, int Cout, int HW,
-                     wfae_stream_t stream) {
+static int conv1x1_fwd_impl(const float* x, const float* w, const float* bias, const float* res,
+                            int64_t res_img_stride, float* y, int NB, int Cin, int Cout, int HW, float* stat_part,
+                            int64_t stat_capacity, int* stat_rows, wfae_stream_t stream) {
   WFAE_REQUIRE(x && w && y, WFAE_ERR_NULL_POINTER, "conv1x1_fwd: null pointer");
   WFAE_REQUIRE(NB > 0 && Cin > 0 && Cout > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "conv1x1_fwd: bad shape");
   WFAE_REQUIRE((int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "conv1x1_fwd: NB*HW too large");
@@ -1293,7 +1326,34 @@ int wfae_conv1x1_fwd(const float* x, const float* w, const float* bias, const fl
   p.a_vec = (Cin % 4 == 0) && aligned16(w);
   p.b_vec = (HW % 4 == 0) && aligned16(x);
   p.c_vec = (HW % 4 == 0) && aligned16(y) && (!res || (aligned16(res) && res_img_stride % 4 == 0));
+  if (stat_rows) {
+    // the statistics ride in the vector epilogue of the two-wave-column kernels; anything else reports 0 rows and the
+    // caller runs wfae_bn_stats_train on y
+    const int ntiles = cdiv(p.N, BN);
+    const int64_t rows = 2 * (int64_t)ntiles;
+    const bool ok = stat_part && p.a_vec && p.b_vec && p.c_vec && pick_bm(p.M, ntiles) != 32 &&
+                    stat_capacity >= 2 * rows * Cout;
+    *stat_rows = ok ? (int)rows : 0;
+    if (ok) {
+      p.stat_sum = stat_part;
+      p.stat_sq = stat_part + rows * Cout;
+    }
+  }
   return launch_gemm<A_KCONTIG, B_NCONTIG, E_BATCHED>(p, 1, (hipStream_t)stream, "conv1x1_fwd");
+}
+
+int wfae_conv1x1_fwd(const float* x, const float* w, const float* bias, const float* res,
+                     int64_t res_img_stride, float* y, int NB, int Cin, int Cout, int HW,
+                     wfae_stream_t stream) {
+  return conv1x1_fwd_impl(x, w, bias, res, res_img_stride, y, NB, Cin, Cout, HW, nullptr, 0, nullptr, stream);
+}
+
+int wfae_conv1x1_fwd_stats(const float* x, const float* w, const float* bias, const float* res,
+                           int64_t res_img_stride, float* y, int NB, int Cin, int Cout, int HW, float* stat_part,
+                           int64_t stat_capacity, int* stat_rows, wfae_stream_t stream) {
+  WFAE_REQUIRE(stat_part && stat_rows, WFAE_ERR_NULL_POINTER, "conv1x1_fwd_stats: null pointer");
+  return conv1x1_fwd_impl(x, w, bias, res, res_img_stride, y, NB, Cin, Cout, HW, stat_part, stat_capacity, stat_rows,
+                          stream);
 }
 
 int wfae_conv1x1_bwd_data(const float* dy, const float* w, float* dx, int NB, int Cin, int Cout,

@@ -93,6 +93,28 @@ __global__ __launch_bounds__(RT) void chan_reduce_kernel(const float* __restrict
   }
 }
 
+// partial rows of a producer epilogue (wfae_conv1x1_fwd_stats): sum[P][C], sq[P][C] -> fp64 partials in the layout
+// chan_reduce_kernel writes, part[(c * splits + s) * 2 + {0,1}]; block (c / 64, s) adds the rows p = s, s + splits, ...
+__global__ __launch_bounds__(256) void stat_rows_reduce_kernel(const float* __restrict__ sum, const float* __restrict__ sq,
+                                                               double* __restrict__ part, int P, int C, int splits) {
+  __shared__ double sm[2][4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, s = blockIdx.y;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (long p = s + (long)rg * splits; p < P; p += 4l * splits) {
+      s1 += (double)sum[p * C + c];
+      s2 += (double)sq[p * C + c];
+    }
+  sm[0][rg][cl] = s1;
+  sm[1][rg][cl] = s2;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    part[((long)c * splits + s) * 2 + 0] = (sm[0][0][cl] + sm[0][1][cl]) + (sm[0][2][cl] + sm[0][3][cl]);
+    part[((long)c * splits + s) * 2 + 1] = (sm[1][0][cl] + sm[1][1][cl]) + (sm[1][2][cl] + sm[1][3][cl]);
+  }
+}
+
 __global__ void bn_finalize_kernel(const double* __restrict__ part, int splits, long count, int C,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ running_mean,
@@ -566,6 +588,31 @@ int wfae_bn_stats_train(const float* x, int NB, int C, int HW, const float* gamm
   int rc = check_launch("bn_stats");
   if (rc) return rc;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, g.splits,
+                     (long)NB * HW, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
+                     save_invstd, scale, shift);
+  return check_launch("bn_finalize");
+}
+
+int wfae_bn_stats_from_rows(const float* stat_part, int rows, int NB, int C, int HW, const float* gamma,
+                            const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                            float* save_mean, float* save_invstd, float* scale, float* shift, void* ws, size_t ws_bytes,
+                            wfae_stream_t stream) {
+  WFAE_REQUIRE(stat_part && gamma && beta && save_mean && save_invstd && scale && shift, WFAE_ERR_NULL_POINTER,
+               "bn_stats_from_rows: null pointer");
+  WFAE_REQUIRE(rows > 0 && NB > 0 && C > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "bn_stats_from_rows: bad shape");
+  // enough (channel block, row slice) blocks to fill the chip: the partial rows are ~3 % of the tensor, read once
+  int splits = (int)((1024l * 64 + C - 1) / C);
+  if (splits > rows / 8) splits = rows / 8;
+  if (splits < 1) splits = 1;
+  if (splits > 1024) splits = 1024;
+  WFAE_REQUIRE(ws && ws_bytes >= sizeof(double) * 2 * (size_t)C * splits, WFAE_ERR_WORKSPACE,
+               "bn_stats_from_rows: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(stat_rows_reduce_kernel, dim3(cdiv(C, 64), splits), dim3(256), 0, st, stat_part,
+                     stat_part + (long)rows * C, (double*)ws, rows, C, splits);
+  int rc = check_launch("stat_rows_reduce");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, splits,
                      (long)NB * HW, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
                      save_invstd, scale, shift);
   return check_launch("bn_finalize");

@@ -19,6 +19,8 @@ which adopts it as `p.grad` without a copy.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -37,6 +39,15 @@ BN_EPS = 1e-5
 _overlap = False
 _side = {}
 
+
+# BatchNorm statistics of 1x1-convolution outputs reduced in the GEMM epilogue instead of by a pass over the tensor
+# (WFAE_STAT_FUSION=1).  OFF by default: the fused sums are as accurate as the separate pass (both within 1e-7 of fp64,
+# tools/debug_stats.py) but not correctly ROUNDED — the separate pass accumulates in fp64 and, like torch's CPU
+# BatchNorm, returns the correctly rounded mean, so its statistics agree with the reference's bit for bit in most
+# channels.  A 1-ulp difference of a channel mean is a coherent perturbation of that whole channel, and at B = 1 the
+# 40-layer batch-statistics network with an L1 loss amplifies it: gradient norms moved from 5e-6 (median) / 9e-5 (max)
+# of the reference's to 2.7e-4 / 4.2e-3 (tools/debug_gradnorm.py), for 0.3-1.5 % of step time.  Parity first.
+STAT_FUSION = os.environ.get("WFAE_STAT_FUSION", "0") == "1"
 
 def set_wgrad_overlap(flag: bool):
     global _overlap
@@ -138,6 +149,16 @@ def _bn_stats(x, bn, training):
         bn._nbt_pending += 1
         return st
     return ops.bn_fold_eval(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+
+
+def _bn_stats_rows(sr, x, bn, training):
+    """_bn_stats of x when a producer epilogue may already have reduced its per-channel sums (ops.StatRows)"""
+    if training and sr is not None:
+        st = ops.bn_stats_from_rows(sr, tuple(x.shape), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                                    bn.momentum)
+        bn._nbt_pending += 1
+        return st
+    return _bn_stats(x, bn, training)
 
 
 def _use_batch_stats(bn):
@@ -484,20 +505,31 @@ def _mk_stats(mean, invstd, scale, shift):
 
 class BottleneckFn(Function):
     @staticmethod
-    def forward(ctx, x, g1, b1, w1, g2, b2, wg, g3, b3, w3, mod):
-        x = _c(x)
+    def forward(ctx, x, g1, b1, w1, g2, b2, wg, g3, b3, w3, mod, x_stats=None):
+        """`x_stats`: the BatchNorm sums of x if the kernel that produced x already reduced them (the previous
+        Bottleneck's last 1x1 convolution); `mod._out_stats` receives those of y when `mod.emit_stats` is set.  In
+        training mode the statistics of the two 1x1 outputs (t1 here, y for the next block) ride in the GEMM
+        epilogues instead of costing a pass over the tensor each — when STAT_FUSION is on (default off, see above)."""
+        xc = _c(x)
+        if xc is not x:
+            x_stats = None
+        x = xc
         bn1, bn2, bn3 = mod.f[0], mod.f[3], mod.f[6]
         groups = mod.f[5].groups
         training = _use_batch_stats(bn1)
-        st1 = _bn_stats(x, bn1, training)
+        fuse = training and STAT_FUSION
+        st1 = _bn_stats_rows(x_stats if fuse else None, x, bn1, training)
         a1 = ops.bn_act_fwd(x, st1, 1)
-        t1 = ops.conv1x1_fwd(a1, w1)
-        st2 = _bn_stats(t1, bn2, training)
+        t1, sr2 = ops.conv1x1_fwd_stats(a1, w1) if fuse else (ops.conv1x1_fwd(a1, w1), None)
+        st2 = _bn_stats_rows(sr2, t1, bn2, training)
         a2 = ops.bn_act_fwd(t1, st2, 1)
         t2 = _g3_fwd(a2, wg, groups)
         st3 = _bn_stats(t2, bn3, training)
         a3 = ops.bn_act_fwd(t2, st3, 1)
-        y = ops.conv1x1_fwd(a3, w3, None, x)
+        if fuse and getattr(mod, "emit_stats", False):
+            y, mod._out_stats = ops.conv1x1_fwd_stats(a3, w3, None, x)
+        else:
+            y, mod._out_stats = ops.conv1x1_fwd(a3, w3, None, x), None
         ctx.save_for_backward(x, a1, t1, a2, t2, a3, g1, w1, g2, wg, g3, w3,
                               st1.mean, st1.invstd, st1.scale, st1.shift,
                               st2.mean, st2.invstd, st2.scale, st2.shift,
@@ -533,7 +565,7 @@ class BottleneckFn(Function):
         del dt1
         dg1, db1 = grad_buffer(g1), grad_buffer(ctx.betas[0])
         dx = ops.bn_act_bwd(da1, x, g1, st1, dg1, db1, dy, 1, tr)
-        return dx, dg1, db1, dw1, dg2, db2, dwg, dg3, db3, dw3, None
+        return dx, dg1, db1, dw1, dg2, db2, dwg, dg3, db3, dw3, None, None
 
 
 # ------------------------------------------------------------ leaf layers --

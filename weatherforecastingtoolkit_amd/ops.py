@@ -91,6 +91,32 @@ def conv1x1_fwd(x, w, bias=None, res=None, res_broadcast=False):
     return y
 
 
+class StatRows:
+    """partial BatchNorm sums written by a producer epilogue: `part` = sum[rows][C] ++ sumsq[rows][C]"""
+    __slots__ = ("part", "rows")
+
+    def __init__(self, part, rows):
+        self.part, self.rows = part, rows
+
+
+def conv1x1_fwd_stats(x, w, bias=None, res=None):
+    """conv1x1_fwd whose epilogue also reduces the per-channel sum / sum of squares of y (for the BatchNorm that
+    follows).  -> (y, StatRows | None); None = this shape is not served, run bn_stats_train on y."""
+    import ctypes
+    _chk(x, w, bias, res)
+    nb, cin, h, wd = x.shape
+    cout = w.shape[0]
+    y = torch.empty((nb, cout, h, wd), dtype=x.dtype, device=x.device)
+    cap = 4 * ((nb * h * wd + 127) // 128) * cout
+    part = torch.empty(cap, dtype=torch.float32, device=x.device)
+    rows = ctypes.c_int(0)
+    _call("wfae_conv1x1_fwd_stats", 2 * nb * h * wd * cin * cout,
+          4 * (nb * h * wd * (cin + cout) + cin * cout) + (0 if res is None else 4 * nb * h * wd * cout),
+          _p(x), _p(w), _p(bias), _p(res), cout * h * wd, _p(y), nb, cin, cout, h * wd, _p(part), cap,
+          ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream(), label="wfae_conv1x1_fwd")
+    return y, (StatRows(part, rows.value) if rows.value > 0 else None)
+
+
 def conv1x1_bwd_data(dy, w):
     _chk(dy, w)
     nb, cout, h, wd = dy.shape
@@ -437,6 +463,18 @@ def bn_stats_train(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum
     _call("wfae_bn_stats_train", 0, 4 * x.numel(), _p(x), nb, c, h * wd, _p(gamma), _p(beta), eps, momentum, _p(running_mean),
               _p(running_var), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift), ws.data_ptr(), ws.numel(),
               _stream())
+    return st
+
+
+def bn_stats_from_rows(sr, shape, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
+    """bn_stats_train of a tensor of `shape` (N, C, H, W) whose partial sums a producer epilogue left in `sr`"""
+    _chk(gamma, beta, running_mean, running_var)
+    nb, c, h, wd = shape
+    st = BnStats(c, gamma.device)
+    ws = workspace()
+    _call("wfae_bn_stats_from_rows", 0, 4 * sr.part.numel(), _p(sr.part), sr.rows, nb, c, h * wd, _p(gamma), _p(beta), eps,
+          momentum, _p(running_mean), _p(running_var), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
+          ws.data_ptr(), ws.numel(), _stream(), label="wfae_bn_stats_train")
     return st
 
 

@@ -31,13 +31,18 @@ def _norm_act_conv(c_in, c_out, k, **conv_kw):
 
 
 def _residual_stack(width, depth, groups):
-    return tnn.Sequential(*(Bottleneck(width, groups) for _ in range(depth)))
+    blocks = [Bottleneck(width, groups) for _ in range(depth)]
+    for blk in blocks[:-1]:        # the next module is a Bottleneck, whose first BatchNorm wants the sums of this output
+        blk.emit_stats = True
+    return tnn.Sequential(*blocks)
 
 
 class Bottleneck(tnn.Module):
     """Pre-activation bottleneck  x + W3 . gelu(bn(G3x3 . gelu(bn(W1 . gelu(bn(x))))))  at a quarter of the width in
     the middle (reference ae_64x8x8_lin.py:7-22; `f.0 … f.8` are its Sequential indices).  Runs as ONE autograd
-    node (functional.BottleneckFn): 13 forward launches, the residual add fused into the last 1x1 epilogue."""
+    node (functional.BottleneckFn) with the residual add fused into the last 1x1 epilogue.  With
+    functional.STAT_FUSION (off by default) the BatchNorm sums of both 1x1 outputs also ride in the GEMM epilogues; the
+    sums of the block output travel to the next block as the `_wfae_stats` attribute."""
 
     def __init__(self, channels: int, groups: int = 8):
         super().__init__()
@@ -49,10 +54,16 @@ class Bottleneck(tnn.Module):
                 + _norm_act_conv(inner, channels, 1))
         self.f = tnn.Sequential(*body)
 
+    emit_stats = False   # set by the enclosing stack: reduce the BatchNorm sums of the output for the next block
+    _out_stats = None
+
     def forward(self, x):
         bn1, _, w1, bn2, _, wg, bn3, _, w3 = self.f
-        return Fn.BottleneckFn.apply(x, bn1.weight, bn1.bias, w1.weight, bn2.weight, bn2.bias, wg.weight,
-                                     bn3.weight, bn3.bias, w3.weight, self)
+        y = Fn.BottleneckFn.apply(x, bn1.weight, bn1.bias, w1.weight, bn2.weight, bn2.bias, wg.weight,
+                                  bn3.weight, bn3.bias, w3.weight, self, getattr(x, "_wfae_stats", None))
+        if self._out_stats is not None:
+            y._wfae_stats, self._out_stats = self._out_stats, None
+        return y
 
 
 class EncBlock(tnn.Module):

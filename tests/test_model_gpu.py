@@ -98,7 +98,9 @@ def test_full_model_golden(dev, gname):
             assert relerr(z, g["z"]) < 1e-4
             gn = np.array([p.grad.double().norm().item() for p in net.parameters()])
             rel = np.abs(gn - g["grad_norms"]) / (g["grad_norms"] + 1e-12)
-            assert rel.max() < 2e-3, (names[int(rel.argmax())], rel.max())
+            # measured (tools/debug_gradnorm.py): max 2e-5 / 5e-5 / 9e-5 on the three fixtures, median 4-8e-6; the
+            # reference's own fp32-vs-fp64 spread is 6e-6 max (tests/golden/ae_gradnorm_sensitivity.py)
+            assert rel.max() < 5e-4, (names[int(rel.argmax())], rel.max())
             assert relerr(net.dec[-1].weight.grad, g["g_dec_last_w"]) < 1e-3
             assert relerr(net.enc[0].down[0].weight.grad, g["g_enc0_w"]) < 2e-3
             assert opt.arenas[0].grads_in_arena(), "gradients were not produced inside the flat arena"

@@ -168,7 +168,7 @@ def test_conv4x4s2_winograd(ops, dev, nb, chi, clo, hlo, wlo, mode):
 # -------------------------------------------------------------- direct convs
 @pytest.mark.parametrize("nb,cin,cout,h,w,groups", [
     (2, 32, 32, 16, 16, 8), (1, 64, 64, 12, 20, 8), (2, 128, 128, 8, 8, 8), (2, 256, 256, 8, 8, 8),
-    (2, 16, 1, 16, 16, 1), (1, 128, 1, 24, 40, 1), (3, 8, 8, 7, 9, 2),
+    (2, 16, 1, 16, 16, 1), (1, 128, 1, 24, 40, 1), (3, 8, 8, 7, 9, 2), (2, 64, 1, 20, 28, 1), (3, 128, 1, 48, 48, 1),
 ])
 def test_dconv3x3(ops, dev, nb, cin, cout, h, w, groups):
     x = rnd((nb, cin, h, w), 1)
@@ -183,6 +183,8 @@ def test_dconv3x3(ops, dev, nb, cin, cout, h, w, groups):
     dw = torch.empty_like(wt, device=dev)
     ops.dconv_bwd_weight(dy.to(dev), x.to(dev), dw, 3, 1, 1, groups)
     assert relerr(dw, wr.grad) < TOL
+    ops.dconv_bwd_weight(dy.to(dev), x.to(dev), dw, 3, 1, 1, groups, accumulate=True)
+    assert relerr(dw, 2 * wr.grad) < TOL
 
 
 @pytest.mark.parametrize("nb,cin,cout,h,w,pad", [
@@ -276,8 +278,11 @@ def test_gconv3x3_blocked(ops, dev, nb, c, h, w):
     assert relerr(dw, 2 * wr.grad) < TOL
 
 
-@pytest.mark.parametrize("nb,cout,h,w", [(2, 16, 16, 24), (1, 256, 64, 64), (3, 32, 20, 12)])
+@pytest.mark.parametrize("nb,cout,h,w", [(2, 16, 16, 24), (1, 256, 64, 64), (3, 32, 20, 12), (2, 64, 48, 40), (3, 128, 24, 72),
+                                         (5, 64, 16, 8)])
 def test_dconv4x4s2_cin1(ops, dev, nb, cout, h, w):
+    """first-layer convolution Conv2d(1, C, 4, 2, 1): forward and weight gradient (Cout % 64 == 0 with Wo % 4 == 0 runs
+    the MFMA weight-gradient kernel incl. partial tiles, the rest the generic one), accumulate form included"""
     x, wt, dy = rnd((nb, 1, h, w), 1, 0, 1), rnd((cout, 1, 4, 4), 2, -0.3, 0.3), rnd((nb, cout, h // 2, w // 2), 3)
     xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
     ref = F.conv2d(xr, wr, stride=2, padding=1)
@@ -286,6 +291,8 @@ def test_dconv4x4s2_cin1(ops, dev, nb, cout, h, w):
     dw = torch.empty_like(wt, device=dev)
     ops.dconv_bwd_weight(dy.to(dev), x.to(dev), dw, 4, 2, 1, 1)
     assert relerr(dw, wr.grad) < TOL
+    ops.dconv_bwd_weight(dy.to(dev), x.to(dev), dw, 4, 2, 1, 1, accumulate=True)
+    assert relerr(dw, 2 * wr.grad) < TOL
 
 
 # ----------------------------------------------------------------- BatchNorm

@@ -300,9 +300,17 @@ int wfae_dconv_bwd_weight(const float* dy, const float* x, float* dw, int NB, in
   WFAE_REQUIRE(NB > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && groups > 0 && Cin % groups == 0 &&
                    Cout % groups == 0,
                WFAE_ERR_BAD_SHAPE, "dconv_bwd_weight: bad shape");
+  if (KS == 3 && stride == 1 && pad == 1 && groups == 1 && Cout == 1) {
+    const int rc = c1_wgrad_mfma(1, x, dy, dw, NB, Cin, H, W, accumulate, ws, ws_bytes, (hipStream_t)stream);
+    if (rc != WFAE_ERR_UNSUPPORTED) return rc;
+  }
   if (KS == 3 && stride == 1 && pad == 1 && groups == 1 && Cout == 1 && Cin >= 16 && NB <= 65535) {
     const int rc = c1conv3_wgrad(dy, x, dw, NB, Cin, H, W, accumulate, ws, ws_bytes, (hipStream_t)stream);
     if (rc != WFAE_ERR_WORKSPACE) return rc;      // partials did not fit: generic kernel below
+  }
+  if (KS == 4 && stride == 2 && pad == 1 && Cin == 1 && groups == 1) {
+    const int rc = c1_wgrad_mfma(0, dy, x, dw, NB, Cout, H, W, accumulate, ws, ws_bytes, (hipStream_t)stream);
+    if (rc != WFAE_ERR_UNSUPPORTED) return rc;   // odd shapes: generic kernel below
   }
   const int IG = Cin / groups, OG = Cout / groups;
   const int KK = KS * KS;
@@ -902,9 +910,135 @@ __global__ __launch_bounds__(192) void gconv3_wgrad_mfma_kernel(const float* __r
     }
 }
 
+// -------------------------------------------------------------------------------------
+// Weight gradients in which ONE of the two channel counts is 1:
+//   FLIP = false, KS = 4, S = 2: Conv2d(1, C, 4, 2, 1) — the encoder's first layer (1 -> 256 at 384x384) and the
+//     PatchGAN's (1 -> 64):   dW[c][tap] = sum_p big[c][p] * small[S p - pad + tap],   big = dy, small = the image;
+//   FLIP = true,  KS = 3, S = 1: Conv2d(C, 1, 3, 1, 1) — the decoder's output convolution (128 -> 1):
+//     dW[c][tap] = sum_p x[c][p + tap - 1] dy[p] = sum_q big[c][q] * small[q + 1 - tap],   big = x, small = dy.
+// Either way a (C x pixels) . (pixels x taps) product that is HBM-bound on the single read of `big` (1.2 / 2.4 GB
+// at B = 32).  One v_mfma_f32_16x16x4_f32 tile = 16 channels x 16 tap columns; a block of 4 waves covers 64 channels
+// and walks 4 x 32 pixel tiles: `big` staged as it lies in memory (bgs[c][pixel], row stride 132 words: the
+// 16-byte stores and the fragment reads — lane = (channel, pixel k) -> bank 4 c + k — are conflict-free), the
+// single-channel patch with a row stride that keeps the taps of a pixel on different banks; tile i + 1 is prefetched into registers while
+// tile i is multiplied.  (Generic dconv_wgrad_kernel: 1.49 ms on the first layer; c1conv3_wgrad: 1.45 ms.)
+// -------------------------------------------------------------------------------------
+template <int KS, int S, bool FLIP>
+__global__ __launch_bounds__(256) void c1_wgrad_mfma_kernel(const float* __restrict__ big, const float* __restrict__ small,
+                                                            float* __restrict__ part, int NB, int C, int Hs, int Ws,
+                                                            int Hb, int Wb, int pad, int tiles_x, int tiles_y, int parts) {
+  // 4 x 32 pixel tiles: a tile row of one channel is one whole 128-byte line of `big` (16-pixel-wide tiles read half
+  // lines and ran at 3.2 TB/s of useful bytes)
+  constexpr int TH = 4, TW = 32, NPIX = TH * TW, CB = 64, DLD = NPIX + 4, KK = KS * KS;  // bgs[c][pixel], stride 132
+  constexpr int PH = S * (TH - 1) + KS, PW = S * (TW - 1) + KS;      // 10 x 66 / 6 x 34
+  constexpr int ROWS = S == 2 ? 68 : 36;                             // tap (ky, kx) -> bank 4 ky + kx
+  constexpr int PSLOT = (PH * PW + 255) / 256;
+  static_assert(KK <= 16, "taps fit the 16 MFMA columns");
+  __shared__ __attribute__((aligned(16))) float bgs[CB * DLD];
+  __shared__ float xs[PH * ROWS];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int c0 = blockIdx.y * CB;
+  const int lm = lane & 15, kq = lane >> 4;          // A: channel 16 wave + lm;  B: tap lm;  k lane = pixel
+  const int tky = lm < KK ? lm / KS : 0, tkx = lm < KK ? lm % KS : 0;   // columns >= KK compute garbage, never stored
+  const int tapoff = FLIP ? (KS - 1 - tky) * ROWS + (KS - 1 - tkx) : tky * ROWS + tkx;
+  const long HWb = (long)Hb * Wb;
+
+  g3_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // staging maps: big — thread -> (q = t % 8, row = (t / 8) % 4, cl0 = t / 32), slot j = channel cl0 + 8 j;
+  // patch — elements t + 256 j of the PH x PW patch
+  const int dq = t & 7, dr = (t >> 3) & 3, dcl = t >> 5;
+  float4 rd[8];
+  float rp[PSLOT];
+  const int per_img = tiles_x * tiles_y, total = NB * per_img;
+  auto prefetch = [&](int tile) {
+    const int n = tile / per_img;
+    const int tr = tile - n * per_img;
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+    const int oy = oy0 + dr, ox = ox0 + dq * 4;
+    const bool dok = oy < Hb && ox < Wb;            // Wb % 4 == 0
+    const float* __restrict__ dp = big + ((long)n * C + c0 + dcl) * HWb + (dok ? (long)oy * Wb + ox : 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(dp + (long)(8 * j) * HWb);
+      rd[j] = dok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float* __restrict__ xp = small + (long)n * Hs * Ws;
+    const int py0 = FLIP ? oy0 - pad : S * oy0 - pad, px0 = FLIP ? ox0 - pad : S * ox0 - pad;
+#pragma unroll
+    for (int j = 0; j < PSLOT; ++j) {
+      const int idx = t + j * 256;
+      const int ry = idx / PW, rx = idx - ry * PW;
+      const int iy = py0 + ry, ix = px0 + rx;
+      const bool ok = idx < PH * PW && iy >= 0 && iy < Hs && ix >= 0 && ix < Ws;
+      const float v = xp[ok ? (long)iy * Ws + ix : 0];
+      rp[j] = ok ? v : 0.f;
+    }
+  };
+  if ((int)blockIdx.x < total) prefetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < total; tile += parts) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      *reinterpret_cast<float4*>(bgs + (dcl + 8 * j) * DLD + dr * TW + dq * 4) = rd[j];
+#pragma unroll
+    for (int j = 0; j < PSLOT; ++j) {
+      const int idx = t + j * 256;
+      const int ry = idx / PW, rx = idx - ry * PW;
+      if (idx < PH * PW) xs[ry * ROWS + rx] = rp[j];
+    }
+    __syncthreads();
+    if (tile + parts < total) prefetch(tile + parts);
+    const float* __restrict__ ab = bgs + (wave * 16 + lm) * DLD + kq;
+    const float* __restrict__ bb = xs + tapoff + S * kq;
+#pragma unroll
+    for (int r = 0; r < TH; ++r)
+#pragma unroll
+      for (int s = 0; s < TW / 4; ++s) {
+        const float a = ab[r * TW + s * 4];
+        const float b = bb[S * r * ROWS + 4 * S * s];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      }
+  }
+  // C/D: column = lane % 16 = tap, row = channel 4 kq + reg of this wave's 16
+  if (lm < KK) {
+    float* __restrict__ dst = part + (long)blockIdx.x * C * KK + (long)(c0 + wave * 16) * KK;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[(4 * kq + r) * KK + lm] = acc[r];
+  }
+}
+
 }  // namespace
 
 namespace wfae {
+// Conv2d(1, C, 4, 2, 1) (flip = 0: big = dy (N,C,H/2,W/2), small = x (N,1,H,W)) or Conv2d(C, 1, 3, 1, 1) (flip = 1:
+// big = x (N,C,H,W), small = dy (N,1,H,W)) weight gradient on c1_wgrad_mfma_kernel; WFAE_ERR_UNSUPPORTED for shapes
+// it does not take (odd sizes, C % 64, unaligned `big`, workspace)
+int c1_wgrad_mfma(int flip, const float* big, const float* small, float* dw, int NB, int C, int H, int W,
+                  int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  static const int on = getenv("WFAE_C1_WGRAD_MFMA") ? atoi(getenv("WFAE_C1_WGRAD_MFMA")) : 1;
+  const int Hb = flip ? H : H / 2, Wb = flip ? W : W / 2;
+  if (!on || (!flip && ((H & 1) || (W & 1))) || C % 64 != 0 || Wb % 4 != 0 ||
+      (reinterpret_cast<uintptr_t>(big) & 15) != 0 || C / 64 > 65535)
+    return WFAE_ERR_UNSUPPORTED;
+  const int tiles_x = cdiv(Wb, 32), tiles_y = cdiv(Hb, 4);
+  const long total = (long)NB * tiles_x * tiles_y;
+  const int gy = C / 64, KK = flip ? 9 : 16;
+  long parts = cdiv(1024, gy);
+  if (parts > total / 2) parts = total / 2 > 0 ? total / 2 : 1;
+  const size_t out_elems = (size_t)C * KK;
+  if (!ws || (size_t)parts * out_elems * sizeof(float) > ws_bytes) return WFAE_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)parts, gy);
+  if (flip)
+    hipLaunchKernelGGL((c1_wgrad_mfma_kernel<3, 1, true>), grid, dim3(256), 0, st, big, small, (float*)ws, NB, C, H, W, Hb,
+                       Wb, 1, tiles_x, tiles_y, (int)parts);
+  else
+    hipLaunchKernelGGL((c1_wgrad_mfma_kernel<4, 2, false>), grid, dim3(256), 0, st, big, small, (float*)ws, NB, C, H, W, Hb,
+                       Wb, 1, tiles_x, tiles_y, (int)parts);
+  int rc = check_launch("c1_wgrad_mfma");
+  if (rc) return rc;
+  return slab_reduce((const float*)ws, dw, nullptr, (long)out_elems, 1, (int)parts, accumulate, st);
+}
+
 // weight gradient of the grouped 3x3 conv for 4 / 8 / 16 / 32 channels per group on the MFMA kernel above;
 // returns WFAE_ERR_UNSUPPORTED otherwise (WFAE_G3_WGRAD_MFMA=0: always)
 int gconv3_wgrad_mfma(const float* dy, const float* x, float* dw, int NB, int C, int H, int W, int groups,

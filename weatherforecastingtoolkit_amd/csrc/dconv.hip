@@ -97,6 +97,82 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(DConvP p) {
   }
 }
 
+// -------------------------------------------------------------------------------------
+// Convolutions whose INPUT has one channel: the encoder's / PatchGAN's first layer Conv2d(1, C, 4, 2, 1) and the data
+// gradient of the output convolution Conv2d(C, 1, 3, 1, 1) (a 3x3 stride-1 convolution of the one-channel dy with
+// the flipped taps).  y[c][p] = sum_tap w[c][tap] * s[S p - pad + tap]: every output element is KS^2 FMAs on a
+// neighbourhood that is the same for all C channels, so a thread keeps the neighbourhood of its 4 consecutive output
+// pixels in registers, walks the channels with wave-uniform (scalar) weight loads and streams one float4 per channel
+// to HBM — no LDS, whole 1 KB row segments per wave store.  HBM-bound on the write of y.
+// -------------------------------------------------------------------------------------
+template <int KS, int S, bool FLIP>
+__global__ __launch_bounds__(256) void c1in_conv_kernel(const float* __restrict__ s_, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int C,
+                                                        int Hs, int Ws, int Ho, int Wo, int pad, int cpb) {
+  constexpr int KK = KS * KS, NW = 3 * S + KS;   // neighbourhood: KS rows x NW columns
+  const int WQ = Wo >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)Ho * WQ) return;
+  const int oy = (int)(idx / WQ), ox = (int)(idx - (long)oy * WQ) * 4;
+  const int n = blockIdx.z;
+  const float* __restrict__ sp = s_ + (long)n * Hs * Ws;
+  float nb[KS][NW];
+#pragma unroll
+  for (int r = 0; r < KS; ++r) {
+    const int iy = S * oy - pad + r;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const int ix = S * ox - pad + q;
+      const bool ok = iy >= 0 && iy < Hs && ix >= 0 && ix < Ws;
+      const float v = sp[ok ? (long)iy * Ws + ix : 0];
+      nb[r][q] = ok ? v : 0.f;
+    }
+  }
+  const int c0 = blockIdx.y * cpb;
+  const int c1 = min(C, c0 + cpb);
+  float* __restrict__ yp = y + ((long)n * C + c0) * Ho * Wo + (long)oy * Wo + ox;
+  const long plane = (long)Ho * Wo;
+#pragma unroll 2
+  for (int c = c0; c < c1; ++c) {
+    const float* __restrict__ wc = w + (long)c * KK;   // wave-uniform: scalar loads
+    const float b = bias ? bias[c] : 0.f;
+    float o0 = b, o1 = b, o2 = b, o3 = b;
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const float wv = FLIP ? wc[KK - 1 - (ky * KS + kx)] : wc[ky * KS + kx];
+        o0 = fmaf(nb[ky][kx], wv, o0);
+        o1 = fmaf(nb[ky][S + kx], wv, o1);
+        o2 = fmaf(nb[ky][2 * S + kx], wv, o2);
+        o3 = fmaf(nb[ky][3 * S + kx], wv, o3);
+      }
+    typedef float vf4s __attribute__((ext_vector_type(4)));
+    const vf4s o = {o0, o1, o2, o3};
+    __builtin_nontemporal_store(o, reinterpret_cast<vf4s*>(yp));
+    yp += plane;
+  }
+}
+
+// s: (N,1,Hs,Ws); y: (N,C,Ho,Wo); w: C x KS x KS taps (flip: used mirrored).  WFAE_ERR_UNSUPPORTED when Wo % 4 != 0
+// or y is not 16-byte aligned (the generic kernels then run).
+template <int KS, int S, bool FLIP>
+int launch_c1in_conv(const float* s_, const float* w, const float* bias, float* y, int NB, int C, int Hs, int Ws, int Ho,
+                     int Wo, int pad, hipStream_t st) {
+  static const int on = getenv("WFAE_C1IN_CONV") ? atoi(getenv("WFAE_C1IN_CONV")) : 1;
+  if (!on || Wo % 4 != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0 || NB > 65535) return WFAE_ERR_UNSUPPORTED;
+  const long threads = (long)Ho * (Wo / 4);
+  const int bx = cdiv(threads, 256);
+  // channel chunks so that the grid has a few thousand blocks; every chunk re-reads the (tiny) one-channel input
+  int chunks = cdiv(4096, (long)bx * NB);
+  if (chunks < 1) chunks = 1;
+  if (chunks > C) chunks = C;
+  const int cpb = cdiv(C, chunks);
+  hipLaunchKernelGGL((c1in_conv_kernel<KS, S, FLIP>), dim3(bx, cdiv(C, cpb), NB), dim3(256), 0, st, s_, w, bias, y, C, Hs,
+                     Ws, Ho, Wo, pad, cpb);
+  return check_launch("c1in_conv");
+}
+
 template <int KS, int S, bool TR>
 int launch_dconv(const DConvP& p, int NB, hipStream_t st) {
   const int OG = p.Cout / p.groups;
@@ -261,6 +337,10 @@ int wfae_dconv_fwd(const float* x, const float* w, const float* bias, float* y, 
     if (use_c1 && KS == 3 && stride == 1 && pad == 1 && groups == 1 && Cout == 1 && Cin >= 16)
       return c1conv3_fwd(x, w, bias, y, NB, Cin, H, W, (hipStream_t)stream);
   }
+  if (Cin == 1 && groups == 1 && KS == 4 && stride == 2 && pad == 1 && !(H & 1) && !(W & 1)) {
+    const int rc = launch_c1in_conv<4, 2, false>(x, w, bias, y, NB, Cout, H, W, H / 2, W / 2, 1, (hipStream_t)stream);
+    if (rc != WFAE_ERR_UNSUPPORTED) return rc;
+  }
   DConvP p = {};
   p.x = x; p.w = w; p.bias = bias; p.y = y;
   p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.pad = pad; p.groups = groups;
@@ -283,6 +363,11 @@ int wfae_dconv_bwd_data(const float* dy, const float* w, float* dx, int NB, int 
   WFAE_REQUIRE((KS == 3 || KS == 4) && pad <= KS - 1, WFAE_ERR_UNSUPPORTED,
                "dconv_bwd_data: stride-1 3x3 / 4x4 convolutions");
   WFAE_REQUIRE(NB <= 65535, WFAE_ERR_BAD_SHAPE, "dconv_bwd_data: batch > 65535");
+  if (Cout == 1 && groups == 1 && KS == 3 && pad == 1) {
+    // one-channel dy: dx[c][p] = sum_tap w[0][c][tap] dy[p + 1 - tap] = a 3x3 convolution of dy with the flipped taps
+    const int rc = launch_c1in_conv<3, 1, true>(dy, w, nullptr, dx, NB, Cin, H, W, H, W, 1, (hipStream_t)stream);
+    if (rc != WFAE_ERR_UNSUPPORTED) return rc;
+  }
   // data gradient = stride-1 convolution of dy (Cout channels, (H+2pad-KS+1) x (W+2pad-KS+1)) producing the
   // Cin x H x W input gradient with transposed + spatially flipped weights and pad' = KS-1-pad.
   DConvP p = {};

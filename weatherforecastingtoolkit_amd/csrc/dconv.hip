@@ -57,14 +57,40 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(DConvP p) {
   for (int ci0 = 0; ci0 < IG; ci0 += CIB) {
     const int cn = min(CIB, IG - ci0);
     __syncthreads();
-    for (int idx = t; idx < cn * TIH * TIW; idx += 256) {
-      const int c = idx / (TIH * TIW);
-      const int r = idx - c * (TIH * TIW);
-      const int ry = r / TIW, rx = r - ry * TIW;
-      const int iy = iy_base + ry, ix = ix_base + rx;
-      float v = 0.f;
-      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = xg[((long)(ci0 + c) * p.H + iy) * p.W + ix];
-      xs[c][ry][rx] = v;
+    if (cn == CIB) {
+      // full chunk: all loads of the patch are issued before the first LDS store (the rolled loop below waits for
+      // every element: load -> store -> load ...), out-of-image elements read a clamped address and are zeroed
+      constexpr int NSLOT = (CIB * TIH * TIW + 255) / 256;
+      float rv[NSLOT];
+#pragma unroll
+      for (int j = 0; j < NSLOT; ++j) {
+        const int idx = t + j * 256;
+        const int c = idx / (TIH * TIW);
+        const int r = idx - c * (TIH * TIW);
+        const int ry = r / TIW, rx = r - ry * TIW;
+        const int iy = iy_base + ry, ix = ix_base + rx;
+        const bool ok = idx < CIB * TIH * TIW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const float v = xg[ok ? ((long)(ci0 + c) * p.H + iy) * p.W + ix : 0];
+        rv[j] = ok ? v : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < NSLOT; ++j) {
+        const int idx = t + j * 256;
+        const int c = idx / (TIH * TIW);
+        const int r = idx - c * (TIH * TIW);
+        const int ry = r / TIW, rx = r - ry * TIW;
+        if (idx < CIB * TIH * TIW) xs[c][ry][rx] = rv[j];
+      }
+    } else {
+      for (int idx = t; idx < cn * TIH * TIW; idx += 256) {
+        const int c = idx / (TIH * TIW);
+        const int r = idx - c * (TIH * TIW);
+        const int ry = r / TIW, rx = r - ry * TIW;
+        const int iy = iy_base + ry, ix = ix_base + rx;
+        float v = 0.f;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = xg[((long)(ci0 + c) * p.H + iy) * p.W + ix];
+        xs[c][ry][rx] = v;
+      }
     }
     __syncthreads();
     for (int c = 0; c < cn; ++c) {

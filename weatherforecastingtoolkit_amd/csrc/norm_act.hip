@@ -115,6 +115,29 @@ __global__ __launch_bounds__(256) void stat_rows_reduce_kernel(const float* __re
   }
 }
 
+// column sums of a row-major matrix x[rows][C] (bias gradient of nn.Linear: inner == 1 in wfae_reduce_sum), first
+// stage: block (column block, row slice) = 64 columns x 16 row groups over `rps` rows, coalesced reads along the
+// columns, fp64 partials in the layout sum_finalize_kernel reads.  (chan_reduce_kernel walks a column with stride C:
+// 22 us per call on 2048 x 512 problems.)
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, int rows, int C, int rps,
+                                                      double* __restrict__ part, int splits) {
+  __shared__ double sm[16][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, s = blockIdx.y;
+  const long r1 = min((long)rows, (long)(s + 1) * rps);
+  double a = 0.0;
+  if (c < C)
+    for (long r = (long)s * rps + rg; r < r1; r += 16) a += (double)x[r * C + c];
+  sm[rg][cl] = a;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += sm[r][cl];
+    part[((long)c * splits + s) * 2] = t;
+  }
+}
+
 __global__ void bn_finalize_kernel(const double* __restrict__ part, int splits, long count, int C,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ running_mean,
@@ -734,6 +757,19 @@ int wfae_reduce_sum(const float* x, int outer, int C, int inner, float* out, int
   const long maxp = (long)(ws_bytes / (sizeof(double) * 2 * (size_t)C));
   WFAE_REQUIRE(ws && maxp >= 1, WFAE_ERR_WORKSPACE, "reduce_sum: workspace too small");
   hipStream_t st = (hipStream_t)stream;
+  if (inner == 1) {  // x[outer][C]: column sums in two coalesced stages
+    int splits = cdiv(outer, 64);
+    if (splits > maxp) splits = (int)maxp;
+    if (splits > 1024) splits = 1024;
+    const int rps = cdiv(outer, splits);
+    splits = cdiv(outer, rps);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64), splits), dim3(1024), 0, st, x, outer, C, rps, (double*)ws, splits);
+    int rc = check_launch("reduce_sum_cols");
+    if (rc) return rc;
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, splits, C, out,
+                       accumulate);
+    return check_launch("reduce_sum_finalize");
+  }
   // channel index goes to grid.x: fold very wide C (linear bias, pos_emb) into chunks of 65535*... (grid.x is 2^31)
   RedGeom g = red_geom(outer, C, inner, maxp < 65535 ? maxp : 65535);
   const int vec = (inner % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);

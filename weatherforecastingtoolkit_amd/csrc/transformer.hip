@@ -85,14 +85,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
-__global__ void ln_param_reduce_kernel(const float* __restrict__ part, int blocks, int E, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int beta) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= E) return;
+// block = 64 columns x 16 row groups: the per-block partials are added 16-way in parallel, then combined through LDS
+// in a fixed order
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ part, int blocks, int E,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               int beta) {
+  __shared__ float sa[16][64], sc[16][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + cl;
   float a = 0.f, c = 0.f;
-  for (int b = 0; b < blocks; ++b) { a += part[((long)b * 2) * E + i]; c += part[((long)b * 2 + 1) * E + i]; }
-  dgamma[i] = (beta ? dgamma[i] : 0.f) + a;
-  dbeta[i] = (beta ? dbeta[i] : 0.f) + c;
+  if (i < E)
+    for (int b = rg; b < blocks; b += 16) { a += part[((long)b * 2) * E + i]; c += part[((long)b * 2 + 1) * E + i]; }
+  sa[rg][cl] = a;
+  sc[rg][cl] = c;
+  __syncthreads();
+  if (rg == 0 && i < E) {
+    float ta = 0.f, tc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ta += sa[r][cl]; tc += sc[r][cl]; }
+    dgamma[i] = (beta ? dgamma[i] : 0.f) + ta;
+    dbeta[i] = (beta ? dbeta[i] : 0.f) + tc;
+  }
 }
 
 // ---------------------------------------------------------------- attention
@@ -268,8 +281,10 @@ int wfae_layernorm_bwd(const float* dy, const float* x, const float* res, const 
   WFAE_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, WFAE_ERR_NULL_POINTER,
                "layernorm_bwd: null pointer");
   WFAE_REQUIRE(rows > 0 && E > 0 && E <= 2048, WFAE_ERR_BAD_SHAPE, "layernorm_bwd: bad shape");
-  int blocks = cdiv(rows, 64);
-  if (blocks > 256) blocks = 256;
+  // 8 rows per block (2 per wave): the row loop is a chain of dependent wave reductions, so rows per wave, not bytes,
+  // set the time — 64 rows per block left 2048-row problems on 32 blocks (120 us per call in the ViT step)
+  int blocks = cdiv(rows, 8);
+  if (blocks > 1024) blocks = 1024;
   const int rpb = cdiv(rows, blocks);
   blocks = cdiv(rows, rpb);
   const size_t need = (size_t)blocks * 2 * E * sizeof(float);
@@ -279,7 +294,7 @@ int wfae_layernorm_bwd(const float* dy, const float* x, const float* res, const 
                      gamma, mean, rstd, dx, (float*)ws, rows, E, rpb);
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(E, 128)), dim3(128), 0, st, (const float*)ws, blocks, E, dgamma,
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(E, 64)), dim3(1024), 0, st, (const float*)ws, blocks, E, dgamma,
                      dbeta, accumulate);
   return check_launch("layernorm_bwd_reduce");
 }

@@ -85,6 +85,63 @@ def test_conv4_forms_adjoint_and_bilinear_full_size(dev):
         ops.set_winograd("auto")
 
 
+@pytest.mark.parametrize("c,h", [(256, 48), (128, 96), (64, 192), (32, 384)])
+def test_grouped3x3_forms_adjoint_full_size(dev, c, h):
+    """grouped 3x3 convolution of the Bottleneck at the four channels-per-group widths of the model, B = 32, full
+    resolution: <fwd(x), y> = <x, dgrad(y)> = <w, wgrad(y, x)> (the MFMA kernels at 16 / 32 channels per group, the
+    MFMA weight gradient at all four), linearity, and agreement with the pre-MFMA kernels"""
+    import os
+    from weatherforecastingtoolkit_amd import ops
+    torch.manual_seed(1)
+    b, g = 32, 8
+    x = torch.rand(b, c, h, h, device=dev) - 0.5
+    y = torch.rand(b, c, h, h, device=dev) - 0.5
+    w = (torch.rand(c, c // g, 3, 3, device=dev) - 0.5) * 0.2
+    f = ops.gconv3x3_fwd(x, w, g, False)
+    d = ops.gconv3x3_fwd(y, w, g, True)
+    dw = torch.empty_like(w)
+    ops.gconv3x3_bwd_weight(y, x, dw, g)
+    a1 = (f.double() * y.double()).sum().item()
+    a2 = (x.double() * d.double()).sum().item()
+    a3 = (w.double() * dw.double()).sum().item()
+    scale = (f.double().norm() * y.double().norm()).item()
+    assert abs(a1 - a2) < 1e-5 * scale and abs(a1 - a3) < 1e-5 * scale, (a1, a2, a3, scale)
+    assert relerr(ops.gconv3x3_fwd(2.0 * x, w, g, False), 2.0 * f) < 1e-5
+    dw2 = dw.clone()
+    ops.gconv3x3_bwd_weight(y, x, dw2, g, accumulate=True)
+    assert relerr(dw2, 2.0 * dw) < 1e-5
+
+
+def test_one_channel_convs_adjoint_full_size(dev):
+    """first layer Conv2d(1, 256, 4, 2, 1) and output convolution Conv2d(128, 1, 3, 1, 1) at B = 32, 384 x 384:
+    <conv(x), y> = <w, wgrad(y, x)> (= <x, dgrad(y)> for the output convolution, whose data gradient is built)"""
+    from weatherforecastingtoolkit_amd import ops
+    torch.manual_seed(2)
+    b = 32
+    x1 = torch.rand(b, 1, 384, 384, device=dev)
+    w1 = (torch.rand(256, 1, 4, 4, device=dev) - 0.5) * 0.3
+    y1 = torch.rand(b, 256, 192, 192, device=dev) - 0.5
+    f1 = ops.dconv_fwd(x1, w1, None, 4, 2, 1, 1)
+    dw1 = torch.empty_like(w1)
+    ops.dconv_bwd_weight(y1, x1, dw1, 4, 2, 1, 1)
+    a1 = (f1.double() * y1.double()).sum().item()
+    a3 = (w1.double() * dw1.double()).sum().item()
+    assert abs(a1 - a3) < 1e-5 * (f1.double().norm() * y1.double().norm()).item(), (a1, a3)
+    del x1, y1, f1
+    x2 = torch.rand(b, 128, 384, 384, device=dev) - 0.5
+    w2 = (torch.rand(1, 128, 3, 3, device=dev) - 0.5) * 0.1
+    y2 = torch.rand(b, 1, 384, 384, device=dev) - 0.5
+    f2 = ops.dconv_fwd(x2, w2, None, 3, 1, 1, 1)
+    d2 = ops.dconv_bwd_data(y2, w2, 128, 3, 1, 1)
+    dw2 = torch.empty_like(w2)
+    ops.dconv_bwd_weight(y2, x2, dw2, 3, 1, 1, 1)
+    b1 = (f2.double() * y2.double()).sum().item()
+    b2 = (x2.double() * d2.double()).sum().item()
+    b3 = (w2.double() * dw2.double()).sum().item()
+    scale = (f2.double().norm() * y2.double().norm()).item()
+    assert abs(b1 - b2) < 1e-5 * scale and abs(b1 - b3) < 1e-5 * scale, (b1, b2, b3, scale)
+
+
 def test_train_step_is_deterministic(dev):
     """two runs of the same B = 8, 384^2 step give bit-identical loss, reconstruction and gradients"""
     from weatherforecastingtoolkit_amd import functional as Fn

@@ -1273,7 +1273,12 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // choose split count so tiles*splits covers the chip a few times over
 inline int pick_splits(int M, int N, int K, size_t ws_bytes, int* k_per_split, bool big_tiles = false) {
-  const long tiles = (long)cdiv(M, big_tiles && M >= 256 ? 256 : (M > 64 ? 128 : (M > 32 ? 64 : 32))) * cdiv(N, BN);
+  int bm = big_tiles && M >= 256 ? 256 : (M > 64 ? 128 : (M > 32 ? 64 : 32));
+  // short reductions (the 512..2048-deep linear layers of the token models): shrink the tile before splitting K —
+  // 2048 x 512 x 512 used to run as 64 tiles x 16 splits of two stages each plus a 16-slab reduce
+  if (K <= 4096)
+    while (bm > 32 && (long)cdiv(M, bm) * cdiv(N, BN) < 512) bm >>= 1;
+  const long tiles = (long)cdiv(M, bm) * cdiv(N, BN);
   const int stages = cdiv(K, BK);
   long want = (1024 + tiles - 1) / tiles;
   if (want < 1) want = 1;

@@ -116,13 +116,19 @@ template <int D>
 __global__ __launch_bounds__(64) void mha_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                      float* __restrict__ probs, int S, int N, int H, float scale,
                                                      float p_drop, unsigned long long seed, long rs, long rn) {
-  __shared__ float ks[64][D + 1], vs[64][D + 1];
+  // rows padded to D + 4 words: 16-byte aligned, so a key / value row is read (all lanes the same address: an LDS
+  // broadcast) as D / 4 ds_read_b128 instead of D ds_read_b32 — the loops below are LDS-instruction bound
+  static_assert(D % 4 == 0, "head dim");
+  __shared__ __attribute__((aligned(16))) float ks[64][D + 4], vs[64][D + 4];
   const int n = blockIdx.x / H, h = blockIdx.x % H;
   const int E = H * D, i = threadIdx.x;
   if (i < S) {
-    const float* row = qkv + ((long)i * rs + (long)n * rn) * 3 * E + h * D;
+    const float4* row4 = reinterpret_cast<const float4*>(qkv + ((long)i * rs + (long)n * rn) * 3 * E + h * D);
 #pragma unroll
-    for (int d = 0; d < D; ++d) { ks[i][d] = row[E + d]; vs[i][d] = row[2 * E + d]; }
+    for (int d = 0; d < D / 4; ++d) {
+      *reinterpret_cast<float4*>(&ks[i][4 * d]) = row4[E / 4 + d];
+      *reinterpret_cast<float4*>(&vs[i][4 * d]) = row4[2 * E / 4 + d];
+    }
   }
   __syncthreads();
   if (i >= S) return;
@@ -135,7 +141,13 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const float* __restrict__ q
   for (int j = 0; j < S; ++j) {
     float s = 0.f;
 #pragma unroll
-    for (int d = 0; d < D; ++d) s = fmaf(q[d], ks[j][d], s);
+    for (int d = 0; d < D / 4; ++d) {
+      const float4 k4 = *reinterpret_cast<const float4*>(&ks[j][4 * d]);
+      s = fmaf(q[4 * d], k4.x, s);
+      s = fmaf(q[4 * d + 1], k4.y, s);
+      s = fmaf(q[4 * d + 2], k4.z, s);
+      s = fmaf(q[4 * d + 3], k4.w, s);
+    }
     pr[j] = s;
     mx = fmaxf(mx, s);
   }
@@ -151,7 +163,13 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const float* __restrict__ q
     pr[j] = pj;  // softmax probabilities (before dropout) saved for backward
     if (p_drop > 0.f) pj = rng01(seed, (((unsigned long long)n * H + h) * S + i) * S + j) >= p_drop ? pj * keep : 0.f;
 #pragma unroll
-    for (int d = 0; d < D; ++d) o[d] = fmaf(pj, vs[j][d], o[d]);
+    for (int d = 0; d < D / 4; ++d) {
+      const float4 v4 = *reinterpret_cast<const float4*>(&vs[j][4 * d]);
+      o[4 * d] = fmaf(pj, v4.x, o[4 * d]);
+      o[4 * d + 1] = fmaf(pj, v4.y, o[4 * d + 1]);
+      o[4 * d + 2] = fmaf(pj, v4.z, o[4 * d + 2]);
+      o[4 * d + 3] = fmaf(pj, v4.w, o[4 * d + 3]);
+    }
   }
 #pragma unroll
   for (int d = 0; d < D; ++d) out[((long)i * rs + (long)n * rn) * E + h * D + d] = o[d];

@@ -1,0 +1,85 @@
+"""Run under LD_PRELOAD=<libclang_rt.asan> by tests/test_abi_cpu.py (CPU box only): drives the host side of every
+C-ABI family of the sanitizer build (csrc/build_asan.sh: AddressSanitizer + UBSan, no device code) with null pointers,
+bad shapes, short workspaces, misaligned operands and plausible full-size geometries.  With fake non-null device
+pointers an entry point runs ALL its host code (tile / split selection, workspace carving, grid arithmetic) up to the
+launch, which fails cleanly without a GPU.  Any sanitizer report aborts the process; the test asserts exit code 0."""
+import ctypes
+import sys
+
+sys.path.insert(0, sys.argv[2])
+from weatherforecastingtoolkit_amd import _lib  # noqa: E402
+
+lib = _lib.load(sys.argv[1])
+P = 0x7F0000000000          # fake, 16-byte aligned "device" addresses (never dereferenced on the host)
+Q, R, S = P + (1 << 32), P + (2 << 32), P + (3 << 32)
+WS = P + (8 << 32)
+checked = 0
+
+
+def expect(rc, want, what):
+    global checked
+    checked += 1
+    ok = rc in want if isinstance(want, (tuple, list, set)) else rc == want
+    if not ok:
+        print(f"FAIL {what}: rc={rc} want={want} msg={lib.wfae_last_error_string()}")
+        sys.exit(3)
+
+
+NULL, SHAPE, WSP = -2, -1, None
+codes = {}
+for line in open(_lib.HEADER):
+    line = line.strip()
+    if line.startswith("#define WFAE_ERR_") or line.startswith("WFAE_ERR_"):
+        parts = line.replace("=", " ").replace(",", " ").split()
+        try:
+            codes[[p for p in parts if p.startswith("WFAE_ERR_")][0]] = int(parts[-1])
+        except (ValueError, IndexError):
+            pass
+NULL = codes.get("WFAE_ERR_NULL_POINTER", -2)
+SHAPE = codes.get("WFAE_ERR_BAD_SHAPE", -1)
+WSP = codes.get("WFAE_ERR_WORKSPACE", -4)
+LAUNCH = codes.get("WFAE_ERR_LAUNCH", -5)
+ANY_FAIL = set(range(-16, 0))
+
+# --- null pointers / bad shapes are rejected before anything else
+expect(lib.wfae_conv1x1_fwd(None, None, None, None, 0, None, 1, 1, 1, 1, None), NULL, "conv1x1_fwd null")
+expect(lib.wfae_conv1x1_fwd(P, Q, None, None, 0, R, 0, 1, 1, 1, None), SHAPE, "conv1x1_fwd NB=0")
+expect(lib.wfae_conv1x1_fwd(P, Q, None, None, 0, R, 1 << 16, 8, 8, 1 << 16, None), SHAPE, "conv1x1_fwd NB*HW overflow")
+expect(lib.wfae_adamw(None, None, None, None, 10, 0.1, 0.9, 0.999, 1e-8, 0.0, 0.1, 0.001, 1.0, None), NULL, "adamw null")
+expect(lib.wfae_conv1x1_bwd_weight(P, Q, R, 32, 128, 32, 384 * 384, 0, WS, 16, None), WSP, "conv1x1 wgrad short workspace")
+expect(lib.wfae_linear_fwd(P, Q, None, R, 32, 36864, 2048, WS, 1024, None), WSP, "linear_fwd short workspace")
+# --- transformer entry points: alignment of the float4-read qkv buffer, dropout range in fwd AND bwd
+expect(lib.wfae_mha_fwd(P + 4, Q, R, 32, 64, 8, 8, 0, 0.0, 1, None), SHAPE, "mha_fwd misaligned qkv")
+expect(lib.wfae_mha_fwd(P, Q, R, 32, 64, 8, 8, 0, 1.0, 1, None), SHAPE, "mha_fwd p_drop = 1")
+expect(lib.wfae_mha_bwd(P, Q, R, S, 32, 64, 8, 8, 0, 1.0, 1, None), SHAPE, "mha_bwd p_drop = 1")
+expect(lib.wfae_mha_bwd(P, Q, R, S, 32, 64, 8, 8, 0, -0.5, 1, None), SHAPE, "mha_bwd p_drop < 0")
+expect(lib.wfae_mha_fwd(P, Q, R, 65, 64, 8, 8, 0, 0.0, 1, None), SHAPE, "mha_fwd S > 64")
+
+# --- full host paths at the model's real geometries (B = 32, 384x384): tile / split-K selection, workspace carving and
+#     grid arithmetic all run; the launch itself fails without a GPU (any negative status is fine, a sanitizer report
+#     or a crash is not)
+big = 1 << 33
+for (c, h) in [(256, 192), (512, 96), (1024, 48), (1024, 24), (128, 384)]:
+    hw, mid = h * h, c // 4
+    expect(lib.wfae_conv1x1_fwd(P, Q, None, None, 0, R, 32, c, mid, hw, None), ANY_FAIL, f"conv1x1_fwd {c}@{h}")
+    expect(lib.wfae_conv1x1_fwd(P, Q, None, S, c * hw, R, 32, mid, c, hw, None), ANY_FAIL, f"conv1x1_fwd+res {c}@{h}")
+    expect(lib.wfae_conv1x1_bwd_data(P, Q, R, 32, c, mid, hw, None), ANY_FAIL, f"conv1x1_bwd_data {c}@{h}")
+    expect(lib.wfae_conv1x1_bwd_weight(P, Q, R, 32, c, mid, hw, 0, WS, big, None), ANY_FAIL, f"conv1x1_bwd_weight {c}@{h}")
+    expect(lib.wfae_gconv3x3_fwd(P, Q, R, 32, mid, h, h, 8, 0, WS, big, None), ANY_FAIL, f"gconv3x3_fwd {mid}@{h}")
+    expect(lib.wfae_gconv3x3_bwd_weight(P, Q, R, 32, mid, h, h, 8, 0, WS, big, None), ANY_FAIL, f"gconv3x3_wgrad {mid}@{h}")
+    expect(lib.wfae_bn_stats_train(P, 32, c, hw, Q, R, 1e-5, 0.1, S, S + 4096, S + 8192, S + 12288, S + 16384, S + 20480,
+                                   WS, big, None), ANY_FAIL, f"bn_stats_train {c}@{h}")
+out = (ctypes.c_int64 * 4)()
+for variant in (0, 1):
+    for key in [(32, 256, 512, 96, 96), (32, 1024, 1024, 24, 24), (32, 128, 256, 192, 192), (1, 16, 16, 2, 2), (2, 32, 16, 6, 10)]:
+        rc = lib.wfae_wino_sizes(variant, *key, ctypes.cast(out, ctypes.c_void_p))
+        checked += 1
+        if rc == 0:
+            assert all(int(v) > 0 for v in out), (variant, key, list(out))
+expect(lib.wfae_wino_sizes(1, 32, 256, 512, 0, 96, ctypes.cast(out, ctypes.c_void_p)), ANY_FAIL, "wino_sizes Hlo=0")
+expect(lib.wfae_conv4x4s2_down(P, Q, R, 32, 256, 512, 96, 96, None), ANY_FAIL, "conv4x4s2_down")
+expect(lib.wfae_conv4x4s2_wgrad(P, Q, R, 32, 256, 512, 96, 96, 0, WS, big, None), ANY_FAIL, "conv4x4s2_wgrad")
+expect(lib.wfae_linear_fwd(P, Q, S, R, 32, 36864, 2048, WS, big, None), ANY_FAIL, "linear_fwd 36864->2048")
+expect(lib.wfae_linear_bwd_weight_splitk(P, Q, R, 2048, 512, 512, 0, WS, big, None), ANY_FAIL, "linear_bwd_weight_splitk")
+assert lib.wfae_version() == 100 and lib.wfae_workspace_bytes(1 << 24) >= (1 << 26)
+print(f"asan driver: {checked} calls, no sanitizer report")

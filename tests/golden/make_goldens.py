@@ -471,8 +471,50 @@ def g6_gan():
 
 
 # ------------------------------------------------------------------ G7 ---
+def _ssim_tm_form(pred, target, data_range=1.0):
+    """SECOND, independently written SSIM restatement in the shape torchmetrics'
+    StructuralSimilarityIndexMeasure(data_range=1.0) computes it (call site pipeline/metrics.py:71-75): reflect-pad
+    both images by (k-1)/2 = 5, filter the five stacked maps (p, t, p*p, t*t, p*t) with the 2-D 11x11 Gaussian
+    (outer product of the normalised 1-D kernel), variances clamped at 0, crop the 5-pixel border, mean per image,
+    then mean over the batch.  oracle.ssim is the separable valid-window form of pytorch_msssim: the two must agree
+    before G7 is written.  Still "parity unpinned" (neither package exists here), but no longer self-referential."""
+    k, sigma = 11, 1.5
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    dist = torch.arange((1 - k) / 2, (1 + k) / 2, 1, dtype=pred.dtype)
+    g1 = torch.exp(-((dist / sigma) ** 2) / 2)
+    g1 = (g1 / g1.sum()).unsqueeze(0)
+    ch = pred.shape[1]
+    kern = (g1.t() @ g1).expand(ch, 1, k, k)
+    pad = (k - 1) // 2
+    pp = F.pad(pred, (pad, pad, pad, pad), mode="reflect")
+    tp = F.pad(target, (pad, pad, pad, pad), mode="reflect")
+    stack = torch.cat((pp, tp, pp * pp, tp * tp, pp * tp))
+    o = F.conv2d(stack, kern, groups=ch).split(pred.shape[0])
+    mu_p2, mu_t2, mu_pt = o[0] ** 2, o[1] ** 2, o[0] * o[1]
+    var_p = torch.clamp(o[2] - mu_p2, min=0.0)
+    var_t = torch.clamp(o[3] - mu_t2, min=0.0)
+    cov = o[4] - mu_pt
+    full = ((2 * mu_pt + c1) * (2 * cov + c2)) / ((mu_p2 + mu_t2 + c1) * (var_p + var_t + c2))
+    inner = full[..., pad:-pad, pad:-pad]
+    return inner.reshape(inner.shape[0], -1).mean(-1).mean()
+
+
+def _psnr_tm_form(pred, target):
+    """second PSNR restatement, the way pipeline/metrics.py:77-84 drives torchmetrics: one PeakSignalNoiseRatio()
+    call per sample (data_range=None => max(target) - min(target) of that sample, base 10, sum of squared errors /
+    element count), python-float mean over the samples"""
+    vals = []
+    for i in range(pred.shape[0]):
+        p, t = pred[i:i + 1], target[i:i + 1]
+        sse, n = torch.sum(torch.pow(p - t, 2)), t.numel()
+        rng = t.max() - t.min()
+        vals.append(float(2 * torch.log10(rng) - torch.log10(sse / n)) * 10.0)
+    return sum(vals) / len(vals)
+
+
 def g7_metrics():
-    """SSIM/PSNR from the restatement (UNPINNED: pytorch_msssim/torchmetrics absent)."""
+    """SSIM/PSNR from the restatement (UNPINNED: pytorch_msssim/torchmetrics absent), cross-checked against a
+    second, independently written restatement of each."""
     out = {}
     for i, (b, s) in enumerate([(2, 32), (2, 64), (1, 128), (3, 48)]):
         a = T(synth.uniform(7, f"m{i}/a", (b, 1, s, s), 0, 1))
@@ -481,6 +523,11 @@ def g7_metrics():
         out[f"{i}/target"], out[f"{i}/pred"] = a.numpy(), p.numpy()
         out[f"{i}/ssim"] = np.float64(orc.ssim(p.double(), a.double()).item())
         out[f"{i}/psnr"] = np.float64(orc.psnr(p.double(), a.double()))
+        s2, p2 = float(_ssim_tm_form(p.double(), a.double())), _psnr_tm_form(p.double(), a.double())
+        assert abs(s2 - float(out[f"{i}/ssim"])) < 1e-7, ("the two SSIM restatements disagree", i, s2, out[f"{i}/ssim"])
+        assert abs(p2 - float(out[f"{i}/psnr"])) < 1e-7 * abs(p2), ("the two PSNR restatements disagree", i)
+        assert abs(float(_ssim_tm_form(p, a)) - s2) < 2e-6          # fp32 evaluation of the same form
+        out[f"{i}/ssim_form2"], out[f"{i}/psnr_form2"] = np.float64(s2), np.float64(p2)
         pp = p.clone().requires_grad_(True)
         l = 1 - orc.ssim(a, pp)
         l.backward()
@@ -597,6 +644,8 @@ def main():
         g_full("g3_full128_b4_blobs", 128, 4, 1, "blobs")
     if want("g4"):
         g_full("g4_full384_b1", 384, 1, 1, "blobs")
+    if want("g4b4"):
+        g_full("g4_full384_b4", 384, 4, 1, "blobs")       # BASELINE configs[0]: batch 4, 384x384
     if want("g5"):
         g5_tf()
     if want("g6"):

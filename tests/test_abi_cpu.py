@@ -60,3 +60,38 @@ def test_product_never_imports_the_oracle():
     for f in root.rglob("*.py"):
         src = f.read_text()
         assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_host_layer_under_address_and_ub_sanitizers():
+    """a host-only ASan + UBSan build of the C-ABI layer (csrc/build_asan.sh, no device code) is
+    driven through argument validation, workspace carving and launch-geometry arithmetic of every kernel family at the
+    model's real sizes (tests/asan_driver.py).  CPU box only: GPU sanitizers are not available on the pool."""
+    import glob
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("sanitizer builds run on the CPU box only")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "weatherforecastingtoolkit_amd", "csrc")
+    rt = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    if not rt:
+        pytest.skip("no shared ASan runtime in this image")
+    subprocess.run(["bash", os.path.join(csrc, "build_asan.sh")], check=True, capture_output=True, timeout=600)
+    env = dict(os.environ, LD_PRELOAD=rt[0], ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=99",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1:exitcode=98")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "asan_driver.py"),
+                        os.path.join(csrc, "build_asan", "libwfae_asan.so"), root],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    assert "no sanitizer report" in r.stdout
+
+
+def test_mha_entry_points_validate_alignment_and_dropout():
+    """wfae_mha_fwd reads qkv through float4 -> 16-byte alignment is part of the contract; wfae_mha_bwd
+    checks the dropout probability like the forward (keep = 1/(1-p) would be inf)"""
+    lib = _lib.load()
+    p = 0x7F0000000000
+    assert lib.wfae_mha_fwd(p + 4, p + 4096, p + 8192, 8, 64, 8, 8, 0, 0.0, 1, None) == -1
+    assert b"aligned" in lib.wfae_last_error_string()
+    assert lib.wfae_mha_bwd(p, p + 4096, p + 8192, p + 12288, 8, 64, 8, 8, 0, 1.0, 1, None) == -1
+    assert b"dropout" in lib.wfae_last_error_string()

@@ -37,16 +37,26 @@ def _worker(rank, world, port, q):
     p0 = a.flat_p.clone()
     Fn.set_wgrad_overlap(True)
     x = torch.from_numpy(synth.uniform_frames(4, 128, seed=7))[2 * rank:2 * rank + 2].to(dev)
-    recon, _ = net(x)
-    Fn.l1_loss(recon, x).backward()
+    # the rank-local reference gradient comes from a backward with the hooks held back (no exchange in flight while
+    # it is cloned); backward is bit-reproducible (test_fullsize_gpu.py), so the overlapped pass below produces the
+    # same local values
+    with dp.no_sync():
+        recon, _ = net(x)
+        Fn.l1_loss(recon, x).backward()
     Fn.join_side_stream()
     torch.cuda.synchronize()
+    assert dp.hook_launches == 0 and dp._done_from is None and not dp._pending
     g_local = a.flat_g.clone()
+    opt.zero_grad(set_to_none=True)
+    recon, _ = net(x)
+    Fn.l1_loss(recon, x).backward()
+    hooks_fired = dp.hook_launches > 0 and dp._done_from is not None and len(dp._pending) > 0
     dp.reduce_gradients()
+    torch.cuda.synchronize()
     g_sum = a.flat_g.clone()
     gl = [torch.zeros_like(g_local) for _ in range(world)]
     dist.all_gather(gl, g_local)
-    ok_sum = torch.allclose(g_sum, gl[0] + gl[1], rtol=0, atol=0)
+    ok_sum = hooks_fired and torch.equal(g_sum, gl[0] + gl[1])
     opt.step()
     torch.cuda.synchronize()
     pl = [torch.zeros_like(a.flat_p) for _ in range(world)]
@@ -75,3 +85,58 @@ def test_dp_two_ranks_one_gpu(dev):
         assert same_before, "rank-0 parameters were not broadcast"
         assert same_after, "ranks diverged after the optimiser step"
         assert scale == 0.5 and 0 < moved < 1e-4
+
+
+def _traj_worker(rank, world, port, q):
+    """two optimiser steps, once with the hook-driven overlapped exchange and once with the post-backward exchange:
+    the parameters must be bit-identical (same buckets, same sums; only the launch time differs)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    from weatherforecastingtoolkit_amd import functional as Fn, parallel, synth
+    from weatherforecastingtoolkit_amd.optim import FusedAdamW
+    from weatherforecastingtoolkit_amd.pipeline.models.ae_64x8x8_tf import PosAwareAE_TF
+    parallel.init_from_env("gloo")
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(synth.uniform_frames(4, 128, seed=11))[2 * rank:2 * rank + 2].to(dev)
+    out, unused_ok, fired = [], True, []
+    for overlap in (False, True):
+        torch.manual_seed(5)
+        net = PosAwareAE_TF().to(dev).train()          # the _tf model: tf_encoder.* never receives a gradient
+        opt = FusedAdamW(net.parameters(), lr=5e-5, weight_decay=1e-4)
+        dp = parallel.DataParallelTrainer(net, opt, bucket_mb=64, overlap=overlap)
+        Fn.set_wgrad_overlap(True)
+        torch.manual_seed(99)                          # same counter-based dropout seeds in both runs
+        Fn._seed_counter[0] = 0
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            recon, _ = net(x)
+            Fn.l1_loss(recon, x).backward()
+            unused_ok = unused_ok and dp.unused_slots_are_zero()
+            dp.reduce_gradients()
+            opt.step()
+        torch.cuda.synchronize()
+        fired.append(dp.hook_launches)
+        out.append(opt.arenas[0].flat_p.clone())
+    pl = [torch.zeros_like(out[1]) for _ in range(world)]
+    dist.all_gather(pl, out[1])
+    q.put((rank, bool(torch.equal(out[0], out[1])), bool(torch.equal(pl[0], pl[1])), bool(unused_ok), fired))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_overlap_matches_post_backward_exchange(dev):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_traj_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in ps)
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, same_traj, same_ranks, unused_ok, fired in res:
+        assert fired[0] == 0 and fired[1] > 0, fired
+        assert same_traj, "overlapped exchange changed the 2-step parameter trajectory"
+        assert same_ranks, "ranks diverged"
+        assert unused_ok, "gradient slots of never-used parameters are not all zero"

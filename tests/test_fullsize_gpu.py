@@ -43,7 +43,7 @@ def test_b32_384_replicated_batch_matches_reference_b1(dev):
         assert abs(loss.item() - float(g["loss0"])) <= 1e-5 * float(g["loss0"])
         gn = np.array([p.grad.double().norm().item() for p in net.parameters()])
         rel = np.abs(gn - g["grad_norms"]) / (g["grad_norms"] + 1e-12)
-        assert rel.max() < 2e-3, rel.max()
+        assert rel.max() < 5e-4, rel.max()        # measured <= 9e-5 (median 5e-6), DESIGN.md section 2
         assert relerr(net.dec[-1].weight.grad, g["g_dec_last_w"]) < 1e-3
         losses.append(loss.item())
     assert losses[0] == losses[1]             # side-stream weight gradients do not change the forward

@@ -61,7 +61,8 @@ def _frames(g):
     return torch.from_numpy(ev[0].transpose(2, 0, 1)[:, None].astype(np.float32) * np.float32(1 / 255))
 
 
-@pytest.mark.parametrize("gname", ["g3_full128_b2", "g3_full128_b4_blobs", "g4_full384_b1"])
+# g4_full384_b4 = BASELINE configs[0] exactly (batch 4, 384x384) from the reference module on the CPU
+@pytest.mark.parametrize("gname", ["g3_full128_b2", "g3_full128_b4_blobs", "g4_full384_b1", "g4_full384_b4"])
 def test_full_model_golden(dev, gname):
     """config 1 / 2 plumbing: full PosAwareAE_TF train steps vs the reference's numbers."""
     from weatherforecastingtoolkit_amd import functional as Fn

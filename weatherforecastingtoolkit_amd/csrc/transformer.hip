@@ -323,6 +323,9 @@ int wfae_mha_fwd(const float* qkv, float* out, float* probs, int S, int N, int H
   WFAE_REQUIRE(qkv && out && probs, WFAE_ERR_NULL_POINTER, "mha_fwd: null pointer");
   WFAE_REQUIRE(S > 0 && S <= 64 && N > 0 && H > 0, WFAE_ERR_BAD_SHAPE, "mha_fwd: sequence length must be 1..64");
   WFAE_REQUIRE(p_drop >= 0.f && p_drop < 1.f, WFAE_ERR_BAD_SHAPE, "mha_fwd: dropout probability");
+  // the kernels read K / V rows as float4: rows are 3*H*D floats long, so the base pointer decides the alignment
+  WFAE_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15) == 0 && (3 * H * D) % 4 == 0, WFAE_ERR_BAD_SHAPE,
+               "mha_fwd: qkv must be 16-byte aligned (got %p; pass a contiguous tensor, not a sliced view)", (const void*)qkv);
   hipStream_t st = (hipStream_t)stream;
   const float scale = 1.0f / sqrtf((float)D);
   const long rs = batch_first ? 1 : N, rn = batch_first ? S : 1;
@@ -342,6 +345,7 @@ int wfae_mha_bwd(const float* qkv, const float* probs, const float* dout, float*
                  int batch_first, float p_drop, uint64_t seed, wfae_stream_t stream) {
   WFAE_REQUIRE(qkv && probs && dout && dqkv, WFAE_ERR_NULL_POINTER, "mha_bwd: null pointer");
   WFAE_REQUIRE(S > 0 && S <= 64 && N > 0 && H > 0, WFAE_ERR_BAD_SHAPE, "mha_bwd: sequence length must be 1..64");
+  WFAE_REQUIRE(p_drop >= 0.f && p_drop < 1.f, WFAE_ERR_BAD_SHAPE, "mha_bwd: dropout probability");
   hipStream_t st = (hipStream_t)stream;
   const long rs = batch_first ? 1 : N, rn = batch_first ? S : 1;
   const unsigned long long sd = (unsigned long long)seed;

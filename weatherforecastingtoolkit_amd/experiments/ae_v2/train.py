@@ -35,8 +35,10 @@ from .._gan import GanLoss, frozen
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-# Keys of the reference's experiments/ae_v2/config.yaml that this build accepts (so that existing `key=value`
-# override command lines keep parsing, helpers.check_yaml) but never reads: W&B / Lightning / unused schedules.
+# Keys of the reference's experiments/ae_v2/config.yaml that are not in this build's YAML: defaults live here so that
+# existing `key=value` override command lines keep parsing (helpers.check_yaml).  Read: trainer.limit_val_batches /
+# limit_test_batches / save_every_n_steps, logging.log_train_all_metrics_n (metric cadence, :216-218); the rest
+# (W&B / Lightning device lists / unused schedules) is accepted and ignored.
 CARRIED_KEYS = {
     "project_name": "ae_test_v2",
     "lpips": {"disc_beta1": 0.5, "disc_beta2": 0.9, "disc_start_lr": 5e-7, "disc_peak_lr": 5e-6, "disc_final_lr": 5e-8,
@@ -85,11 +87,148 @@ class Loss(GanLoss):
                       f"{split}/rec_loss": rec_loss.detach(), f"{split}/g_loss": g_loss.detach(), f"{split}/d_weight": d_weight}
 
 
+class Model(tnn.Module):
+    """reference Model (experiments/ae_v2/train.py:181-261) minus Lightning: owns the autoencoder and the Loss, the
+    three step functions with the reference's logging keys and metric cadence, and the optimiser / scheduler pair
+    (`configure_optimizers`, :254-261: only `self.autoencoder.parameters()` are optimised)."""
+
+    def __init__(self, cfg, img_size=128, variant="tf"):
+        super().__init__()
+        self.cfg = cfg
+        model_mod = ae_64x8x8_tf if variant == "tf" else ae_64x8x8_lin
+        self.autoencoder = model_mod.PosAwareAE_TF(img_size=img_size)
+        lp = cfg.lpips
+        self.loss = Loss(lp.disc_start, disc_num_layers=lp.disc_num_layers, disc_in_channels=lp.disc_in_channels,
+                         disc_weight=lp.disc_weight, use_actnorm=lp.use_actnorm,
+                         perceptual_weight=lp.perceptual_weight, kl_weight=lp.kl_weight,
+                         logvar_init=lp.logvar_init, recon_weight=lp.recon_weight)
+        self.total_steps = cfg.trainer.total_train_steps
+        self.global_step = 0
+        self.current_epoch = 0
+
+    def forward(self, x):
+        return self.autoencoder(x)
+
+    def get_last_layer(self):
+        return self.autoencoder.dec[-1].weight
+
+    def configure_optimizers(self):
+        o, sp = self.cfg.optim, self.cfg.cosine_warmup
+        self.opt = helpers.adamw_optimizer(self.autoencoder, o.lr, o.weight_decay, o.beta1, o.beta2)
+        self.sched = helpers.cosine_warmup_scheduler(self.opt, sp.start_lr, sp.final_lr, sp.peak_lr, self.total_steps,
+                                                     sp.warmup_ratio * self.total_steps)
+        return self.opt, self.sched
+
+    def training_step(self, batch, batch_idx):
+        """:209-223 — returns (loss, scalar logs).  Image metrics every log_train_all_metrics_n * total_train_steps
+        batches (:216-218), under the reference's `train_*` names."""
+        inp = batch["vil"]
+        pred, z = self(inp)
+        # the reference trains only the autoencoder here: past disc_start the discriminator scores the
+        # reconstruction but is never updated — its parameters stay frozen
+        with frozen(self.loss.discriminator.parameters()):
+            aeloss, logs = self.loss(inp, pred, z, 0, self.get_last_layer(), "train", self.global_step)
+        logs = dict(logs)
+        interval = max(1, int(self.cfg.logging.log_train_all_metrics_n * self.cfg.trainer.total_train_steps))
+        if batch_idx % interval == 0:
+            logs.update(helpers.log_metrics(pred.unsqueeze(2), inp.unsqueeze(2), "train"))
+        return aeloss, logs
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx):
+        """:225-236: generator half of the loss + the image metrics on every batch"""
+        inp = batch["vil"]
+        pred, z = self(inp)
+        aeloss, logs = self.loss(inp, pred, z, 0, self.get_last_layer(), "val", self.global_step)
+        logs = dict(logs)
+        logs.update(helpers.log_metrics(pred.unsqueeze(2), inp.unsqueeze(2), "val"))
+        return aeloss, logs
+
+    @torch.no_grad()
+    def test_step(self, batch, batch_idx):
+        """:238-252: both halves of the loss + the image metrics"""
+        inp = batch["vil"]
+        pred, z = self(inp)
+        _, logs = self.loss(inp, pred, z, 0, self.get_last_layer(), "test", self.global_step)
+        logs = dict(logs)
+        _, log_d = self.loss(inp, pred, z, 1, self.get_last_layer(), "test", self.global_step)
+        logs.update(log_d)
+        logs.update(helpers.log_metrics(pred.unsqueeze(2), inp.unsqueeze(2), "test"))
+        return logs
+
+
+def _mean_logs(rows, world):
+    """epoch mean of per-step scalar logs (Lightning on_epoch=True), averaged over ranks (sync_dist=True)"""
+    if not rows:
+        return {}
+    keys = sorted({k for r in rows for k in r})
+    vals = torch.tensor([sum(float(r[k]) for r in rows if k in r) / max(1, sum(1 for r in rows if k in r)) for k in keys],
+                        dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as dist
+        t = vals.cuda()
+        dist.all_reduce(t)
+        vals = (t / world).cpu()
+    return {k: float(v) for k, v in zip(keys, vals)}
+
+
+def evaluate(model, loader, split, limit, world):
+    """one pass over `limit` (fraction, Lightning limit_*_batches) of the loader in eval mode"""
+    net_training = model.training
+    model.eval()
+    n = len(loader)
+    n = n if limit is None else max(1, int(n * limit)) if n else 0
+    rows = []
+    for i in range(n):
+        batch = loader[i]
+        rows.append(model.test_step(batch, i) if split == "test" else model.validation_step(batch, i)[1])
+    model.train(net_training)
+    out = _mean_logs(rows, world)
+    out["batches"] = n
+    return out
+
+
+def save_checkpoint(path, model, epoch):
+    """Lightning .ckpt layout (keys `state_dict` with the `autoencoder.` / `loss.` prefixes of the reference's
+    LightningModule attributes, `optimizer_states`, `lr_schedulers`, `global_step`, `epoch`)"""
+    flush_bn_counters(model)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    tmp = path + ".tmp"
+    torch.save({"state_dict": sd, "global_step": model.global_step, "epoch": epoch,
+                "optimizer_states": [model.opt.state_dict()], "lr_schedulers": [model.sched.state_dict()],
+                "rng": {"torch_seed": torch.initial_seed(), "dropout_counter": Fn._seed_counter[0]}}, tmp)
+    os.replace(tmp, path)
+
+
+def load_checkpoint(path, model):
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ck["state_dict"]
+    if not any(k.startswith("loss.") for k in sd):      # AE-only checkpoints (round-1 files, exported weights)
+        sd = dict(sd)
+        sd.update({k: v for k, v in model.state_dict().items() if k.startswith("loss.")})
+    model.load_state_dict(sd, strict=True)
+    model.global_step = int(ck.get("global_step", 0))
+    if ck.get("optimizer_states"):
+        model.opt.load_state_dict(ck["optimizer_states"][0])
+    else:   # weights-only checkpoint: moments restart from zero, the bias correction restarts with them
+        print("checkpoint holds no optimiser state: AdamW moments restart from zero", file=sys.stderr)
+    model.sched.load_state_dict(ck["lr_schedulers"][0] if ck.get("lr_schedulers") else {"last_epoch": model.global_step})
+    rng = ck.get("rng")
+    if rng:
+        torch.manual_seed(rng["torch_seed"])
+        Fn._seed_counter[0] = rng["dropout_counter"]
+    return int(ck.get("epoch", 0))
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--resume", type=bool, default=False)
     ap.add_argument("--config", default=os.path.join(HERE, "config.yaml"))
-    ap.add_argument("--max-steps", type=int, default=-1, help="stop early (smoke runs)")
+    ap.add_argument("--max-steps", type=int, default=-1, help="shorten the run (smoke runs): total_train_steps = this")
+    ap.add_argument("--stop-after", type=int, default=-1,
+                    help="stop (and checkpoint) after this many optimiser steps WITHOUT changing the schedule — an "
+                         "interrupted run that `--resume True` continues")
     ap.add_argument("--matmul-precision", default="high", choices=["highest", "high", "medium"],
                     help="reference: torch.set_float32_matmul_precision('high') (train.py main); 'medium' = bf16 "
                          "MFMA operands (BASELINE config 5)")
@@ -97,6 +236,7 @@ def main(argv=None):
     ap.add_argument("--data-format", choices=("npy", "h5"), default="npy")
     ap.add_argument("--model", choices=("tf", "lin"), default="tf",
                     help="tf = ae_64x8x8_tf (what the reference ae_v2/train.py:18 imports), lin = ae_64x8x8_lin (ae_v2_2)")
+    ap.add_argument("--test", action="store_true", help="run the test loop after training (trainer.test)")
     args, unknown = ap.parse_known_args(argv)
     cfg = C.load(args.config, CARRIED_KEYS)
     cli = C.from_dotlist(unknown)
@@ -109,77 +249,106 @@ def main(argv=None):
     ops.set_float32_matmul_precision(args.matmul_precision)
 
     size, frames = (384, 49) if cfg.dataset.name == "sevir" else (128, 25)
+    B = cfg.dataset.batch_size
+    nspe = 1 + (frames - cfg.dataset.seq_len) // cfg.dataset.stride
     if args.data_dir:
-        # real data: <data_dir>/CATALOG.csv + the event files (.npy, or .h5 when h5py is available), the
-        # reference's train split (events before 2019-06-01, pipeline/datasets/sevire/sevir.py:1089-1099)
+        # real data: <data_dir>/CATALOG.csv + the event files (.npy, or .h5 when h5py is available), split by date
+        # like the reference (train < 2019-01-01 <= val < 2019-06-01 <= test, sevire/sevir.py:1227-1243)
         import datetime
         from ...pipeline.datasets.sevire.catalog import CatalogEventStore, H5EventSource, NpyEventSource, SEVIRCatalog
-        catalog = SEVIRCatalog(os.path.join(args.data_dir, "CATALOG.csv"), end_date=datetime.datetime(2019, 6, 1),
-                               shuffle=True, shuffle_seed=1)
+        cat_path = os.path.join(args.data_dir, "CATALOG.csv")
         source = (H5EventSource if args.data_format == "h5" else NpyEventSource)(os.path.join(args.data_dir, "data"))
-        events = CatalogEventStore(catalog, source)
-        size = events.event_shape[0]
+        d_val, d_test = datetime.datetime(2019, 1, 1), datetime.datetime(2019, 6, 1)
+        def store(**kw):
+            cat = SEVIRCatalog(cat_path, **kw)
+            return CatalogEventStore(cat, source) if len(cat) else None       # an empty split: that loop is skipped
+
+        ev_train = store(end_date=d_val, shuffle=True, shuffle_seed=1)
+        ev_val, ev_test = store(start_date=d_val, end_date=d_test), store(start_date=d_test)
+        if ev_train is None:
+            raise ValueError(f"{cat_path}: no training events before {d_val:%Y-%m-%d}")
+        size = ev_train.event_shape[0]
     else:
-        n_events = max(2, (cfg.dataset.batch_size * 8 * world) // (1 + (frames - cfg.dataset.seq_len) // cfg.dataset.stride) + 1)
-        events = synth.blob_events(n_events, size, frames, seed=1234)
-    loader = SEVIRFrameLoader(events, cfg.dataset.batch_size, cfg.dataset.seq_len, cfg.dataset.stride, "NTHW",
-                              shuffle=True, device=dev, num_shard=world, rank=rank)
+        n_events = max(2, (B * 8 * world) // nspe + 1)
+        ev_train = synth.blob_events(n_events, size, frames, seed=1234)
+        ev_val = synth.blob_events(max(1, (B * 2 * world) // nspe + 1), size, frames, seed=4321)
+        ev_test = synth.blob_events(max(1, (B * 2 * world) // nspe + 1), size, frames, seed=9876)
+
+    def mk(ev, shuffle):
+        if ev is None:
+            return ()
+        return SEVIRFrameLoader(ev, B, cfg.dataset.seq_len, cfg.dataset.stride, "NTHW", shuffle=shuffle, device=dev,
+                                num_shard=world, rank=rank)
+    loader, val_loader, test_loader = mk(ev_train, True), mk(ev_val, False), mk(ev_test, False)
     accum = cfg.trainer.accumulate_grad_batches
     total_steps = max(1, int(len(loader) * cfg.trainer.max_epochs / accum))  # reference :306
     if 0 < args.max_steps < total_steps:
         total_steps = args.max_steps
-    disc_start = int(cfg.lpips.disc_start * total_steps)                      # reference :318
+    cfg.trainer.total_train_steps = total_steps
+    cfg.trainer.total_val_steps = max(1, int(len(val_loader) * cfg.trainer.max_epochs / accum))
+    cfg.trainer.total_test_steps = max(1, int(len(test_loader) * cfg.trainer.max_epochs / accum))
+    cfg.lpips.disc_start = int(cfg.lpips.disc_start * total_steps)            # reference :318
 
     torch.manual_seed(0)
-    model_mod = ae_64x8x8_tf if args.model == "tf" else ae_64x8x8_lin
-    net = model_mod.PosAwareAE_TF(img_size=size).to(dev).train()
+    model = Model(cfg, img_size=size, variant=args.model).to(dev).train()
+    net, loss_fn = model.autoencoder, model.loss
     Fn.set_wgrad_overlap(True)
-    loss_fn = Loss(disc_start, disc_num_layers=cfg.lpips.disc_num_layers, disc_in_channels=cfg.lpips.disc_in_channels,
-                   disc_weight=cfg.lpips.disc_weight, use_actnorm=cfg.lpips.use_actnorm,
-                   perceptual_weight=cfg.lpips.perceptual_weight, kl_weight=cfg.lpips.kl_weight,
-                   logvar_init=cfg.lpips.logvar_init, recon_weight=cfg.lpips.recon_weight).to(dev)
-    opt = helpers.adamw_optimizer(net, cfg.optim.lr, cfg.optim.weight_decay, cfg.optim.beta1, cfg.optim.beta2)
-    sched = helpers.cosine_warmup_scheduler(opt, cfg.cosine_warmup.start_lr, cfg.cosine_warmup.final_lr,
-                                            cfg.cosine_warmup.peak_lr, total_steps,
-                                            cfg.cosine_warmup.warmup_ratio * total_steps)
+    opt, sched = model.configure_optimizers()
     dp = parallel.DataParallelTrainer(net, opt)
 
     ckpt_dir = os.path.join(cfg.experiment_path, "outputs", cfg.experiment_name, "checkpoints")
-    step = 0
     last = os.path.join(ckpt_dir, "last.ckpt")
+    epoch = 0
     if args.resume and os.path.exists(last):
-        ck = torch.load(last, map_location="cpu")
-        sd = {k[len("autoencoder."):]: v for k, v in ck["state_dict"].items() if k.startswith("autoencoder.")}
-        net.load_state_dict(sd, strict=True)
-        step = ck.get("global_step", 0)
-        sched.load_state_dict({"last_epoch": step})
-    t0 = time.time()
-    while step < total_steps:
-        for batch in loader.prefetch(2):
-            if step >= total_steps:
+        epoch = load_checkpoint(last, model)
+        for a in opt.arenas:
+            dp.sync.broadcast_(a.flat_p, 0)
+    save_every = max(1, int(total_steps * cfg.trainer.save_every_n_steps))   # helpers.py:241
+    stop_at = total_steps if args.stop_after < 0 else min(total_steps, args.stop_after)
+    nb = len(loader)
+    t0, t_steps = time.time(), 0
+    while model.global_step < stop_at:
+        model.current_epoch = epoch = model.global_step // max(1, nb)
+        first = model.global_step % max(1, nb)                                # mid-epoch resume: skip the batches done
+        for batch_idx, batch in enumerate(loader.prefetch(2, start=first), start=first):
+            if model.global_step >= stop_at:
                 break
-            inp = batch["vil"]
             opt.zero_grad(set_to_none=True)
-            pred, z = net(inp)
-            # the reference trains only the autoencoder here (one optimiser, :254-261): past disc_start the
-            # discriminator scores the reconstruction but is never updated — its parameters stay frozen
-            with frozen(loss_fn.discriminator.parameters()):
-                loss, logs = loss_fn(inp, pred, None, 0, net.dec[-1].weight, "train", step)
-                loss.backward()
+            loss, logs = model.training_step(batch, batch_idx)
+            loss.backward()
             dp.reduce_gradients()
             opt.step()
             sched.step()
-            step += 1
+            model.global_step += 1
+            t_steps += 1
+            step = model.global_step
             if rank == 0 and step % max(1, cfg.trainer.log_every_n_steps) == 0:
                 rec = {k: float(v) for k, v in logs.items()}
-                rec.update(step=step, lr=opt.param_groups[0]["lr"], frames_per_s=step * cfg.dataset.batch_size * world / (time.time() - t0))
+                rec.update(step=step, lr=opt.param_groups[0]["lr"], frames_per_s=t_steps * B * world / (time.time() - t0))
                 print(json.dumps(rec), flush=True)
+            if step % save_every == 0 and step < stop_at:
+                dp.sync_buffers()                                             # collective: every rank
+                if rank == 0:
+                    save_checkpoint(last, model, epoch)
+        if model.global_step % max(1, nb) == 0 or model.global_step >= total_steps:
+            # Lightning runs the validation loop at the end of every training epoch
+            dp.sync_buffers()
+            vlog = evaluate(model, val_loader, "val", cfg.trainer.limit_val_batches, world)
+            if rank == 0 and vlog.get("batches"):
+                vlog.update(step=model.global_step, epoch=epoch)
+                print(json.dumps(vlog), flush=True)
+    dp.sync_buffers()                    # a collective (one broadcast per BatchNorm buffer): every rank takes part
+    if args.test:
+        tlog = evaluate(model, test_loader, "test", cfg.trainer.limit_test_batches, world)
+        if rank == 0:
+            print(json.dumps(tlog), flush=True)
     if rank == 0:
-        dp.sync_buffers()
-        flush_bn_counters(net)
-        os.makedirs(ckpt_dir, exist_ok=True)
-        sd = {"autoencoder." + k: v.detach().cpu() for k, v in net.state_dict().items()}
-        torch.save({"state_dict": sd, "global_step": step}, last)
+        save_checkpoint(last, model, epoch)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()                   # nobody leaves (and tears the communicator down) while rank 0 still saves
+        dist.destroy_process_group()
+    if rank == 0:
         print("done")
     return 0
 

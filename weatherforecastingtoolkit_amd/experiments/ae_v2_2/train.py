@@ -179,7 +179,9 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--resume", type=bool, default=False)
     ap.add_argument("--config", default=os.path.join(HERE, "config.yaml"))
-    ap.add_argument("--max-steps", type=int, default=-1, help="stop early (smoke runs)")
+    ap.add_argument("--max-steps", type=int, default=-1, help="shorten the run (smoke runs): total_train_steps = this")
+    ap.add_argument("--stop-after", type=int, default=-1,
+                    help="stop (and checkpoint) after this many steps WITHOUT changing the schedule; `--resume True` continues")
     ap.add_argument("--matmul-precision", default="high", choices=["highest", "high", "medium"],
                     help="reference: torch.set_float32_matmul_precision('high') (train.py main); 'medium' = bf16 "
                          "MFMA operands (BASELINE config 5)")
@@ -217,30 +219,50 @@ def main(argv=None):
     ckpt_dir = os.path.join(cfg.experiment_path, "outputs", cfg.experiment_name, "checkpoints")
     last = os.path.join(ckpt_dir, "last.ckpt")
     if args.resume and os.path.exists(last):
-        ck = torch.load(last, map_location="cpu")
+        # Lightning restores weights, both optimisers and both schedulers (trainer.fit(ckpt_path=...), reference :296)
+        ck = torch.load(last, map_location="cpu", weights_only=False)
         model.load_state_dict(ck["state_dict"], strict=True)
         model.global_step = ck.get("global_step", 0)
-        model.g_sch.load_state_dict({"last_epoch": model.global_step})
-        model.d_sch.load_state_dict({"last_epoch": max(0, model.global_step - cfg.lpips.disc_start)})
+        if ck.get("optimizer_states"):
+            model.g_opt.load_state_dict(ck["optimizer_states"][0])
+            model.d_opt.load_state_dict(ck["optimizer_states"][1])
+            model.g_sch.load_state_dict(ck["lr_schedulers"][0])
+            model.d_sch.load_state_dict(ck["lr_schedulers"][1])
+        else:
+            model.g_sch.load_state_dict({"last_epoch": model.global_step})
+            model.d_sch.load_state_dict({"last_epoch": max(0, model.global_step - cfg.lpips.disc_start)})
+        for dp in model._dp:
+            for a in dp.opt.arenas:
+                dp.sync.broadcast_(a.flat_p, 0)
+    stop_at = total if args.stop_after < 0 else min(total, args.stop_after)
     t0, done = time.time(), 0
-    while model.global_step < total:
-        for i, batch in enumerate(loader):
-            if model.global_step >= total:
+    while model.global_step < stop_at:
+        first = (model.global_step * accum) % max(1, len(loader))
+        for i in range(first, len(loader)):
+            if model.global_step >= stop_at:
                 break
-            _, logs = model.training_step(batch, i)
+            _, logs = model.training_step(loader[i], i)
             done += 1
             if rank == 0 and done % max(1, cfg.trainer.log_every_n_steps) == 0:
                 rec = {k: float(v) for k, v in logs.items()}
                 rec.update(step=model.global_step, lr=model.g_opt.param_groups[0]["lr"],
                            frames_per_s=done * cfg.dataset.batch_size * world / (time.time() - t0))
                 print(json.dumps(rec), flush=True)
+    for dp in model._dp:
+        dp.sync_buffers()                # collectives (one broadcast per BatchNorm buffer): every rank takes part
     if rank == 0:
-        for dp in model._dp:
-            dp.sync_buffers()
         flush_bn_counters(model)
         os.makedirs(ckpt_dir, exist_ok=True)
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        torch.save({"state_dict": sd, "global_step": model.global_step}, last)
+        torch.save({"state_dict": sd, "global_step": model.global_step,
+                    "optimizer_states": [model.g_opt.state_dict(), model.d_opt.state_dict()],
+                    "lr_schedulers": [model.g_sch.state_dict(), model.d_sch.state_dict()]}, last + ".tmp")
+        os.replace(last + ".tmp", last)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()                   # nobody tears the communicator down while rank 0 still saves
+        dist.destroy_process_group()
+    if rank == 0:
         print("done")
     return 0
 

@@ -97,6 +97,41 @@ class FusedAdamW(torch.optim.Optimizer):
     def arenas(self):
         return [a for a in self._arenas if a is not None]
 
+    # -- checkpointing ---------------------------------------------------------------------------
+    # The moments live in the arenas, outside torch's per-parameter `self.state`, so the inherited state_dict() would
+    # silently drop them.  Lightning restores optimiser + scheduler state on `--resume` (reference
+    # experiments/ae_v2/train.py:322,346 -> trainer.fit(ckpt_path=...)): a resumed run continues the continuous one.
+    def state_dict(self):
+        groups, state = [], {}
+        for gi, (g, arena) in enumerate(zip(self.param_groups, self._arenas)):
+            groups.append({k: v for k, v in g.items() if k != "params"})
+            if arena is not None:
+                state[gi] = {"layout": [int(p.numel()) for p in arena.params],
+                             "exp_avg": arena.m.detach().cpu().clone(), "exp_avg_sq": arena.v.detach().cpu().clone()}
+            else:
+                state[gi] = {"layout": None,
+                             "per_param": [({"m": self.state[p]["m"].cpu().clone(), "v": self.state[p]["v"].cpu().clone()}
+                                            if self.state.get(p) else None) for p in g["params"]]}
+        return {"state": state, "param_groups": groups, "grad_scale": self.grad_scale, "format": "wfae.FusedAdamW/1"}
+
+    def load_state_dict(self, sd):
+        if sd.get("format") != "wfae.FusedAdamW/1":
+            raise ValueError("FusedAdamW.load_state_dict: not a FusedAdamW state (format tag missing)")
+        if len(sd["param_groups"]) != len(self.param_groups):
+            raise ValueError("FusedAdamW.load_state_dict: parameter-group count differs")
+        for gi, (g, arena) in enumerate(zip(self.param_groups, self._arenas)):
+            g.update({k: (tuple(v) if k == "betas" else v) for k, v in sd["param_groups"][gi].items()})
+            st = sd["state"][gi]
+            if arena is not None:
+                if st["layout"] != [int(p.numel()) for p in arena.params]:
+                    raise ValueError("FusedAdamW.load_state_dict: parameter layout of the arena differs")
+                arena.m.copy_(st["exp_avg"].to(arena.m.device))
+                arena.v.copy_(st["exp_avg_sq"].to(arena.v.device))
+            else:
+                for p, ps in zip(g["params"], st["per_param"]):
+                    if ps is not None:
+                        self.state[p] = {"m": ps["m"].to(p.device), "v": ps["v"].to(p.device)}
+
     def _grad_chunks(self):
         """flat views covering every gradient this optimiser would consume"""
         chunks = []

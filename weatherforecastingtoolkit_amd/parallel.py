@@ -29,7 +29,8 @@ def init_from_env(backend=None):
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
     if not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # WFAE_DIST_BACKEND=gloo: several ranks sharing one card (rehearsals on a 1-GPU box; RCCL needs a device per rank)
+            backend = os.environ.get("WFAE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -80,6 +81,8 @@ class DataParallelTrainer:
         self._pending = []       # [(handle, start, end)]
         self._done_from = None   # arena offset from which gradients are already being reduced
         self._hooks = []
+        self._defer = False      # inside no_sync(): backward hooks start no exchange
+        self.hook_launches = 0   # asynchronous all-reduces started from backward hooks (tests / diagnostics)
         if overlap is None:
             # opt-in until it has been timed on a real 8-GPU xGMI node (this build only had 1-GPU boxes)
             overlap = os.environ.get("WFAE_DP_OVERLAP", "0") == "1"
@@ -106,8 +109,29 @@ class DataParallelTrainer:
 
     def _make_hook(self, start):
         def hook(module, grad_input, grad_output):
+            if self._defer:
+                return
+            if self._done_from is not None and start >= self._done_from:
+                # a second backward before reduce_gradients() would ADD un-reduced gradients to slots whose
+                # exchange is already in flight: the ranks would silently diverge
+                raise RuntimeError("DataParallelTrainer: backward ran twice before reduce_gradients(); wrap the "
+                                   "micro-batches of a gradient-accumulation step except the last in dp.no_sync()")
             self._launch_tail(start)
         return hook
+
+    def no_sync(self):
+        """context for the micro-batches of a gradient-accumulation step EXCEPT the last: their backward passes
+        only accumulate into the arena, the hook-driven exchange starts with the last micro-batch (DDP.no_sync)"""
+        dp = self
+
+        class _NoSync:
+            def __enter__(self):
+                self.prev, dp._defer = dp._defer, True
+
+            def __exit__(self, *exc):
+                dp._defer = self.prev
+
+        return _NoSync()
 
     def _launch_tail(self, start):
         """all-reduce arena[start : previously launched start) asynchronously"""
@@ -121,6 +145,7 @@ class DataParallelTrainer:
         for o in range(start, end, n):
             h = dist.all_reduce(a.flat_g[o:min(end, o + n)], op=dist.ReduceOp.SUM, group=self.sync.group, async_op=True)
             self._pending.append(h)
+            self.hook_launches += 1
         self._done_from = start
 
     def sync_buffers(self):
@@ -131,6 +156,22 @@ class DataParallelTrainer:
         for b in self.model.buffers():
             if b.dtype.is_floating_point:
                 dist.broadcast(b, src=0)
+
+    def wait_pending(self):
+        """block until the hook-started all-reduces have landed (reduce_gradients does this itself)"""
+        for h in self._pending:
+            h.wait()
+        self._pending.clear()
+
+    def unused_slots_are_zero(self):
+        """True when every arena slot of a parameter WITHOUT a gradient (the never-used `tf_encoder.*` template of
+        the _tf model) holds exact zeros — those slots ride along in the all-reduce, so they must be
+        the same on every rank (what DDP's find_unused_parameters guarantees by other means)"""
+        for a in self.opt.arenas:
+            for p, o in zip(a.params, a.offsets):
+                if p.grad is None and bool(a.flat_g[o:o + p.numel()].any()):
+                    return False
+        return True
 
     def reduce_gradients(self):
         """call after loss.backward(): exchanges whatever the backward hooks have not started yet and
@@ -148,9 +189,7 @@ class DataParallelTrainer:
             # parameters without a gradient (never-used template layers) contribute their zero-initialised
             # arena slots: the same on every rank, like DDP with find_unused_parameters
             self.sync.allreduce_(a.flat_g[:self._done_from])
-            for h in self._pending:
-                h.wait()
-            self._pending.clear()
+            self.wait_pending()
             self._done_from = None
         else:
             for a in self.opt.arenas:

@@ -94,9 +94,10 @@ class SEVIRFrameLoader:
                 raise TypeError(f"event {e}: expected uint8, got {ev.dtype}")
         return ev
 
-    def prefetch(self, depth=2):
-        """iterate with the host gather + uint8 H2D copy of the next `depth` batches running ahead on a copy stream"""
-        return _Prefetcher(self, depth)
+    def prefetch(self, depth=2, start=0):
+        """iterate (from batch `start`) with the host gather + uint8 H2D copy of the next `depth` batches running
+        ahead on a copy stream"""
+        return _Prefetcher(self, depth, start)
 
     def __getitem__(self, index):
         if index >= len(self):
@@ -117,15 +118,15 @@ class _Prefetcher:
     the consumer trains on batch i; the u8 -> fp32/255 + layout kernel runs on the consumer's stream after an event
     wait.  `depth` pinned buffers / device buffers are recycled."""
 
-    def __init__(self, loader, depth=2):
+    def __init__(self, loader, depth=2, start=0):
         if loader.device is None or loader.device.type != "cuda":
             raise RuntimeError("prefetch() needs a CUDA(HIP) device")
-        self.loader, self.depth = loader, max(1, int(depth))
+        self.loader, self.depth, self.start = loader, max(1, int(depth)), max(0, int(start))
 
     def __iter__(self):
         ld = self.loader
         n = len(ld)
-        if n == 0:
+        if n == 0 or self.start >= n:
             return
         dev = ld.device
         shape = ld.batch_u8(0).shape
@@ -141,7 +142,7 @@ class _Prefetcher:
         def producer():
             try:
                 torch.cuda.set_device(dev)
-                for i in range(n):
+                for i in range(self.start, n):
                     if stop.is_set():
                         return
                     slot = free_slots.get()

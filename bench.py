@@ -11,17 +11,27 @@ global batch 32*N).  Frames are generated on the device before the timed
 region.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      the dominant kernel family of the step, timed live with an event
-                pair on the launch stream around each of its launches (a second
-                pass of the same K steps right after the timed region, streams
-                serialised so concurrent launches do not inflate each other);
-                achieved = algorithmic FLOPs / that time.
+  roofline      the dominant kernel of the step, chosen from THIS run: every launch of
+                every entry point is timed with an event pair on its launch stream (a
+                second pass of the same K steps right after the timed region, streams
+                serialised so concurrent launches do not inflate each other; entry
+                points that launch two kernels are timed per kernel) and the label with
+                the largest total wins; achieved = algorithmic bytes (or FLOPs) / time.
+                `traffic` (HBM bytes per launch) comes from the committed PMC pass of
+                this same command (profiles/pmc_traffic.json) and carries its source
+                tag; it is reported as null + "stale" when the kernel sources have
+                changed since that pass.
   step_roofline whole-step fractions per SURVEY.md §8(d):
-                fp32_fraction = 938.8 GFLOP/frame * fps / 157.3 TFLOP/s,
+                fp32_fraction = 938.8 GFLOP/frame * fps / 157.3 TFLOP/s (direct-form FLOPs),
+                executed_flops_fraction = FLOPs the kernels actually execute (Winograd
+                F(4x4,2x2) runs 12.5/32 of the direct form on the 4x4 layers) / peak,
                 hbm_fraction  = 7.365 GB/frame * fps / 8 TB/s.
   cpu_baseline  the oracle (CPU restatement of the reference path, kind "port")
-                timed on this box's host cores on a bounded sample: one full
-                train step at 384x384, batch 4 = BASELINE configs[0] (rank 0, N=1 only).
+                timed on this box's host cores on a bounded sample: one warm-up + one
+                timed full train step at 384x384, batch 4 = BASELINE configs[0]
+                (rank 0, N=1 only).
+  dp            (N > 1) ranks seen by an all-reduce of ones and the event-timed
+                gradient exchange per step.
 """
 from __future__ import annotations
 
@@ -92,11 +102,26 @@ def cpu_baseline(img_size=384, batch=1):
     x = torch.from_numpy(synth.uniform_frames(batch, img_size, seed=99))
     opt = orc.make_optimizer([p for _, p in orc.trainable(sd)], lr=5e-5, weight_decay=1e-4)
     t0 = time.perf_counter()
+    orc.train_step(x, sd, opt)          # warm-up: oneDNN primitive creation, allocator growth
+    cold = time.perf_counter() - t0
+    t0 = time.perf_counter()
     orc.train_step(x, sd, opt)
     dt = time.perf_counter() - t0
     return {"value": batch / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle/ae_oracle.py train step (fwd+L1+bwd+AdamW), {img_size}x{img_size}, batch {batch}, "
-                      f"1 step, torch CPU fp32, {cores} threads, {dt:.1f} s"}
+                      f"torch CPU fp32, {cores} threads: 1 warm-up step ({cold:.1f} s, cold) + 1 timed step ({dt:.1f} s, warm)"}
+
+
+def kernel_source_tag():
+    """sha256 over the kernel sources: profiles/pmc_traffic.json records the tag of the build it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "weatherforecastingtoolkit_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -143,12 +168,22 @@ def main():
     B, S = args.batch, args.img_size
     x = (torch.randint(0, 256, (B, 1, S, S), generator=gen, device=dev, dtype=torch.int32).float() / 255.0).contiguous()
 
-    def step():
+    xchg = []   # (start, end) event pairs around the gradient exchange, filled during the read-out pass
+
+    def step(time_exchange=False):
         opt.zero_grad(set_to_none=True)
         recon, _ = net(x)
         loss = Fn.l1_loss(recon, x)
         loss.backward()
-        dp.reduce_gradients()
+        if time_exchange and world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            Fn.join_side_stream()
+            e0.record()
+            dp.reduce_gradients()
+            e1.record()
+            xchg.append((e0, e1))
+        else:
+            dp.reduce_gradients()
         opt.step()
         sched.step()
         return loss
@@ -176,9 +211,17 @@ def main():
         fence()
         ops.profile_start()
         for _ in range(args.steps):
-            step()
+            step(time_exchange=True)
         prof = ops.profile_stop()
         Fn.set_wgrad_overlap(not args.no_overlap)
+    ranks_seen, xchg_ms = 1, None
+    if world > 1:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        if xchg:
+            torch.cuda.synchronize()
+            xchg_ms = sum(a.elapsed_time(b) for a, b in xchg) / len(xchg)
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -205,44 +248,50 @@ def main():
                               "hbm_fraction": BYTES_PER_FRAME_384 * scale * fps / world / PEAK_HBM,
                               "binding": "fp32 MFMA/VALU (AI ~127 FLOP/B, SURVEY.md §8d)"},
         }
+        if world > 1:
+            out["dp"] = {"ranks_seen": ranks_seen, "backend": backend, "overlap": bool(dp._hooks),
+                         "grad_exchange_ms_per_step": xchg_ms,
+                         "payload_bytes": 4 * sum(a.numel for a in opt.arenas)}
         if prof:
             tot_ms = sum(v[1] for v in prof.values())
             fam = sorted(prof.items(), key=lambda kv: -kv[1][1])
+            # the dominant kernel of THIS run: the label with the largest total event-timed duration (entry points
+            # that launch two kernels are timed per kernel through ops' `phases` labels)
             name, (calls, ms, fl, by) = fam[0]
-            # the dominant KERNEL is the top row of the committed rocprofv3 --kernel-trace --stats summary of this
-            # same command (profiles/dominant_kernel.json, written by tools/make_profiles.py); some entry points
-            # launch two kernels (bn_act_bwd = reduce + dx), so the largest entry point is not always it
-            try:
-                with open(os.path.join(ROOT, "profiles", "dominant_kernel.json")) as f:
-                    dom = json.load(f)
-                if dom.get("entry_point") in prof:
-                    name = dom["entry_point"]
-                    calls, ms, fl, by = prof[name]
-            except (OSError, ValueError):
-                pass
+            exec_flops_step = sum(v[2] for v in prof.values()) / args.steps
+            out["step_roofline"]["executed_flops_fraction"] = exec_flops_step / (dt / args.steps) / PEAK_FP32
+            out["step_roofline"]["executed_gflop_per_frame"] = exec_flops_step / B / 1e9
             if fl > 0:
                 ach, peak, unit, bound = fl / (ms * 1e-3) / 1e12, PEAK_FP32 / 1e12, "TFLOP/s", "mfma"
             else:
                 ach, peak, unit, bound = by / (ms * 1e-3) / 1e9, PEAK_HBM / 1e9, "GB/s", "hbm"
-            traffic = None
-            try:  # HBM bytes per launch from the committed PMC run of this same command (profiles/)
+            traffic, tsrc = None, None
+            try:  # HBM bytes per launch from the committed PMC pass of this same command (profiles/)
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                    traffic = json.load(f).get(name, {}).get("hbm_bytes_per_launch")
-            except OSError:
+                    pj = json.load(f)
+                ent = pj.get(name, {})
+                tag = kernel_source_tag()
+                stale = pj.get("_kernel_source_tag") != tag
+                tsrc = {"file": "profiles/pmc_traffic.json", "measured_on": pj.get("_source", "?"),
+                        "kernel_source_tag": pj.get("_kernel_source_tag"), "this_build": tag, "stale": stale}
+                if not stale:
+                    traffic = ent.get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
                 pass
             out["roofline"] = {"kernel": KERNEL_OF.get(name, name), "entry_point": name, "bound": bound,
                                "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic,
-                               "launches": calls, "avg_launch_ms": ms / calls,
+                               "traffic_source": tsrc, "launches": calls, "avg_launch_ms": ms / calls,
+                               "algorithmic_per_launch": (fl if fl > 0 else by) / calls,
                                "share_of_kernel_time": ms / tot_ms}
             if name.startswith("wfae_wino_gemm"):
-                # the kernel's own work is 2*M*N*K of the nine transform-domain GEMMs (what `achieved` counts);
-                # the convolution it implements has 16/9 as many algorithmic FLOPs (SURVEY.md 8d counts 2*MAC
-                # of the direct form) — that is the rate the whole-step fp32_fraction above is built from
-                out["roofline"]["conv_algorithmic_tflops"] = ach * 16.0 / 9.0
+                # the kernel's own work is 2*M*N*K of the transform-domain GEMMs (what `achieved` counts); the
+                # convolution it implements has 32/12.5 (F(4x4,2x2)) or 32/18 (F(2x2,2x2)) as many direct-form FLOPs
+                # — that is the rate the whole-step fp32_fraction above is built from
+                out["roofline"]["note"] = "achieved counts executed (Winograd-domain) FLOPs, not direct-form FLOPs"
             out["kernel_breakdown"] = [
                 {"entry_point": k, "calls_per_step": v[0] / args.steps, "ms_per_step": v[1] / args.steps,
                  "tflops": (v[2] / (v[1] * 1e-3) / 1e12) if v[2] else None,
-                 "gbps": v[3] / (v[1] * 1e-3) / 1e9} for k, v in fam[:12]]
+                 "gbps": v[3] / (v[1] * 1e-3) / 1e9} for k, v in fam[:16]]
         if world == 1 and not args.no_cpu_baseline:
             del net, opt, dp
             torch.cuda.empty_cache()

@@ -29,8 +29,12 @@ def main():
     order = np.argsort(-rel)
     print(f"{gname}: loss {loss.item():.9f} golden {float(g['loss0']):.9f}; grad-norm rel dev max {rel.max():.3e} "
           f"median {np.median(rel):.3e}  fusion={Fn.STAT_FUSION}")
-    for i in order[:8]:
+    for i in order[:int(os.environ.get("TOP", "8"))]:
         print(f"  {names[i]:28s} {rel[i]:.3e}  norm {gn[i]:.4e}")
+    from tests._util import relerr
+    print("  elementwise: dec[-1].weight.grad", f"{relerr(net.dec[-1].weight.grad, g['g_dec_last_w']):.3e}",
+          " enc[0].down[0].weight.grad", f"{relerr(net.enc[0].down[0].weight.grad, g['g_enc0_w']):.3e}",
+          " z", f"{relerr(z, g['z']):.3e}")
 
 
 if __name__ == "__main__":

@@ -76,6 +76,24 @@ if ep is not None and ep not in out and top["Name"] in F:
     out[ep] = {"hbm_bytes_per_launch": (2 * fs + ws_) / n * 1024, "fetch_raw_KiB": fs / n, "write_KiB": ws_ / n, "launches": n,
                "source": f"profiles/{tag}_pmc_hbm_traffic_per_kernel.csv"}
     json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
+# every single-kernel label bench.py can name as dominant gets its PMC traffic, tagged with the kernel sources it was
+# measured on (bench.py reports `traffic` only while that tag matches the sources it runs)
+for key, e in (("bn_act_bwd_dx_kernel", "wfae_bn_act_bwd[dx]"), ("bn_act_bwd_reduce_kernel", "wfae_bn_act_bwd[reduce]"),
+               ("bn_act_fwd_kernel", "wfae_bn_act_fwd"), ("chan_reduce_kernel<0>", "wfae_bn_stats_train")):
+    n = fs = ws_ = 0
+    for k in F:
+        if key in k:
+            n += F[k][0]
+            fs += F[k][1]
+            ws_ += W.get(k, [0, 0])[1]
+    if n and e not in out:
+        out[e] = {"hbm_bytes_per_launch": (2 * fs + ws_) / n * 1024, "fetch_raw_KiB": fs / n, "write_KiB": ws_ / n,
+                  "launches": n, "source": f"profiles/{tag}_pmc_hbm_traffic_per_kernel.csv"}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (kernel_source_tag)
+out["_kernel_source_tag"] = bench.kernel_source_tag()
+out["_source"] = f"{tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 1"
+json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 json.dump({"kernel": top["Name"], "entry_point": ep, "calls": int(top["Calls"]), "avg_ns": float(top["AverageNs"]),
            "source": f"profiles/{tag}_bench_b32_384_kernel_stats.csv"}, open("profiles/dominant_kernel.json", "w"), indent=1)
 print(open("profiles/dominant_kernel.json").read())

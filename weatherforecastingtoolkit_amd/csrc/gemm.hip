@@ -78,6 +78,12 @@ struct GemmP {
   int swizzle;       // XCD-aware tile order (set by launch_gemm_v from WFAE_SWIZZLE, default off)
   int nt_store;      // nontemporal stores of the result tile (WFAE_GEMM_NT)
   int a_vec, b_vec, c_vec;  // 16-byte vector accesses are legal for this operand / the result
+  // issue-priority policy for the waves that share a SIMD (WFAE_GEMM_PRIO): two co-resident waves running this
+  // same loop at equal priority drift into lockstep — both multiply, then both sit in their load/store/barrier gap
+  // and the matrix pipe idles (MI355X_MICROARCH.md "Two waves per SIMD", items 2-4).  1: static s_setprio 1 for the
+  // waves in odd hardware wave slots, so one wave of a pair always wins the pipe and the other fills its gaps;
+  // 2: s_setprio 1 only around the multiply phase; 0: none
+  int prio;
   // BatchNorm statistics of the result, fused into the E_BATCHED vector epilogue (kernels with two wave columns):
   // stat_sum / stat_sq [2 * ntiles][M] receive, per output row m (= channel) and 64-column wave tile, the sum and the
   // sum of squares of the values stored by that wave; null = off
@@ -146,6 +152,12 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
+  if (p.prio == 1) {
+    // HW_REG_HW_ID (4), bits [3:0] = wave slot within the SIMD
+    if (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1) __builtin_amdgcn_s_setprio(1);
+  } else if (p.prio == 3) {
+    if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(1);
+  }
   const int mtiles = (p.M + BM - 1) / BM;
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2), so
   // give every XCD a CONTIGUOUS run of tile indices — the blocks resident on one XCD then work on the same B
@@ -918,7 +930,9 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
     const int buf = s & 1;
     if (s + 1 < nstages) load_stage(s + 1);
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch's consumers below the MFMAs
+    if (p.prio == 2) __builtin_amdgcn_s_setprio(1);
     compute(buf);
+    if (p.prio == 2) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     if (s + 1 < nstages) {
       store_a(buf ^ 1);
@@ -1214,7 +1228,9 @@ int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what,
   // nontemporal result stores: 0 never (default), 1 always, 2 only for launches that also stream a residual.
   // Measured neutral for every GEMM of the step (unlike the BatchNorm dx kernel): kept for A/B only
   static const int nts = env_int("WFAE_GEMM_NT", 0);
+  static const int prio = env_int("WFAE_GEMM_PRIO", 0);
   GemmP p = p_in;
+  p.prio = prio;
   p.swizzle = swz;
   p.nt_store = nts == 1 || (nts == 2 && p_in.res != nullptr);
   const int ntiles = cdiv(p.N, BN);

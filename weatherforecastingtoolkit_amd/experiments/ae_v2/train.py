@@ -264,7 +264,8 @@ def main(argv=None):
             return CatalogEventStore(cat, source) if len(cat) else None       # an empty split: that loop is skipped
 
         ev_train = store(end_date=d_val, shuffle=True, shuffle_seed=1)
-        ev_val, ev_test = store(start_date=d_val, end_date=d_test), store(start_date=d_test)
+        ev_val = store(start_date=d_val, end_date=d_test)
+        ev_test = store(start_date=d_test) if args.test else None     # opened only when the test loop will run
         if ev_train is None:
             raise ValueError(f"{cat_path}: no training events before {d_val:%Y-%m-%d}")
         size = ev_train.event_shape[0]
@@ -290,6 +291,7 @@ def main(argv=None):
     cfg.lpips.disc_start = int(cfg.lpips.disc_start * total_steps)            # reference :318
 
     torch.manual_seed(0)
+    Fn._seed_counter[0] = 0          # the counter-based dropout stream restarts with the run (restored on --resume)
     model = Model(cfg, img_size=size, variant=args.model).to(dev).train()
     net, loss_fn = model.autoencoder, model.loss
     Fn.set_wgrad_overlap(True)

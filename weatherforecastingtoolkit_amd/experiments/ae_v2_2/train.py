@@ -212,6 +212,7 @@ def main(argv=None):
     cfg.lpips.disc_start = int(cfg.lpips.disc_start * total)                     # reference :274
 
     torch.manual_seed(0)
+    Fn._seed_counter[0] = 0          # the counter-based dropout stream restarts with the run (restored on --resume)
     model = Model(cfg, img_size=size).to(dev).train()
     Fn.set_wgrad_overlap(True)
     model.configure_optimizers()

@@ -181,9 +181,16 @@ class DataParallelTrainer:
         if self.world == 1:
             return
         for a in self.opt.arenas:
+            # gradients that autograd SUMMED from several uses of a parameter (the discriminator on the real and the
+            # fake batch, ae_v2_2/train.py:88-89) live in fresh buffers outside the arena (functional.grad_buffer):
+            # exchange those tensor by tensor — FusedAdamW consumes them from p.grad as well.  The graph is the same
+            # on every rank, so every rank issues the same sequence of collectives.
             runs, stray = a.runs()
-            if stray:
-                raise RuntimeError("data-parallel step needs every gradient inside the flat arena")
+            for i in stray:
+                g = a.params[i].grad
+                if not g.is_contiguous():
+                    raise RuntimeError("data-parallel step: non-contiguous gradient outside the arena")
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.sync.group)
         if self._done_from is not None:
             a = self.opt.arenas[0]
             # parameters without a gradient (never-used template layers) contribute their zero-initialised

@@ -83,6 +83,20 @@ int wfae_conv1x1_fwd(const float* x, const float* w, const float* bias, const fl
 int wfae_conv1x1_fwd_stats(const float* x, const float* w, const float* bias, const float* res,
                            int64_t res_img_stride, float* y, int NB, int Cin, int Cout, int HW,
                            float* stat_part, int64_t stat_capacity, int* stat_rows, wfae_stream_t stream);
+/* BatchNorm-apply + GELU fused into the 1x1 GEMM's operand loader (SURVEY.md 2.2 K3/K7/K8 "fused prologue"):
+ * y = conv1x1(gelu(x * bn_scale[c] + bn_shift[c]), w) (+bias)(+res) and, for the backward pass,
+ * dw (+)= dy * gelu(x * bn_scale + bn_shift)^T — the activated tensor of the reference's BN -> GELU -> Conv1x1 chain
+ * (pipeline/models/ae_64x8x8_lin.py:14-15) is rebuilt between the global load and the LDS store and never exists in
+ * HBM.  bn_scale / bn_shift [Cin] are the folded vectors wfae_bn_stats_train / wfae_bn_fold_eval produce; results are
+ * bit-identical to wfae_bn_act_fwd followed by wfae_conv1x1_fwd / wfae_conv1x1_bwd_weight.  fp32 matmul precision,
+ * HW % 4 == 0, Cin % 4 == 0 and 16-byte aligned tensors only (WFAE_ERR_UNSUPPORTED otherwise: run the two-kernel form);
+ * the weight-gradient form also needs Cin >= min(128, Cout). */
+int wfae_conv1x1_fwd_bnact(const float* x, const float* bn_scale, const float* bn_shift, const float* w,
+                           const float* bias, const float* res, int64_t res_img_stride, float* y, int NB, int Cin,
+                           int Cout, int HW, wfae_stream_t stream);
+int wfae_conv1x1_bwd_weight_bnact(const float* dy, const float* x, const float* bn_scale, const float* bn_shift,
+                                  float* dw, int NB, int Cin, int Cout, int HW, int accumulate, void* ws,
+                                  size_t ws_bytes, wfae_stream_t stream);
 int wfae_conv1x1_bwd_data(const float* dy, const float* w, float* dx, int NB, int Cin, int Cout,
                           int HW, wfae_stream_t stream);
 int wfae_conv1x1_bwd_weight(const float* dy, const float* x, float* dw, int NB, int Cin, int Cout,

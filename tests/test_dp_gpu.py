@@ -140,3 +140,43 @@ def test_dp_overlap_matches_post_backward_exchange(dev):
         assert same_traj, "overlapped exchange changed the 2-step parameter trajectory"
         assert same_ranks, "ranks diverged"
         assert unused_ok, "gradient slots of never-used parameters are not all zero"
+
+
+def _rccl_worker(port, q):
+    """world_size 1 over the REAL backend: RCCL communicator creation, in-place all-reduce / broadcast on slices of the
+    flat gradient arena (the exact calls GradSync issues), async handles as the backward hooks use them"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    try:
+        from weatherforecastingtoolkit_amd import parallel
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        sync = parallel.GradSync(bucket_mb=1)
+        sync.world = 2                      # take the collective code path although the group has one rank
+        flat = torch.arange(700_001, dtype=torch.float32, device="cuda:0")
+        ref = flat.clone()
+        sync.allreduce_(flat)               # sum over one rank: identity, through ncclAllReduce on 1 MiB buckets
+        sync.broadcast_(flat, 0)
+        hs = [dist.all_reduce(flat[o:o + 1000], async_op=True) for o in (0, 4096, 699_000)]   # offsets as the hooks use
+        for h in hs:
+            h.wait()
+        ones = torch.ones(1, device="cuda:0")
+        dist.all_reduce(ones)
+        torch.cuda.synchronize()
+        q.put((bool(torch.equal(flat, ref)), int(ones.item()), dist.get_backend()))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        q.put(("error", repr(e), ""))
+
+
+def test_rccl_backend_single_rank(dev):
+    """The one-GPU box cannot hold two RCCL ranks (one device per rank); this at least drives the nccl (= RCCL) backend
+    itself — communicator, bucketed in-place all-reduce, broadcast, async handles, barrier — on one rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(60)
+    assert res[0] is True and res[1] == 1 and res[2] == "nccl", res
+    assert p.exitcode == 0

@@ -459,3 +459,45 @@ def test_gelu_grad_tracks_exact_erf_form(ops, dev):
     y = ops.gelu_fwd(u.to(dev)).double().cpu()
     ye = 0.5 * ud * (1 + torch.erf(ud / 2 ** 0.5))
     assert float(((y - ye).abs() / ye.abs().clamp(min=1.0)).max()) < 5e-7
+
+
+@pytest.mark.parametrize("nb,cin,cout,h,w", [(2, 128, 32, 24, 20), (3, 256, 64, 12, 12), (2, 1024, 256, 6, 6),
+                                              (1, 144, 36, 8, 4), (2, 64, 16, 8, 8), (4, 512, 128, 24, 24)])
+def test_conv1x1_bnact_prologue_is_bit_identical(ops, dev, nb, cin, cout, h, w):
+    """BatchNorm-apply + GELU fused into the GEMM operand loaders (wfae_conv1x1_fwd_bnact /
+    wfae_conv1x1_bwd_weight_bnact) against the materialised two-kernel form: same arithmetic, same accumulation order
+    -> identical bits (the parity bars of the model tests therefore carry over unchanged)"""
+    torch.manual_seed(3)
+    x = (torch.randn(nb, cin, h, w) * 1.5 + 0.3).to(dev)
+    wt = (torch.randn(cout, cin, 1, 1) * 0.1).to(dev)
+    res = torch.randn(nb, cout, h, w).to(dev)
+    dy = torch.randn(nb, cout, h, w).to(dev)
+    g, b = (torch.rand(cin) + 0.5).to(dev), torch.randn(cin).to(dev)
+    rm, rv = torch.zeros(cin, device=dev), torch.ones(cin, device=dev)
+    st = ops.bn_stats_train(x, g, b, rm, rv)
+    assert ops.conv1x1_bnact_supported(x, cout)
+    a = ops.bn_act_fwd(x, st, 1)
+    assert torch.equal(ops.conv1x1_fwd_bnact(x, st, wt), ops.conv1x1_fwd(a, wt))
+    assert torch.equal(ops.conv1x1_fwd_bnact(x, st, wt, None, res), ops.conv1x1_fwd(a, wt, None, res))
+    dw0, dw1 = torch.empty_like(wt), torch.empty_like(wt)
+    ops.conv1x1_bwd_weight(dy, a, dw0)
+    ops.conv1x1_bwd_weight_bnact(dy, x, st, dw1)
+    assert torch.equal(dw0, dw1)
+    ops.conv1x1_bwd_weight(dy, a, dw0, accumulate=True)
+    ops.conv1x1_bwd_weight_bnact(dy, x, st, dw1, accumulate=True)
+    assert torch.equal(dw0, dw1)
+    # and against torch on the CPU
+    ref = F.conv2d(F.gelu(F.batch_norm(x.cpu(), None, None, g.cpu(), b.cpu(), True, 0.0, 1e-5)), wt.cpu())
+    assert relerr(ops.conv1x1_fwd_bnact(x, st, wt), ref) < TOL
+
+
+def test_conv1x1_bnact_refuses_unserved_geometries(ops, dev):
+    from weatherforecastingtoolkit_amd._lib import WfaeError
+    x = torch.randn(1, 32, 6, 6, device=dev)                 # Cin 32 < min(128, Cout 64): weight-gradient form not served
+    assert not ops.conv1x1_bnact_supported(x, 64)
+    st = ops.bn_stats_train(x, torch.ones(32, device=dev), torch.zeros(32, device=dev), torch.zeros(32, device=dev),
+                            torch.ones(32, device=dev))
+    with pytest.raises(WfaeError):
+        ops.conv1x1_bwd_weight_bnact(torch.randn(1, 64, 6, 6, device=dev), x, st, torch.empty(64, 32, 1, 1, device=dev))
+    x2 = torch.randn(1, 128, 3, 3, device=dev)               # HW = 9: not a multiple of 4
+    assert not ops.conv1x1_bnact_supported(x2, 32)

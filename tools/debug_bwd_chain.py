@@ -1,0 +1,122 @@
+"""Where along the backward chain does the GPU step leave the reference?  Gradients w.r.t. the stage outputs of the
+autoencoder (dec.0 .. dec.4, the latent z, enc.3 .. enc.0) on a golden input.
+
+    python tools/debug_bwd_chain.py --make [golden]     build container: oracle in fp32 AND fp64 on the CPU, writes
+                                                        tests/golden/dbg_chain_<golden>.npz (norm + a strided sample of
+                                                        every checkpoint gradient, both precisions)
+    python tools/debug_bwd_chain.py [golden]            GPU box: the product path against those samples
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests._util import golden  # noqa: E402
+
+NS = 8192
+
+
+def sample(t):
+    f = t.detach().reshape(-1)
+    n = min(NS, f.numel())
+    idx = (torch.arange(n, dtype=torch.int64) * (f.numel() - 1)) // max(1, n - 1)
+    return f[idx].double().cpu().numpy()
+
+
+def make(gname):
+    from oracle import ae_oracle as orc
+    from weatherforecastingtoolkit_amd import synth
+    from tests.test_model_gpu import _frames
+    g = golden(gname)
+    size = int(g["img_size"])
+    x32 = _frames(g)
+    np_sd = synth.synth_state_dict(synth.ae_state_dict_spec(size), seed=0)
+    out = {}
+    torch.set_num_threads(8)
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        sd = orc.to_torch_sd(np_sd)
+        sd = {k: (v.detach().to(dt).requires_grad_(v.requires_grad) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+        x = x32.to(dt)
+        keep = {}
+
+        def mark(name, t):
+            t.retain_grad()
+            keep[name] = t
+            return t
+        h = x
+        for i in range(4):
+            h = mark(f"enc{i}", orc.enc_block(h, sd, f"enc.{i}", True))
+        h = torch.nn.functional.conv2d(h, sd["enc.4.weight"], sd["enc.4.bias"]) + sd["pos_emb"]
+        z = mark("z", torch.nn.functional.linear(h.flatten(1), sd["to_latent.weight"], sd["to_latent.bias"]))
+        pe = sd["pos_emb"]
+        h = torch.nn.functional.linear(z, sd["from_latent.weight"], sd["from_latent.bias"]).view(z.shape[0], *pe.shape[1:])
+        h = mark("dec0", torch.nn.functional.conv2d(h, sd["dec.0.weight"], sd["dec.0.bias"]))
+        F_ = torch.nn.functional
+        for k in range(1, 5):   # dec_block (oracle/ae_oracle.py) unrolled so that every unit output can be marked
+            pfx = f"dec.{k}"
+            h = F_.conv_transpose2d(h, sd[pfx + ".up.0.weight"], stride=2, padding=1)
+            h = mark(f"dec{k}.up", F_.gelu(orc._bn(h, sd, pfx + ".up.1", True)))
+            for j in range(4):
+                h = mark(f"dec{k}.res{j}" if j < 3 else f"dec{k}", orc.bottleneck(h, sd, f"{pfx}.res.{j}", True))
+        recon = torch.sigmoid(torch.nn.functional.conv2d(h, sd["dec.5.weight"], sd["dec.5.bias"], padding=1))
+        loss = (recon - x).abs().mean()
+        loss.backward()
+        for name, t in keep.items():
+            out[f"{tag}/{name}/norm"] = np.float64(t.grad.double().norm().item())
+            out[f"{tag}/{name}/sample"] = sample(t.grad)
+        print(tag, "loss", loss.item(), flush=True)
+    path = os.path.join(ROOT, "tests", "golden", f"dbg_chain_{gname}.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path)
+
+
+def check(gname):
+    from tests.test_model_gpu import _build, _frames
+    from weatherforecastingtoolkit_amd import functional as Fn
+    g = golden(gname)
+    d = np.load(os.path.join(ROOT, "tests", "golden", f"dbg_chain_{gname}.npz"))
+    dev = torch.device("cuda:0")
+    net = _build(int(g["img_size"]), dev)
+    x = _frames(g).to(dev)
+    grads = {}
+
+    def grab(name):
+        def fwd_hook(mod, inp, out):
+            out.register_hook(lambda gr: grads.__setitem__(name, gr.detach().clone()))
+        return fwd_hook
+    for i in range(4):
+        net.enc[i].register_forward_hook(grab(f"enc{i}"))
+    for k in range(5):
+        net.dec[k].register_forward_hook(grab(f"dec{k}"))
+    for k in range(1, 5):
+        for j in range(3):
+            net.dec[k].res[j].register_forward_hook(grab(f"dec{k}.res{j}"))
+        def pre(mod, inp, name=f"dec{k}.up"):
+            inp[0].register_hook(lambda gr: grads.__setitem__(name, gr.detach().clone()))
+            return None
+        net.dec[k].res[0].register_forward_pre_hook(pre)
+    recon, z = net(x)
+    z.register_hook(lambda gr: grads.__setitem__("z", gr.detach().clone()))
+    Fn.l1_loss(recon, x).backward()
+    torch.cuda.synchronize()
+    print(f"{'checkpoint':8s} {'|gpu-f64|/|f64| (sample)':>26s} {'|f32cpu-f64|/|f64|':>22s} {'norm gpu/f64 - 1':>18s} {'norm f32cpu/f64 - 1':>20s}")
+    order = []
+    for k in (4, 3, 2, 1):
+        order += [f"dec{k}", f"dec{k}.res2", f"dec{k}.res1", f"dec{k}.res0", f"dec{k}.up"]
+    for name in order + ["dec0", "z", "enc3", "enc2", "enc1", "enc0"]:
+        t = grads[name]
+        s, s64, s32 = sample(t), d[f"f64/{name}/sample"], d[f"f32/{name}/sample"]
+        e_gpu = np.linalg.norm(s - s64) / np.linalg.norm(s64)
+        e_cpu = np.linalg.norm(s32 - s64) / np.linalg.norm(s64)
+        n = t.double().norm().item()
+        print(f"{name:10s} {e_gpu:26.3e} {e_cpu:22.3e} {n / float(d[f'f64/{name}/norm']) - 1:18.3e} "
+              f"{float(d[f'f32/{name}/norm']) / float(d[f'f64/{name}/norm']) - 1:20.3e}")
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    gname = args[0] if args else "g4_full384_b4"
+    make(gname) if "--make" in sys.argv else check(gname)

@@ -90,6 +90,26 @@ def main():
                     report(f"conv1x1 {nm:5s} {cin}->{cout} @{h}{' +res' if res and nm == 'fwd' else ''}", ms, fl, by + extra)
                     acc("conv1_" + nm, ms, 4)
                 del x, w, dy, r, dw
+    if "fuse" in only:
+        # BatchNorm-apply + GELU in the GEMM loaders vs the materialised form, first BatchNorm of a Bottleneck (C -> C/4)
+        for c, h in stages:
+            mid = c // 4
+            x, w, dy = rnd(B, c, h, h), rnd(mid, c, 1, 1), rnd(B, mid, h, h)
+            g, b_, rm, rv = torch.ones(c, device=dev), torch.zeros(c, device=dev), torch.zeros(c, device=dev), torch.ones(c, device=dev)
+            st = ops.bn_stats_train(x, g, b_, rm, rv)
+            dw = torch.empty_like(w)
+            a = ops.bn_act_fwd(x, st, 1)
+            fl, by = 2 * B * h * h * c * mid, 4 * (B * h * h * (c + mid) + c * mid)
+            ms0 = timeit(lambda: ops.conv1x1_fwd(ops.bn_act_fwd(x, st, 1), w), R)
+            ms1 = timeit(lambda: ops.conv1x1_fwd_bnact(x, st, w), R)
+            report(f"bn+gelu ; conv1x1 fwd {c}->{mid} @{h}  (two kernels)", ms0, fl, by + 8 * x.numel())
+            report(f"conv1x1_fwd_bnact     {c}->{mid} @{h}  (fused)", ms1, fl, by)
+            ms2 = timeit(lambda: ops.conv1x1_bwd_weight(dy, a, dw), R)
+            ms3 = timeit(lambda: ops.conv1x1_bwd_weight_bnact(dy, x, st, dw), R)
+            report(f"conv1x1 wgrad {c}->{mid} @{h}  (saved a1)", ms2, fl, by)
+            report(f"conv1x1_bwd_weight_bnact {c}->{mid} @{h}  (recompute)", ms3, fl, by)
+            acc("fwd_two_kernels", ms0, 4); acc("fwd_fused", ms1, 4); acc("wgrad_saved", ms2, 4); acc("wgrad_recompute", ms3, 4)
+            del x, w, dy, a, dw
     if "dconv" in only:
         for c, h in stages:
             mid = c // 4

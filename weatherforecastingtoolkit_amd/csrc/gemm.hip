@@ -89,6 +89,13 @@ struct GemmP {
   // sum of squares of the values stored by that wave; null = off
   float* stat_sum;
   float* stat_sq;
+  // BatchNorm-apply + GELU prologue on the B operand (PRO kernels): B'(k,n) = gelu(B(k,n) * b_scale[c] + b_shift[c]) with
+  // c the CHANNEL index of the element — k for B_NCONTIG (1x1 forward: B = x, k = input channel), n for B_KCONTIG
+  // (1x1 weight gradient: B = x, n = input channel).  Applied between the global load and the LDS store, so the
+  // activated tensor a = gelu(bn(x)) of the reference's BN -> GELU -> Conv1x1 chain (ae_64x8x8_lin.py:14-15) is never
+  // written to HBM; the arithmetic is the one of bn_act_fwd_kernel (norm_act.hip), bit for bit.
+  const float* b_scale;
+  const float* b_shift;
   // 4x4 s2 geometry (gather kinds): lo side Hlo x Wlo, hi side 2Hlo x 2Wlo
   int Chi, Clo, Hlo, Wlo;
   // grouped 3x3 weight gradient (B_WGRAD3): blockIdx.y = group, Chi = total channels,
@@ -121,6 +128,11 @@ __device__ __forceinline__ float4 load4u(const float* ptr) {
   return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// gelu(v * s + h) on four elements: exactly bn_act_fwd_kernel<GELU>'s arithmetic (norm_act.hip)
+__device__ __forceinline__ float4 bn_gelu4(float4 v, float s, float h) {
+  return make_float4(gelu_f(fmaf(v.x, s, h)), gelu_f(fmaf(v.y, s, h)), gelu_f(fmaf(v.z, s, h)), gelu_f(fmaf(v.w, s, h)));
+}
+
 // VEC: every operand/result row is 16-byte aligned and a multiple of 4 floats long, so all
 // global traffic is dwordx4.  Loaders are BRANCH-FREE: out-of-range elements load from a clamped
 // (always valid) address and are zeroed by a select, so the compiler issues every global load of
@@ -130,9 +142,10 @@ __device__ __forceinline__ float4 load4u(const float* ptr) {
 // PREC: WFAE_PRECISION_FP32 — v_mfma_f32_32x32x2_f32; WFAE_PRECISION_BF16 — same loaders, LDS images and epilogue,
 // but the operand fragments are rounded to bf16 (v_cvt_pk_bf16_f32, RNE) after the LDS read and one
 // v_mfma_f32_32x32x16_bf16 consumes a whole 16-deep stage (fp32 accumulation).
-template <int BM, int WMW, int WNW, int AK, int BKD, int EK, bool VEC, int MF, int PREC = 0>
+template <int BM, int WMW, int WNW, int AK, int BKD, int EK, bool VEC, int MF, int PREC = 0, int PRO = 0>
 __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP || PREC == 1) ? 3 : 4))) void gemm_kernel(GemmP p) {
   static_assert(WMW * WNW == 4, "4 waves");
+  static_assert(PRO == 0 || (VEC && (BKD == B_NCONTIG || BKD == B_KCONTIG)), "prologue: vector kernels, plain B kinds");
   static_assert(MF == 32, "v_mfma_f32_32x32x2_f32 (the 16x16x4 form measured the same rate and was dropped)");
   constexpr int WROWS = BM / WMW, WCOLS = BN / WNW;  // wave tile
   constexpr int TM = WROWS / MF;
@@ -194,6 +207,8 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
   float4 ra[A_IT];
   float4 rb[B_IT];
   float rg[8];  // gather kinds
+  float pb_s[B_IT], pb_h[B_IT];  // PRO: folded BatchNorm scale / shift of the channel each staged B row belongs to
+  int pb_k = 0;                  // PRO, B_NCONTIG: channel of this thread's first row in the NEXT lean stage
 
   const int H = 2 * p.Hlo, W = 2 * p.Wlo;
   const int HWlo = p.Hlo * p.Wlo;
@@ -333,6 +348,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
       }
     }
     if constexpr (BKD == B_NCONTIG) {
+      pb_k = k_begin + (t >> 5);
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         lb_k[i] = k_begin + (t >> 5) + i * 8;
@@ -347,6 +363,10 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
         const int n = n0 + kc_row(idx);
         const int k = k_begin + kc_k(idx);
         lb_st[i] = n < p.N;
+        if constexpr (PRO) {  // the channel of a K-contiguous row never changes
+          pb_s[i] = p.b_scale[lb_st[i] ? n : 0];
+          pb_h[i] = p.b_shift[lb_st[i] ? n : 0];
+        }
         const int img = k / p.b_hw;
         lb_pk[i] = k - img * p.b_hw;
         lb_off[i] = (long)img * p.b_img + (long)(lb_st[i] ? n : 0) * p.b_ld + lb_pk[i];
@@ -458,6 +478,10 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
           rb[i] = load4u(Bp + lb_off[i]);
         else
           rb[i] = *reinterpret_cast<const float4*>(Bp + lb_off[i]);
+        if constexpr (PRO && BKD == B_NCONTIG) {  // full stages: k < K, no clamp needed
+          pb_s[i] = p.b_scale[pb_k + i * 8];
+          pb_h[i] = p.b_shift[pb_k + i * 8];
+        }
         if constexpr (BKD == B_NCONTIG || BKD == B_TAPN) {
           lb_off[i] += (long)BK * p.b_ld;
         } else {
@@ -471,6 +495,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
           }
         }
       }
+      if constexpr (PRO && BKD == B_NCONTIG) pb_k += BK;
       if constexpr (BKD == B_TAPN) {  // next tap after Chi channels: rewind the channel walk, shift by one tap
         lt_c += BK;
         if (lt_c >= p.Chi) {
@@ -601,6 +626,10 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
       for (int i = 0; i < B_IT; ++i) {
         const int k = k0 + (t >> 5) + i * 8;
         const bool ok = bn_ok && k < k_end;
+        if constexpr (PRO) {
+          pb_s[i] = p.b_scale[k < k_end ? k : 0];
+          pb_h[i] = p.b_shift[k < k_end ? k : 0];
+        }
         if constexpr (VEC) {
           rb[i] = ld4raw(Bp, bn_base + (long)k * p.b_ld, ok);
           b_okbits = (b_okbits & ~(1u << i)) | ((unsigned)ok << i);
@@ -804,7 +833,8 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         float4 v = rb[i];
-        if (!lean_regs) v = sel4(v, b_okbits, i);
+        if constexpr (PRO) v = bn_gelu4(v, pb_s[i], pb_h[i]);
+        if (!lean_regs) v = sel4(v, b_okbits, i);  // after the prologue: elements beyond K / N must stay exact zeros
         *reinterpret_cast<float4*>(&Bs[buf][(t >> 5) + i * 8][(t & 31) * 4]) = v;
       }
     } else if constexpr (BKD == B_KCONTIG || BKD == B_TAPK) {
@@ -813,6 +843,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
         const int idx = t + i * NT;
         const int nl = kc_row(idx), kq = kc_k(idx);
         float4 v = rb[i];
+        if constexpr (PRO) v = bn_gelu4(v, pb_s[i], pb_h[i]);
         if (!lean_regs) v = sel4(v, b_okbits, i);
         Bs[buf][kq + 0][nl] = v.x;
         Bs[buf][kq + 1][nl] = v.y;
@@ -1221,7 +1252,7 @@ inline int pick_bm(int M, long col_blocks) {
   return bm;
 }
 
-template <int AK, int BKD, int EK, bool VEC>
+template <int AK, int BKD, int EK, bool VEC, int PRO = 0>
 int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what, int ydim = 1) {
   static const int use256 = env_int("WFAE_BM256", 1);
   static const int swz = env_int("WFAE_SWIZZLE", 0);  // measured: no change (the GEMMs are not L2-miss bound), kept for A/B
@@ -1229,6 +1260,9 @@ int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what,
   // Measured neutral for every GEMM of the step (unlike the BatchNorm dx kernel): kept for A/B only
   static const int nts = env_int("WFAE_GEMM_NT", 0);
   static const int prio = env_int("WFAE_GEMM_PRIO", 0);
+  // A/B: extra (unused) dynamic LDS per block caps the blocks per CU, leaving registers / wave slots for the
+  // HBM-bound kernels of the other stream to run beside the GEMM (tools/overlap_probe.py)
+  static const int dyn_lds = env_int("WFAE_GEMM_DYNLDS", 0);
   GemmP p = p_in;
   p.prio = prio;
   p.swizzle = swz;
@@ -1237,19 +1271,19 @@ int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what,
   dim3 block(NT);
   bool big = false;
   if constexpr (VEC) {
-    if (wfae::matmul_precision() == WFAE_PRECISION_BF16) {
+    if (PRO == 0 && wfae::matmul_precision() == WFAE_PRECISION_BF16) {
       // bf16 operands: the MFMA time of a stage falls 16x, the kernels turn loader / HBM bound and the
       // 128-row tile (3 waves per SIMD) hides that latency best
       const int bm = pick_bm(p.M, (long)ntiles * ydim * zdim);
       if (bm == 128) {
         dim3 grid(cdiv(p.M, 128) * ntiles, ydim, zdim);
-        hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, true, 32, 1>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, true, 32, 1>), grid, block, dyn_lds, st, p);
       } else if (bm == 64) {
         dim3 grid(cdiv(p.M, 64) * ntiles, ydim, zdim);
-        hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK, true, 32, 1>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK, true, 32, 1>), grid, block, dyn_lds, st, p);
       } else {
         dim3 grid(cdiv(p.M, 32) * ntiles, ydim, zdim);
-        hipLaunchKernelGGL((gemm_kernel<32, 1, 4, AK, BKD, EK, true, 32, 1>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((gemm_kernel<32, 1, 4, AK, BKD, EK, true, 32, 1>), grid, block, dyn_lds, st, p);
       }
       return check_launch(what);
     }
@@ -1259,20 +1293,20 @@ int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what,
     if ((gather || p.big_ok || bm_force256) && use256 && p.M >= 256 && (long)cdiv(p.M, 256) * ntiles * zdim * ydim >= 1024) {
       big = true;
       dim3 grid(cdiv(p.M, 256) * ntiles, ydim, zdim);
-      hipLaunchKernelGGL((gemm_kernel<256, 2, 2, AK, BKD, EK, true, 32>), grid, block, 0, st, p);
+      hipLaunchKernelGGL((gemm_kernel<256, 2, 2, AK, BKD, EK, true, 32, 0, PRO>), grid, block, dyn_lds, st, p);
     }
   }
   const int bm = big ? 256 : pick_bm(p.M, (long)ntiles * ydim * zdim);
   if (big) {
   } else if (bm == 128) {
     dim3 grid(cdiv(p.M, 128) * ntiles, ydim, zdim);
-    hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, VEC, 32>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, VEC, 32, 0, PRO>), grid, block, dyn_lds, st, p);
   } else if (bm == 64) {
     dim3 grid(cdiv(p.M, 64) * ntiles, ydim, zdim);
-    hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK, VEC, 32>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK, VEC, 32, 0, PRO>), grid, block, dyn_lds, st, p);
   } else {
     dim3 grid(cdiv(p.M, 32) * ntiles, ydim, zdim);
-    hipLaunchKernelGGL((gemm_kernel<32, 1, 4, AK, BKD, EK, VEC, 32>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<32, 1, 4, AK, BKD, EK, VEC, 32, 0, PRO>), grid, block, dyn_lds, st, p);
   }
   return check_launch(what);
 }
@@ -1375,6 +1409,60 @@ int wfae_conv1x1_fwd_stats(const float* x, const float* w, const float* bias, co
   WFAE_REQUIRE(stat_part && stat_rows, WFAE_ERR_NULL_POINTER, "conv1x1_fwd_stats: null pointer");
   return conv1x1_fwd_impl(x, w, bias, res, res_img_stride, y, NB, Cin, Cout, HW, stat_part, stat_capacity, stat_rows,
                           stream);
+}
+
+int wfae_conv1x1_fwd_bnact(const float* x, const float* bn_scale, const float* bn_shift, const float* w,
+                           const float* bias, const float* res, int64_t res_img_stride, float* y, int NB, int Cin,
+                           int Cout, int HW, wfae_stream_t stream) {
+  WFAE_REQUIRE(x && bn_scale && bn_shift && w && y, WFAE_ERR_NULL_POINTER, "conv1x1_fwd_bnact: null pointer");
+  WFAE_REQUIRE(NB > 0 && Cin > 0 && Cout > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "conv1x1_fwd_bnact: bad shape");
+  WFAE_REQUIRE((int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "conv1x1_fwd_bnact: NB*HW too large");
+  WFAE_REQUIRE(wfae::matmul_precision() == WFAE_PRECISION_FP32, WFAE_ERR_UNSUPPORTED,
+               "conv1x1_fwd_bnact: fp32 matmul precision only (use wfae_bn_act_fwd + wfae_conv1x1_fwd)");
+  GemmP p = {};
+  p.A = w; p.B = x; p.C = y; p.bias = bias; p.res = res;
+  p.b_scale = bn_scale; p.b_shift = bn_shift;
+  p.M = Cout; p.N = NB * HW; p.K = Cin; p.k_per_split = cdiv(Cin, BK) * BK;
+  p.a_hw = Cin; p.a_img = 0; p.a_ld = Cin;
+  p.b_hw = HW; p.b_img = (long)Cin * HW; p.b_ld = HW;
+  p.c_hw = HW; p.c_img = (long)Cout * HW; p.c_ld = HW; p.res_img = res_img_stride;
+  const bool vec = (Cin % 4 == 0) && aligned16(w) && (HW % 4 == 0) && aligned16(x) && aligned16(y) &&
+                   (!res || (aligned16(res) && res_img_stride % 4 == 0));
+  WFAE_REQUIRE(vec, WFAE_ERR_UNSUPPORTED,
+               "conv1x1_fwd_bnact: needs Cin %% 4 == 0, HW %% 4 == 0 and 16-byte aligned tensors (Cin %d, HW %d)", Cin, HW);
+  p.a_vec = p.b_vec = p.c_vec = 1;
+  // one M tile of 256 rows when Cout fills it: every element of x is then loaded (and activated) exactly once
+  p.big_ok = 1;
+  return launch_gemm_v<A_KCONTIG, B_NCONTIG, E_BATCHED, true, 1>(p, 1, (hipStream_t)stream, "conv1x1_fwd_bnact");
+}
+
+int wfae_conv1x1_bwd_weight_bnact(const float* dy, const float* x, const float* bn_scale, const float* bn_shift,
+                                  float* dw, int NB, int Cin, int Cout, int HW, int accumulate, void* ws,
+                                  size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(dy && x && bn_scale && bn_shift && dw, WFAE_ERR_NULL_POINTER, "conv1x1_bwd_weight_bnact: null pointer");
+  WFAE_REQUIRE(NB > 0 && Cin > 0 && Cout > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "conv1x1_bwd_weight_bnact: bad shape");
+  WFAE_REQUIRE((int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "conv1x1_bwd_weight_bnact: NB*HW too large");
+  WFAE_REQUIRE(wfae::matmul_precision() == WFAE_PRECISION_FP32, WFAE_ERR_UNSUPPORTED,
+               "conv1x1_bwd_weight_bnact: fp32 matmul precision only");
+  const size_t slab = (size_t)Cout * Cin * sizeof(float);
+  WFAE_REQUIRE(ws && ws_bytes >= slab, WFAE_ERR_WORKSPACE, "conv1x1_bwd_weight_bnact: workspace %zu < %zu", ws_bytes, slab);
+  // dW (M = Cout, N = Cin) = dY * A^T with A = gelu(bn(x)) rebuilt in the B loader; the roles are not swapped here
+  // (the activated operand must be B), so Cin < 128 would pad the 128-wide N tile: not served
+  WFAE_REQUIRE(Cin >= 128 || Cin >= Cout, WFAE_ERR_UNSUPPORTED, "conv1x1_bwd_weight_bnact: Cin %d < min(128, Cout)", Cin);
+  GemmP p = {};
+  p.K = NB * HW;
+  p.A = dy; p.B = x; p.C = (float*)ws;
+  p.b_scale = bn_scale; p.b_shift = bn_shift;
+  p.M = Cout; p.N = Cin;
+  p.a_hw = HW; p.a_img = (long)Cout * HW; p.a_ld = HW;
+  p.b_hw = HW; p.b_img = (long)Cin * HW; p.b_ld = HW;
+  const bool vec = (HW % 4 == 0) && HW >= BK && aligned16(dy) && aligned16(x) && (Cin % 4 == 0) && aligned16(ws);
+  WFAE_REQUIRE(vec, WFAE_ERR_UNSUPPORTED, "conv1x1_bwd_weight_bnact: needs HW %% 4 == 0, HW >= 16, Cin %% 4 == 0, aligned tensors");
+  p.a_vec = p.b_vec = p.c_vec = 1;
+  const int splits = pick_splits(p.M, p.N, p.K, ws_bytes, &p.k_per_split);
+  int rc = launch_gemm_v<A_KCONTIG, B_KCONTIG, E_SLAB, true, 1>(p, splits, (hipStream_t)stream, "conv1x1_bwd_weight_bnact");
+  if (rc) return rc;
+  return splitk_finish((float*)ws, dw, nullptr, (long)Cout * Cin, Cin, splits, accumulate, (hipStream_t)stream, 0);
 }
 
 int wfae_conv1x1_bwd_data(const float* dy, const float* w, float* dx, int NB, int Cin, int Cout,

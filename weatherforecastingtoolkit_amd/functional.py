@@ -49,6 +49,16 @@ _side = {}
 # of the reference's to 2.7e-4 / 4.2e-3 (tools/debug_gradnorm.py), for 0.3-1.5 % of step time.  Parity first.
 STAT_FUSION = os.environ.get("WFAE_STAT_FUSION", "0") == "1"
 
+# BatchNorm-apply + GELU of a Bottleneck's FIRST BatchNorm (the C-channel residual stream: 70 % of the BN/GELU bytes)
+# inside the operand loaders of the two GEMMs that consume it (forward C -> C/4 convolution, its weight gradient):
+# a1 = gelu(bn1(x)) is never written, saved or re-read (ops.conv1x1_fwd_bnact).  Bit-identical results.
+# The forward GEMM gains wherever it is HBM-bound (C <= 512), the weight gradient pays for evaluating erf a second time
+# (tools/kbench.py --only fuse, B = 32: forward 21.96 -> 16.57 ms per step, weight gradients 12.50 -> 16.92 ms), so the
+# fused form is used up to WFAE_FUSE_A1_MAXC input channels.  WFAE_FUSE_A1=0 restores the materialised form (A/B).
+FUSE_A1 = os.environ.get("WFAE_FUSE_A1", "1") == "1"
+FUSE_A1_MAXC = int(os.environ.get("WFAE_FUSE_A1_MAXC", "256"))
+
+
 def set_wgrad_overlap(flag: bool):
     global _overlap
     _overlap = bool(flag)
@@ -519,8 +529,13 @@ class BottleneckFn(Function):
         training = _use_batch_stats(bn1)
         fuse = training and STAT_FUSION
         st1 = _bn_stats_rows(x_stats if fuse else None, x, bn1, training)
-        a1 = ops.bn_act_fwd(x, st1, 1)
-        t1, sr2 = ops.conv1x1_fwd_stats(a1, w1) if fuse else (ops.conv1x1_fwd(a1, w1), None)
+        fuse_a1 = FUSE_A1 and not fuse and x.shape[1] <= FUSE_A1_MAXC and ops.conv1x1_bnact_supported(x, w1.shape[0])
+        if fuse_a1:
+            a1, sr2 = None, None
+            t1 = ops.conv1x1_fwd_bnact(x, st1, w1)
+        else:
+            a1 = ops.bn_act_fwd(x, st1, 1)
+            t1, sr2 = ops.conv1x1_fwd_stats(a1, w1) if fuse else (ops.conv1x1_fwd(a1, w1), None)
         st2 = _bn_stats_rows(sr2, t1, bn2, training)
         a2 = ops.bn_act_fwd(t1, st2, 1)
         t2 = _g3_fwd(a2, wg, groups)
@@ -530,7 +545,7 @@ class BottleneckFn(Function):
             y, mod._out_stats = ops.conv1x1_fwd_stats(a3, w3, None, x)
         else:
             y, mod._out_stats = ops.conv1x1_fwd(a3, w3, None, x), None
-        ctx.save_for_backward(x, a1, t1, a2, t2, a3, g1, w1, g2, wg, g3, w3,
+        ctx.save_for_backward(x, _opt(a1), t1, a2, t2, a3, g1, w1, g2, wg, g3, w3,
                               st1.mean, st1.invstd, st1.scale, st1.shift,
                               st2.mean, st2.invstd, st2.scale, st2.shift,
                               st3.mean, st3.invstd, st3.scale, st3.shift)
@@ -560,7 +575,10 @@ class BottleneckFn(Function):
         dt1 = ops.bn_act_bwd(da2, t1, g2, st2, dg2, db2, None, 1, tr)
         del da2
         dw1 = grad_buffer(w1)
-        _wgrad(lambda: ops.conv1x1_bwd_weight(dt1, a1, dw1), dt1, a1)
+        if a1.numel() == 0:     # a1 was never materialised: the weight gradient rebuilds it from x in its loader
+            _wgrad(lambda: ops.conv1x1_bwd_weight_bnact(dt1, x, st1, dw1), dt1, x, st1.scale, st1.shift)
+        else:
+            _wgrad(lambda: ops.conv1x1_bwd_weight(dt1, a1, dw1), dt1, a1)
         da1 = ops.conv1x1_bwd_data(dt1, w1)
         del dt1
         dg1, db1 = grad_buffer(g1), grad_buffer(ctx.betas[0])

@@ -117,6 +117,38 @@ def conv1x1_fwd_stats(x, w, bias=None, res=None):
     return y, (StatRows(part, rows.value) if rows.value > 0 else None)
 
 
+def conv1x1_bnact_supported(x, cout):
+    """geometries wfae_conv1x1_fwd_bnact / wfae_conv1x1_bwd_weight_bnact serve (the library re-checks and refuses the rest)"""
+    nb, cin, h, wd = x.shape
+    return ((h * wd) % 4 == 0 and h * wd >= 16 and cin % 4 == 0 and (cin >= 128 or cin >= cout)
+            and get_float32_matmul_precision() == "highest")
+
+
+def conv1x1_fwd_bnact(x, st, w, bias=None, res=None):
+    """conv1x1_fwd(bn_act_fwd(x, st, GELU), w): the activated tensor is rebuilt in the GEMM's operand loader and never
+    written (reference chain BN -> GELU -> Conv2d 1x1, pipeline/models/ae_64x8x8_lin.py:14-15)"""
+    _chk(x, w, bias, res)
+    nb, cin, h, wd = x.shape
+    cout = w.shape[0]
+    y = torch.empty((nb, cout, h, wd), dtype=x.dtype, device=x.device)
+    _call("wfae_conv1x1_fwd_bnact", 2 * nb * h * wd * cin * cout,
+          4 * (nb * h * wd * (cin + cout) + cin * cout) + (0 if res is None else 4 * nb * h * wd * cout),
+          _p(x), _p(st.scale), _p(st.shift), _p(w), _p(bias), _p(res), cout * h * wd, _p(y), nb, cin, cout, h * wd, _stream())
+    return y
+
+
+def conv1x1_bwd_weight_bnact(dy, x, st, dw, accumulate=False):
+    """conv1x1_bwd_weight(dy, bn_act_fwd(x, st, GELU), dw) without the activated tensor in HBM"""
+    _chk(dy, x, dw)
+    nb, cout, h, wd = dy.shape
+    cin = x.shape[1]
+    ws = workspace()
+    _call("wfae_conv1x1_bwd_weight_bnact", 2 * nb * h * wd * cin * cout, 4 * (nb * h * wd * (cin + cout) + cin * cout),
+          _p(dy), _p(x), _p(st.scale), _p(st.shift), _p(dw), nb, cin, cout, h * wd, int(accumulate), ws.data_ptr(),
+          ws.numel(), _stream())
+    return dw
+
+
 def conv1x1_bwd_data(dy, w):
     _chk(dy, w)
     nb, cout, h, wd = dy.shape

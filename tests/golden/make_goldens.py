@@ -250,6 +250,14 @@ def g_full(name, img_size, batch, steps, frames="uniform"):
             out["g_dec_last_w"] = net.dec[-1].weight.grad.numpy()
             out["g_pos_emb_sample"] = net.pos_emb.grad.flatten()[:256].numpy()
             out["g_enc0_w"] = net.enc[0].down[0].weight.grad.numpy()
+            # the L1 loss has a kink at recon == x: d loss / d recon = sign(recon - x) / N.  A pixel whose |recon - x| is
+            # below an implementation's forward error (1e-4 relative is the bar) may take the other sign there, which is
+            # a rank-one O(1/N) change of the gradient that every layer spreads further (tools/debug_bwd_chain.py found
+            # exactly that at B = 4, 384x384: one pixel with |recon - x| = 1.4e-5).  The reference's sign pattern is
+            # stored so that a test can separate "same arithmetic on the same branch" from "which branch".
+            out["l1_gt_bits"] = np.packbits((recon.detach() > x).numpy().reshape(-1))
+            out["l1_lt_bits"] = np.packbits((recon.detach() < x).numpy().reshape(-1))
+            out["l1_min_abs_diff"] = np.sort((recon.detach() - x).abs().flatten().numpy())[:64]
         out[f"loss{s}"] = np.float64(loss.item())
         opt.step()
         sched.step()

@@ -112,6 +112,13 @@ def check(gname):
         e_gpu = np.linalg.norm(s - s64) / np.linalg.norm(s64)
         e_cpu = np.linalg.norm(s32 - s64) / np.linalg.norm(s64)
         n = t.double().norm().item()
+        if e_gpu > 10 * e_cpu:      # where are the bad samples?  (flat index, gpu, fp64)
+            n_el, ns = t.numel(), len(s)
+            dev_ = np.abs(s - s64)
+            worst = np.argsort(-dev_)[:6]
+            rms = float(np.sqrt(np.mean(s64 ** 2)))
+            print(f"    {name}: shape {tuple(t.shape)} rms {rms:.3e}; worst samples (flat index: gpu vs f64): " +
+                  ", ".join(f"{int(i) * (n_el - 1) // max(1, ns - 1)}: {s[i]:.4e} vs {s64[i]:.4e}" for i in worst))
         print(f"{name:10s} {e_gpu:26.3e} {e_cpu:22.3e} {n / float(d[f'f64/{name}/norm']) - 1:18.3e} "
               f"{float(d[f'f32/{name}/norm']) / float(d[f'f64/{name}/norm']) - 1:20.3e}")
 

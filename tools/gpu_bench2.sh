@@ -2,7 +2,7 @@
 # kernel+model tests -> bench (with cpu baseline) -> kernel-trace stats -> two PMC passes (FETCH_SIZE, WRITE_SIZE)
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout -k 10 600 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider -x > gpurun_out/gpu_tests.log 2>&1
+timeout -k 10 1100 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider -x > gpurun_out/gpu_tests.log 2>&1
 rc=$?; tail -n 5 gpurun_out/gpu_tests.log; echo "gpu tests rc=$rc"
 if [ $rc -ne 0 ]; then exit $rc; fi
 timeout -k 10 600 python bench.py --steps 5 --warmup 2 > gpurun_out/bench.log 2> gpurun_out/bench.err || { tail -30 gpurun_out/bench.err; exit 4; }

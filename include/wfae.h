@@ -88,7 +88,7 @@ int wfae_conv1x1_fwd_stats(const float* x, const float* w, const float* bias, co
  * dw (+)= dy * gelu(x * bn_scale + bn_shift)^T — the activated tensor of the reference's BN -> GELU -> Conv1x1 chain
  * (pipeline/models/ae_64x8x8_lin.py:14-15) is rebuilt between the global load and the LDS store and never exists in
  * HBM.  bn_scale / bn_shift [Cin] are the folded vectors wfae_bn_stats_train / wfae_bn_fold_eval produce; results are
- * bit-identical to wfae_bn_act_fwd followed by wfae_conv1x1_fwd / wfae_conv1x1_bwd_weight.  fp32 matmul precision,
+ * bit-identical to wfae_bn_act_fwd followed by wfae_conv1x1_fwd / wfae_conv1x1_bwd_weight (in either matmul precision).
  * HW % 4 == 0, Cin % 4 == 0 and 16-byte aligned tensors only (WFAE_ERR_UNSUPPORTED otherwise: run the two-kernel form);
  * the weight-gradient form also needs Cin >= min(128, Cout). */
 int wfae_conv1x1_fwd_bnact(const float* x, const float* bn_scale, const float* bn_shift, const float* w,

@@ -576,6 +576,18 @@ def g9_linear_forecast():
             lin.bias.copy_(T(synth.uniform(9, f"lf{i}/b", tuple(lin.bias.shape), -0.1, 0.1)))
         loss, pred_abs = orc.linear_forecast_loss(v, lin.weight, lin.bias, tin)
         loss.backward()
+        # second, independently written restatement (index-explicit, fp64 numpy): input feature (ti, c) -> ti*C + c and
+        # output feature j -> (to, c') = divmod(j, C), which is what the reference's permute/reshape pairs
+        # (train.py:80: `.permute(0, 3, 4, 1, 2).reshape(b, h, w, 13*c)` ... `.permute(0, 3, 1, 2).reshape(b, 12, c, h, w)`)
+        # amount to; the two must agree before the fixture is written (still "parity unpinned": no reference output exists)
+        vd, wd, bd = v.double().numpy(), lin.weight.detach().double().numpy(), lin.bias.detach().double().numpy()
+        last = vd[:, tin - 1:tin]
+        xin, tgt2 = vd[:, :tin] - last, vd[:, tin:] - last
+        w4 = wd.reshape(t - tin, c, tin, c)                      # [to, c', ti, c]
+        pred2 = np.einsum("ouic,bicyx->bouyx", w4, xin) + bd.reshape(1, t - tin, c, 1, 1)
+        loss2 = float(np.mean((pred2 - tgt2) ** 2))
+        assert abs(loss2 - loss.item()) <= 2e-6 * abs(loss2), ("forecaster restatements disagree", i, loss2, loss.item())
+        assert np.max(np.abs(pred2 + last - pred_abs.detach().double().numpy())) < 1e-5
         out[f"{i}/cfg"] = np.array([b, t, tin, c, h, w])
         out[f"{i}/loss"] = np.float64(loss.item())
         out[f"{i}/pred_abs"] = pred_abs.detach().numpy()

@@ -1271,19 +1271,19 @@ int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what,
   dim3 block(NT);
   bool big = false;
   if constexpr (VEC) {
-    if (PRO == 0 && wfae::matmul_precision() == WFAE_PRECISION_BF16) {
+    if (wfae::matmul_precision() == WFAE_PRECISION_BF16) {
       // bf16 operands: the MFMA time of a stage falls 16x, the kernels turn loader / HBM bound and the
       // 128-row tile (3 waves per SIMD) hides that latency best
       const int bm = pick_bm(p.M, (long)ntiles * ydim * zdim);
       if (bm == 128) {
         dim3 grid(cdiv(p.M, 128) * ntiles, ydim, zdim);
-        hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, true, 32, 1>), grid, block, dyn_lds, st, p);
+        hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, true, 32, 1, PRO>), grid, block, dyn_lds, st, p);
       } else if (bm == 64) {
         dim3 grid(cdiv(p.M, 64) * ntiles, ydim, zdim);
-        hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK, true, 32, 1>), grid, block, dyn_lds, st, p);
+        hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK, true, 32, 1, PRO>), grid, block, dyn_lds, st, p);
       } else {
         dim3 grid(cdiv(p.M, 32) * ntiles, ydim, zdim);
-        hipLaunchKernelGGL((gemm_kernel<32, 1, 4, AK, BKD, EK, true, 32, 1>), grid, block, dyn_lds, st, p);
+        hipLaunchKernelGGL((gemm_kernel<32, 1, 4, AK, BKD, EK, true, 32, 1, PRO>), grid, block, dyn_lds, st, p);
       }
       return check_launch(what);
     }
@@ -1417,8 +1417,6 @@ int wfae_conv1x1_fwd_bnact(const float* x, const float* bn_scale, const float* b
   WFAE_REQUIRE(x && bn_scale && bn_shift && w && y, WFAE_ERR_NULL_POINTER, "conv1x1_fwd_bnact: null pointer");
   WFAE_REQUIRE(NB > 0 && Cin > 0 && Cout > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "conv1x1_fwd_bnact: bad shape");
   WFAE_REQUIRE((int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "conv1x1_fwd_bnact: NB*HW too large");
-  WFAE_REQUIRE(wfae::matmul_precision() == WFAE_PRECISION_FP32, WFAE_ERR_UNSUPPORTED,
-               "conv1x1_fwd_bnact: fp32 matmul precision only (use wfae_bn_act_fwd + wfae_conv1x1_fwd)");
   GemmP p = {};
   p.A = w; p.B = x; p.C = y; p.bias = bias; p.res = res;
   p.b_scale = bn_scale; p.b_shift = bn_shift;
@@ -1442,8 +1440,6 @@ int wfae_conv1x1_bwd_weight_bnact(const float* dy, const float* x, const float* 
   WFAE_REQUIRE(dy && x && bn_scale && bn_shift && dw, WFAE_ERR_NULL_POINTER, "conv1x1_bwd_weight_bnact: null pointer");
   WFAE_REQUIRE(NB > 0 && Cin > 0 && Cout > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "conv1x1_bwd_weight_bnact: bad shape");
   WFAE_REQUIRE((int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "conv1x1_bwd_weight_bnact: NB*HW too large");
-  WFAE_REQUIRE(wfae::matmul_precision() == WFAE_PRECISION_FP32, WFAE_ERR_UNSUPPORTED,
-               "conv1x1_bwd_weight_bnact: fp32 matmul precision only");
   const size_t slab = (size_t)Cout * Cin * sizeof(float);
   WFAE_REQUIRE(ws && ws_bytes >= slab, WFAE_ERR_WORKSPACE, "conv1x1_bwd_weight_bnact: workspace %zu < %zu", ws_bytes, slab);
   // dW (M = Cout, N = Cin) = dY * A^T with A = gelu(bn(x)) rebuilt in the B loader; the roles are not swapped here

@@ -529,7 +529,9 @@ class BottleneckFn(Function):
         training = _use_batch_stats(bn1)
         fuse = training and STAT_FUSION
         st1 = _bn_stats_rows(x_stats if fuse else None, x, bn1, training)
-        fuse_a1 = FUSE_A1 and not fuse and x.shape[1] <= FUSE_A1_MAXC and ops.conv1x1_bnact_supported(x, w1.shape[0])
+        # 'medium' (bf16 MFMA operands): the GEMMs are HBM-bound at every width, evaluating erf in their loaders is free
+        maxc = FUSE_A1_MAXC if ops.get_float32_matmul_precision() == "highest" else 1 << 30
+        fuse_a1 = FUSE_A1 and not fuse and x.shape[1] <= maxc and ops.conv1x1_bnact_supported(x, w1.shape[0])
         if fuse_a1:
             a1, sr2 = None, None
             t1 = ops.conv1x1_fwd_bnact(x, st1, w1)

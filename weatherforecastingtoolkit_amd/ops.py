@@ -120,8 +120,7 @@ def conv1x1_fwd_stats(x, w, bias=None, res=None):
 def conv1x1_bnact_supported(x, cout):
     """geometries wfae_conv1x1_fwd_bnact / wfae_conv1x1_bwd_weight_bnact serve (the library re-checks and refuses the rest)"""
     nb, cin, h, wd = x.shape
-    return ((h * wd) % 4 == 0 and h * wd >= 16 and cin % 4 == 0 and (cin >= 128 or cin >= cout)
-            and get_float32_matmul_precision() == "highest")
+    return (h * wd) % 4 == 0 and h * wd >= 16 and cin % 4 == 0 and (cin >= 128 or cin >= cout)
 
 
 def conv1x1_fwd_bnact(x, st, w, bias=None, res=None):

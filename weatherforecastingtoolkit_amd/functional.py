@@ -52,11 +52,12 @@ STAT_FUSION = os.environ.get("WFAE_STAT_FUSION", "0") == "1"
 # BatchNorm-apply + GELU of a Bottleneck's FIRST BatchNorm (the C-channel residual stream: 70 % of the BN/GELU bytes)
 # inside the operand loaders of the two GEMMs that consume it (forward C -> C/4 convolution, its weight gradient):
 # a1 = gelu(bn1(x)) is never written, saved or re-read (ops.conv1x1_fwd_bnact).  Bit-identical results.
-# The forward GEMM gains wherever it is HBM-bound (C <= 512), the weight gradient pays for evaluating erf a second time
-# (tools/kbench.py --only fuse, B = 32: forward 21.96 -> 16.57 ms per step, weight gradients 12.50 -> 16.92 ms), so the
-# fused form is used up to WFAE_FUSE_A1_MAXC input channels.  WFAE_FUSE_A1=0 restores the materialised form (A/B).
+# Measured (B = 32, 384x384, fp32, profiles/r02_v2_*): forward GEMMs + apply passes 21.6 -> 14.8 ms per step, weight
+# gradients 12.7 -> 15.0 ms (they evaluate the GELU a second time), step 256.0 -> 249.7 ms, peak memory 106.9 -> 86.4 GiB.
+# WFAE_FUSE_A1=0 restores the materialised form, WFAE_FUSE_A1_MAXC limits the fused form to that many input channels (A/B:
+# 256 -> 250.1 ms, 512 -> 249.6 ms, all -> 249.7 ms).
 FUSE_A1 = os.environ.get("WFAE_FUSE_A1", "1") == "1"
-FUSE_A1_MAXC = int(os.environ.get("WFAE_FUSE_A1_MAXC", "256"))
+FUSE_A1_MAXC = int(os.environ.get("WFAE_FUSE_A1_MAXC", str(1 << 30)))
 
 
 def set_wgrad_overlap(flag: bool):
@@ -529,9 +530,7 @@ class BottleneckFn(Function):
         training = _use_batch_stats(bn1)
         fuse = training and STAT_FUSION
         st1 = _bn_stats_rows(x_stats if fuse else None, x, bn1, training)
-        # 'medium' (bf16 MFMA operands): the GEMMs are HBM-bound at every width, evaluating erf in their loaders is free
-        maxc = FUSE_A1_MAXC if ops.get_float32_matmul_precision() == "highest" else 1 << 30
-        fuse_a1 = FUSE_A1 and not fuse and x.shape[1] <= maxc and ops.conv1x1_bnact_supported(x, w1.shape[0])
+        fuse_a1 = FUSE_A1 and not fuse and x.shape[1] <= FUSE_A1_MAXC and ops.conv1x1_bnact_supported(x, w1.shape[0])
         if fuse_a1:
             a1, sr2 = None, None
             t1 = ops.conv1x1_fwd_bnact(x, st1, w1)

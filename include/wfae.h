@@ -89,8 +89,8 @@ int wfae_conv1x1_fwd_stats(const float* x, const float* w, const float* bias, co
  * (pipeline/models/ae_64x8x8_lin.py:14-15) is rebuilt between the global load and the LDS store and never exists in
  * HBM.  bn_scale / bn_shift [Cin] are the folded vectors wfae_bn_stats_train / wfae_bn_fold_eval produce; results are
  * bit-identical to wfae_bn_act_fwd followed by wfae_conv1x1_fwd / wfae_conv1x1_bwd_weight (in either matmul precision).
- * HW % 4 == 0, Cin % 4 == 0 and 16-byte aligned tensors only (WFAE_ERR_UNSUPPORTED otherwise: run the two-kernel form);
- * the weight-gradient form also needs Cin >= min(128, Cout). */
+ * HW % 4 == 0 (>= 16 for the weight gradient), channel counts % 4 == 0 and 16-byte aligned tensors only
+ * (WFAE_ERR_UNSUPPORTED otherwise: run the two-kernel form). */
 int wfae_conv1x1_fwd_bnact(const float* x, const float* bn_scale, const float* bn_shift, const float* w,
                            const float* bias, const float* res, int64_t res_img_stride, float* y, int NB, int Cin,
                            int Cout, int HW, wfae_stream_t stream);
@@ -361,6 +361,12 @@ int wfae_patchify(const float* img, float* rows, int B, int C, int Hp, int Wp, i
 int wfae_unpatchify(const float* rows, const float* bias, float* img, int B, int C, int Hp, int Wp, int P,
                     wfae_stream_t stream);
 int wfae_add_bcast(const float* x, const float* p, float* out, int64_t outer, int64_t inner, wfae_stream_t stream);
+/* strided row copy: dst[r][dst_off + c] = src[(r / row_div) * src_ld + src_off + c], c < cols, r < rows; dst rows are
+ * dst_ld floats long; zero_fill: the other columns of each dst row are written as 0.  The layout-only steps of
+ * AE_ViT_2048.forward (pipeline/models/ae_vit.py:135 `query_vec.expand`, :86 the value slice of a fused k/v projection,
+ * :89 one token copied to all positions) and their gradients. */
+int wfae_copy_rows(const float* src, float* dst, int64_t rows, int cols, int64_t src_ld, int src_off, int row_div,
+                   int dst_ld, int dst_off, int zero_fill, wfae_stream_t stream);
 /* sum_mid: out[a][b] = sum_m x[a][m][b] (gradient of a row broadcast over the token axis) */
 int wfae_sum_mid(const float* x, float* out, int64_t A, int M, int64_t Bn, wfae_stream_t stream);
 int wfae_sq_attn_fwd(const float* q, const float* kv, float* out, float* probs, int B, int L, int H, int D,

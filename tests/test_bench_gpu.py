@@ -1,0 +1,41 @@
+"""GPU: bench.py's output contract on a small configuration (2 frames of 128x128): one JSON line with the headline
+fields, a `roofline` object computed from this run's own event timings, the whole-step fractions and the CPU baseline."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_json_contract(dev):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--img-size", "128"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "step_roofline", "kernel_breakdown"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["unit"] == "frames/s" and d["value"] > 0 and abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    ro = d["roofline"]
+    assert ro["bound"] in ("hbm", "mfma") and ro["unit"] in ("GB/s", "TFLOP/s")
+    assert 0 < ro["frac"] <= 1.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9
+    # recomputable from the line alone: achieved = algorithmic work per launch / average launch duration
+    scale = 1e9 if ro["unit"] == "GB/s" else 1e12
+    assert abs(ro["algorithmic_per_launch"] / (ro["avg_launch_ms"] * 1e-3) / scale - ro["achieved"]) < 1e-6 * ro["achieved"]
+    # the dominant kernel is the label with the largest event-timed total of THIS run
+    top = max(d["kernel_breakdown"], key=lambda k: k["ms_per_step"])
+    assert top["entry_point"] == ro["entry_point"]
+    ts = ro["traffic_source"]
+    assert ts is None or (ts["stale"] == (ro["traffic"] is None) or ro["traffic"] is None)
+    sr = d["step_roofline"]
+    assert 0 < sr["executed_flops_fraction"] < sr["fp32_fraction"] * 1.0001 < 1.0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "warm" in cb["sample"]

@@ -469,7 +469,9 @@ def test_gelu_tracks_exact_erf_form(ops, dev):
                                               (1, 144, 36, 8, 4), (2, 64, 16, 8, 8), (4, 512, 128, 24, 24),
                                               (1, 136, 34, 8, 4),      # Cin % 16 != 0: partial last K stage of the forward
                                               (1, 128, 32, 6, 6),      # NB*HW % 16 != 0: partial last K stage of the weight gradient
-                                              (3, 132, 40, 10, 6)])
+                                              (3, 132, 40, 10, 6),
+                                              (2, 32, 128, 8, 8), (2, 64, 256, 12, 12),   # Cin < min(128, Cout): swapped roles, A-side prologue
+                                              (1, 36, 132, 6, 6)])
 def test_conv1x1_bnact_prologue_is_bit_identical(ops, dev, nb, cin, cout, h, w):
     """BatchNorm-apply + GELU fused into the GEMM operand loaders (wfae_conv1x1_fwd_bnact /
     wfae_conv1x1_bwd_weight_bnact) against the materialised two-kernel form: same arithmetic, same accumulation order
@@ -509,11 +511,11 @@ def test_conv1x1_bnact_prologue_is_bit_identical(ops, dev, nb, cin, cout, h, w):
 
 def test_conv1x1_bnact_refuses_unserved_geometries(ops, dev):
     from weatherforecastingtoolkit_amd._lib import WfaeError
-    x = torch.randn(1, 32, 6, 6, device=dev)                 # Cin 32 < min(128, Cout 64): weight-gradient form not served
-    assert not ops.conv1x1_bnact_supported(x, 64)
-    st = ops.bn_stats_train(x, torch.ones(32, device=dev), torch.zeros(32, device=dev), torch.zeros(32, device=dev),
-                            torch.ones(32, device=dev))
-    with pytest.raises(WfaeError):
-        ops.conv1x1_bwd_weight_bnact(torch.randn(1, 64, 6, 6, device=dev), x, st, torch.empty(64, 32, 1, 1, device=dev))
     x2 = torch.randn(1, 128, 3, 3, device=dev)               # HW = 9: not a multiple of 4
     assert not ops.conv1x1_bnact_supported(x2, 32)
+    st = ops.bn_stats_train(x2, torch.ones(128, device=dev), torch.zeros(128, device=dev), torch.zeros(128, device=dev),
+                            torch.ones(128, device=dev))
+    with pytest.raises(WfaeError):
+        ops.conv1x1_fwd_bnact(x2, st, torch.randn(32, 128, 1, 1, device=dev))
+    with pytest.raises(WfaeError):
+        ops.conv1x1_bwd_weight_bnact(torch.randn(1, 32, 3, 3, device=dev), x2, st, torch.empty(32, 128, 1, 1, device=dev))

@@ -522,16 +522,44 @@ __global__ __launch_bounds__(256) void gconv3_kernel(const float* __restrict__ x
 #pragma unroll
       for (int o = 0; o < CPG; ++o) acc[a][b][o] = 0.f;
 
+  // row-wise staging when the tile columns are whole 128-byte lines (W % 32 == 0: every layer of the model): 8 lanes
+  // fetch the 32 interior floats of a patch row as float4, the first / last of them also the halo element — the
+  // element-wise form below spent more instructions on index arithmetic (two integer divisions per element) than the
+  // 72 / 144 FMAs per channel the element feeds
+  const bool rowwise = (W & 31) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   for (int ci0 = 0; ci0 < CPG; ci0 += CIB) {
     __syncthreads();
-    for (int idx = t; idx < CIB * IH * IWU; idx += 256) {
-      const int c = idx / (IH * IWU);
-      const int r = idx - c * (IH * IWU);
-      const int ry = r / IWU, rx = r - ry * IWU;
-      const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
-      float v = 0.f;
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = xg[((long)(ci0 + c) * H + iy) * W + ix];
-      xs[c][ry][rx] = v;
+    if (rowwise) {
+      const int j = t & 7;                       // float4 index within the row
+      for (int rr = t >> 3; rr < CIB * IH; rr += 32) {
+        const int c = rr / IH, ry = rr - c * IH;
+        const int iy = oy0 - 1 + ry;
+        const bool rok = iy >= 0 && iy < H;
+        const float* __restrict__ row = xg + ((long)(ci0 + c) * H + (rok ? iy : 0)) * W + ox0;
+        float4 v = *reinterpret_cast<const float4*>(row + 4 * j);
+        if (!rok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float* d = &xs[c][ry][1 + 4 * j];
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        if (j == 0) {
+          const bool ok = rok && ox0 > 0;
+          const float h = row[ok ? -1 : 0];
+          xs[c][ry][0] = ok ? h : 0.f;
+        } else if (j == 7) {
+          const bool ok = rok && ox0 + TW < W;
+          const float h = row[ok ? TW : 0];
+          xs[c][ry][IWU - 1] = ok ? h : 0.f;
+        }
+      }
+    } else {
+      for (int idx = t; idx < CIB * IH * IWU; idx += 256) {
+        const int c = idx / (IH * IWU);
+        const int r = idx - c * (IH * IWU);
+        const int ry = r / IWU, rx = r - ry * IWU;
+        const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
+        float v = 0.f;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = xg[((long)(ci0 + c) * H + iy) * W + ix];
+        xs[c][ry][rx] = v;
+      }
     }
     __syncthreads();
 #pragma unroll 1  // measured: 2 and 4 are slower at 4 / 8 channels per group (SGPR pressure of the weight loads)

@@ -145,7 +145,9 @@ __device__ __forceinline__ float4 bn_gelu4(float4 v, float s, float h) {
 template <int BM, int WMW, int WNW, int AK, int BKD, int EK, bool VEC, int MF, int PREC = 0, int PRO = 0>
 __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP || PREC == 1) ? 3 : 4))) void gemm_kernel(GemmP p) {
   static_assert(WMW * WNW == 4, "4 waves");
+  // PRO 1: prologue on the B operand; PRO 2: on a K-contiguous A operand (the weight gradient with swapped roles)
   static_assert(PRO == 0 || (VEC && (BKD == B_NCONTIG || BKD == B_KCONTIG)), "prologue: vector kernels, plain B kinds");
+  static_assert(PRO != 2 || AK == A_KCONTIG, "A-side prologue: K-contiguous A");
   static_assert(MF == 32, "v_mfma_f32_32x32x2_f32 (the 16x16x4 form measured the same rate and was dropped)");
   constexpr int WROWS = BM / WMW, WCOLS = BN / WNW;  // wave tile
   constexpr int TM = WROWS / MF;
@@ -207,6 +209,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
   float4 ra[A_IT];
   float4 rb[B_IT];
   float rg[8];  // gather kinds
+  float pa_s[A_IT], pa_h[A_IT];  // PRO 2: the same for the rows (channels) of a K-contiguous A operand
   float pb_s[B_IT], pb_h[B_IT];  // PRO: folded BatchNorm scale / shift of the channel each staged B row belongs to
   int pb_k = 0;                  // PRO, B_NCONTIG: channel of this thread's first row in the NEXT lean stage
 
@@ -334,6 +337,10 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
         const int m = m0 + kc_row(idx);
         const int k = k_begin + kc_k(idx);
         la_st[i] = inb && m < p.M;
+        if constexpr (PRO == 2) {
+          pa_s[i] = p.b_scale[la_st[i] ? m : 0];
+          pa_h[i] = p.b_shift[la_st[i] ? m : 0];
+        }
         const int img = k / p.a_hw;
         la_pk[i] = k - img * p.a_hw;
         la_off[i] = (long)img * p.a_img + (long)(la_st[i] ? m : 0) * p.a_ld + la_pk[i];
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
         const int n = n0 + kc_row(idx);
         const int k = k_begin + kc_k(idx);
         lb_st[i] = n < p.N;
-        if constexpr (PRO) {  // the channel of a K-contiguous row never changes
+        if constexpr (PRO == 1) {  // the channel of a K-contiguous row never changes
           pb_s[i] = p.b_scale[lb_st[i] ? n : 0];
           pb_h[i] = p.b_shift[lb_st[i] ? n : 0];
         }
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
           rb[i] = load4u(Bp + lb_off[i]);
         else
           rb[i] = *reinterpret_cast<const float4*>(Bp + lb_off[i]);
-        if constexpr (PRO && BKD == B_NCONTIG) {  // full stages: k < K, no clamp needed
+        if constexpr (PRO == 1 && BKD == B_NCONTIG) {  // full stages: k < K, no clamp needed
           pb_s[i] = p.b_scale[pb_k + i * 8];
           pb_h[i] = p.b_shift[pb_k + i * 8];
         }
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
           }
         }
       }
-      if constexpr (PRO && BKD == B_NCONTIG) pb_k += BK;
+      if constexpr (PRO == 1 && BKD == B_NCONTIG) pb_k += BK;
       if constexpr (BKD == B_TAPN) {  // next tap after Chi channels: rewind the channel walk, shift by one tap
         lt_c += BK;
         if (lt_c >= p.Chi) {
@@ -605,6 +612,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
       const int idx = t + i * NT;
       if (A_IT * NT == A_CNT || idx < A_CNT) {
         float4 v = ra[i];
+        if constexpr (PRO == 2) v = bn_gelu4(v, pa_s[i], pa_h[i]);
         if (!lean_regs) v = sel4(v, a_okbits, i);  // wave-uniform branch: full stages carry no predicate
         if constexpr (AK == A_KCONTIG) {
           const int ml = kc_row(idx), kq = kc_k(idx);
@@ -626,7 +634,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
       for (int i = 0; i < B_IT; ++i) {
         const int k = k0 + (t >> 5) + i * 8;
         const bool ok = bn_ok && k < k_end;
-        if constexpr (PRO) {
+        if constexpr (PRO == 1) {
           pb_s[i] = p.b_scale[k < k_end ? k : 0];
           pb_h[i] = p.b_shift[k < k_end ? k : 0];
         }
@@ -833,7 +841,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         float4 v = rb[i];
-        if constexpr (PRO) v = bn_gelu4(v, pb_s[i], pb_h[i]);
+        if constexpr (PRO == 1) v = bn_gelu4(v, pb_s[i], pb_h[i]);
         if (!lean_regs) v = sel4(v, b_okbits, i);  // after the prologue: elements beyond K / N must stay exact zeros
         *reinterpret_cast<float4*>(&Bs[buf][(t >> 5) + i * 8][(t & 31) * 4]) = v;
       }
@@ -843,7 +851,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
         const int idx = t + i * NT;
         const int nl = kc_row(idx), kq = kc_k(idx);
         float4 v = rb[i];
-        if constexpr (PRO) v = bn_gelu4(v, pb_s[i], pb_h[i]);
+        if constexpr (PRO == 1) v = bn_gelu4(v, pb_s[i], pb_h[i]);
         if (!lean_regs) v = sel4(v, b_okbits, i);
         Bs[buf][kq + 0][nl] = v.x;
         Bs[buf][kq + 1][nl] = v.y;
@@ -1442,23 +1450,28 @@ int wfae_conv1x1_bwd_weight_bnact(const float* dy, const float* x, const float* 
   WFAE_REQUIRE((int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "conv1x1_bwd_weight_bnact: NB*HW too large");
   const size_t slab = (size_t)Cout * Cin * sizeof(float);
   WFAE_REQUIRE(ws && ws_bytes >= slab, WFAE_ERR_WORKSPACE, "conv1x1_bwd_weight_bnact: workspace %zu < %zu", ws_bytes, slab);
-  // dW (M = Cout, N = Cin) = dY * A^T with A = gelu(bn(x)) rebuilt in the B loader; the roles are not swapped here
-  // (the activated operand must be B), so Cin < 128 would pad the 128-wide N tile: not served
-  WFAE_REQUIRE(Cin >= 128 || Cin >= Cout, WFAE_ERR_UNSUPPORTED, "conv1x1_bwd_weight_bnact: Cin %d < min(128, Cout)", Cin);
+  // dW (M = Cout, N = Cin) = dY * A^T with A = gelu(bn(x)) rebuilt in the loader of whichever operand x is: B normally,
+  // A when the roles are swapped (Cin is the small side: dW^T = A dY^T, as in wfae_conv1x1_bwd_weight)
+  const bool swap = Cin < Cout && Cin < 128;
+  const float* a = swap ? x : dy;
+  const float* b = swap ? dy : x;
+  const int Ma = swap ? Cin : Cout, Nb = swap ? Cout : Cin;
   GemmP p = {};
   p.K = NB * HW;
-  p.A = dy; p.B = x; p.C = (float*)ws;
+  p.A = a; p.B = b; p.C = (float*)ws;
   p.b_scale = bn_scale; p.b_shift = bn_shift;
-  p.M = Cout; p.N = Cin;
-  p.a_hw = HW; p.a_img = (long)Cout * HW; p.a_ld = HW;
-  p.b_hw = HW; p.b_img = (long)Cin * HW; p.b_ld = HW;
-  const bool vec = (HW % 4 == 0) && HW >= BK && aligned16(dy) && aligned16(x) && (Cin % 4 == 0) && aligned16(ws);
-  WFAE_REQUIRE(vec, WFAE_ERR_UNSUPPORTED, "conv1x1_bwd_weight_bnact: needs HW %% 4 == 0, HW >= 16, Cin %% 4 == 0, aligned tensors");
+  p.M = Ma; p.N = Nb;
+  p.a_hw = HW; p.a_img = (long)Ma * HW; p.a_ld = HW;
+  p.b_hw = HW; p.b_img = (long)Nb * HW; p.b_ld = HW;
+  const bool vec = (HW % 4 == 0) && HW >= BK && aligned16(dy) && aligned16(x) && (Nb % 4 == 0) && aligned16(ws);
+  WFAE_REQUIRE(vec, WFAE_ERR_UNSUPPORTED, "conv1x1_bwd_weight_bnact: needs HW %% 4 == 0, HW >= 16, channel counts %% 4 == 0, aligned tensors");
   p.a_vec = p.b_vec = p.c_vec = 1;
   const int splits = pick_splits(p.M, p.N, p.K, ws_bytes, &p.k_per_split);
-  int rc = launch_gemm_v<A_KCONTIG, B_KCONTIG, E_SLAB, true, 1>(p, splits, (hipStream_t)stream, "conv1x1_bwd_weight_bnact");
+  int rc = swap ? launch_gemm_v<A_KCONTIG, B_KCONTIG, E_SLAB, true, 2>(p, splits, (hipStream_t)stream, "conv1x1_bwd_weight_bnact")
+                : launch_gemm_v<A_KCONTIG, B_KCONTIG, E_SLAB, true, 1>(p, splits, (hipStream_t)stream, "conv1x1_bwd_weight_bnact");
   if (rc) return rc;
-  return splitk_finish((float*)ws, dw, nullptr, (long)Cout * Cin, Cin, splits, accumulate, (hipStream_t)stream, 0);
+  return splitk_finish((float*)ws, dw, nullptr, (long)Cout * Cin, Nb, splits, accumulate, (hipStream_t)stream,
+                       swap ? Ma : 0);
 }
 
 int wfae_conv1x1_bwd_data(const float* dy, const float* w, float* dx, int NB, int Cin, int Cout,

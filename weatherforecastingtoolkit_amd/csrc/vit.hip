@@ -32,6 +32,26 @@ __global__ __launch_bounds__(256) void patch_kernel(const float* __restrict__ sr
 }
 
 // out[o][i] = x[o][i] + p[i]
+// dst[r][dst_off + c] = src[(r / row_div) * src_ld + src_off + c]  (c < cols); with zero_fill the other columns of each
+// dst row are zeroed.  One strided row copy serves the layout-only steps of AE_ViT_2048 (pipeline/models/ae_vit.py):
+// a (1,F) parameter expanded to B rows (src_ld = 0), a column slice and its zero-padded gradient, a row repeated l times.
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows,
+                                                        int cols, long src_ld, int src_off, int row_div, int dst_ld,
+                                                        int dst_off, int zero_fill, long total) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  const int width = zero_fill ? dst_ld : cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long r = i / width;
+    const int c = (int)(i - r * width);
+    if (zero_fill) {
+      const int cs = c - dst_off;
+      dst[r * dst_ld + c] = (cs >= 0 && cs < cols) ? src[(r / row_div) * src_ld + src_off + cs] : 0.f;
+    } else {
+      dst[r * dst_ld + dst_off + c] = src[(r / row_div) * src_ld + src_off + c];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void add_bcast_kernel(const float* __restrict__ x, const float* __restrict__ p,
                                                         float* __restrict__ out, long inner, long total) {
   const long stride = (long)gridDim.x * blockDim.x;
@@ -150,6 +170,17 @@ int wfae_unpatchify(const float* rows, const float* bias, float* img, int B, int
   const long total = (long)B * C * Hp * P * Wp * P;
   hipLaunchKernelGGL(patch_kernel, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, rows, img, bias, C, Hp, Wp, P, 1, total);
   return check_launch("unpatchify");
+}
+
+int wfae_copy_rows(const float* src, float* dst, int64_t rows, int cols, int64_t src_ld, int src_off, int row_div,
+                   int dst_ld, int dst_off, int zero_fill, wfae_stream_t stream) {
+  WFAE_REQUIRE(src && dst, WFAE_ERR_NULL_POINTER, "copy_rows: null pointer");
+  WFAE_REQUIRE(rows > 0 && cols > 0 && row_div > 0 && src_ld >= 0 && src_off >= 0 && dst_off >= 0 && dst_off + cols <= dst_ld,
+               WFAE_ERR_BAD_SHAPE, "copy_rows: bad shape");
+  const long total = (long)rows * (zero_fill ? dst_ld : cols);
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, src, dst, (long)rows, cols,
+                     (long)src_ld, src_off, row_div, dst_ld, dst_off, zero_fill, total);
+  return check_launch("copy_rows");
 }
 
 int wfae_add_bcast(const float* x, const float* p, float* out, int64_t outer, int64_t inner, wfae_stream_t stream) {

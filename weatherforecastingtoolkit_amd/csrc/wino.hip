@@ -87,13 +87,23 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
       const int Y = Y0 + 2 * i + p;
       const bool rok = Y >= 0 && Y < H;
       const float* __restrict__ row = src + (long)(rok ? Y : 0) * W;
+      // the patch row is hi[X0 .. X0 + 2M + 1] with X0 = 2M tx - 1: one halo element, 2M elements that start on a
+      // 16-byte boundary (W % 4 == 0, the tiles cover the row exactly), one halo element -> 2 + M/2 loads instead of
+      // 2M + 2 (the kernel was bound by load instructions: lanes are 8 M bytes apart, every dword load of a wave
+      // touches 16 cache lines)
+      const float v0 = row[X0 >= 0 ? X0 : 0];
+      rowbuf[i][0] = (rok && X0 >= 0) ? v0 : 0.f;
 #pragma unroll
-      for (int c = 0; c < PSZ; ++c) {
-        const int X = X0 + c;
-        const bool ok = rok && X >= 0 && X < W;
-        const float v = row[ok ? X : 0];
-        rowbuf[i][c] = ok ? v : 0.f;
+      for (int c4 = 0; c4 < 2 * M; c4 += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(row + X0 + 1 + c4);
+        rowbuf[i][1 + c4] = rok ? v.x : 0.f;
+        rowbuf[i][2 + c4] = rok ? v.y : 0.f;
+        rowbuf[i][3 + c4] = rok ? v.z : 0.f;
+        rowbuf[i][4 + c4] = rok ? v.w : 0.f;
       }
+      const int XL = X0 + PSZ - 1;
+      const float vl = row[XL < W ? XL : 0];
+      rowbuf[i][PSZ - 1] = (rok && XL < W) ? vl : 0.f;
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {

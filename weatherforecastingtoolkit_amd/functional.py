@@ -58,6 +58,13 @@ STAT_FUSION = os.environ.get("WFAE_STAT_FUSION", "0") == "1"
 # 256 -> 250.1 ms, 512 -> 249.6 ms, all -> 249.7 ms).
 FUSE_A1 = os.environ.get("WFAE_FUSE_A1", "1") == "1"
 FUSE_A1_MAXC = int(os.environ.get("WFAE_FUSE_A1_MAXC", str(1 << 30)))
+# The same for the THIRD BatchNorm of a Bottleneck (C/4 channels -> the C/4 -> C convolution and its weight gradient; the
+# roles of that weight gradient are swapped when C/4 < 128, so the prologue sits on its A operand there).  The forward
+# GEMM re-loads (and re-activates) every element once per M tile, 1 - 8 times: measured for the whole step, fusing it
+# at every width costs 3 ms (247.4 -> 250.5 ms), at C <= 256 0.5 ms, at C <= 128 nothing — so it is limited to
+# WFAE_FUSE_A3_MAXC = 128 output channels (one M tile; -1.1 GiB).  WFAE_FUSE_A3=0: off.
+FUSE_A3 = os.environ.get("WFAE_FUSE_A3", "1") == "1"
+FUSE_A3_MAXC = int(os.environ.get("WFAE_FUSE_A3_MAXC", "128"))
 
 
 def set_wgrad_overlap(flag: bool):
@@ -541,12 +548,16 @@ class BottleneckFn(Function):
         a2 = ops.bn_act_fwd(t1, st2, 1)
         t2 = _g3_fwd(a2, wg, groups)
         st3 = _bn_stats(t2, bn3, training)
-        a3 = ops.bn_act_fwd(t2, st3, 1)
-        if fuse and getattr(mod, "emit_stats", False):
-            y, mod._out_stats = ops.conv1x1_fwd_stats(a3, w3, None, x)
+        if FUSE_A3 and not fuse and w3.shape[0] <= FUSE_A3_MAXC and ops.conv1x1_bnact_supported(t2, w3.shape[0]):
+            a3 = None
+            y, mod._out_stats = ops.conv1x1_fwd_bnact(t2, st3, w3, None, x), None
         else:
-            y, mod._out_stats = ops.conv1x1_fwd(a3, w3, None, x), None
-        ctx.save_for_backward(x, _opt(a1), t1, a2, t2, a3, g1, w1, g2, wg, g3, w3,
+            a3 = ops.bn_act_fwd(t2, st3, 1)
+            if fuse and getattr(mod, "emit_stats", False):
+                y, mod._out_stats = ops.conv1x1_fwd_stats(a3, w3, None, x)
+            else:
+                y, mod._out_stats = ops.conv1x1_fwd(a3, w3, None, x), None
+        ctx.save_for_backward(x, _opt(a1), t1, a2, t2, _opt(a3), g1, w1, g2, wg, g3, w3,
                               st1.mean, st1.invstd, st1.scale, st1.shift,
                               st2.mean, st2.invstd, st2.scale, st2.shift,
                               st3.mean, st3.invstd, st3.scale, st3.shift)
@@ -563,7 +574,10 @@ class BottleneckFn(Function):
         dy = _c(dy)
         mid = w1.shape[0]
         dw3 = grad_buffer(w3)
-        _wgrad(lambda: ops.conv1x1_bwd_weight(dy, a3, dw3), dy, a3)
+        if a3.numel() == 0:     # a3 = gelu(bn3(t2)) was never materialised: rebuilt in the weight gradient's loader
+            _wgrad(lambda: ops.conv1x1_bwd_weight_bnact(dy, t2, st3, dw3), dy, t2, st3.scale, st3.shift)
+        else:
+            _wgrad(lambda: ops.conv1x1_bwd_weight(dy, a3, dw3), dy, a3)
         da3 = ops.conv1x1_bwd_data(dy, w3)
         dg3, db3 = grad_buffer(g3), grad_buffer(ctx.betas[2])
         dt2 = ops.bn_act_bwd(da3, t2, g3, st3, dg3, db3, None, 1, tr)
@@ -840,12 +854,12 @@ class AddBcastFn(Function):
 
 
 class ExpandRowsFn(Function):
-    """(1, F) parameter -> (B, F) rows (query_vec.expand, dec_queries.expand in AE_ViT_2048.forward)"""
+    """(1, F) parameter -> (B, F) rows (query_vec.expand, dec_queries.expand in AE_ViT_2048.forward): wfae_copy_rows"""
 
     @staticmethod
     def forward(ctx, p, b):
         ctx.p = p
-        return p.reshape(1, -1).expand(b, -1).contiguous()   # a copy, no arithmetic
+        return ops.copy_rows(_c(p.detach()).view(-1), b, p.numel(), 0)   # every row = the parameter (src_ld = 0)
 
     @staticmethod
     def backward(ctx, dy):
@@ -860,15 +874,14 @@ class SliceColsFn(Function):
 
     @staticmethod
     def forward(ctx, x, a, b):
+        x = _c(x)
         ctx.cfg = (x.shape, a, b)
-        return x[:, a:b].contiguous()
+        return ops.copy_rows(x, x.shape[0], b - a, x.shape[1], src_off=a)
 
     @staticmethod
     def backward(ctx, dy):
         shape, a, b = ctx.cfg
-        dx = torch.zeros(shape, dtype=dy.dtype, device=dy.device)
-        dx[:, a:b].copy_(dy)
-        return dx, None, None
+        return ops.copy_rows(_c(dy), shape[0], b - a, b - a, dst_ld=shape[1], dst_off=a, zero_fill=True), None, None
 
 
 class RepeatRowsFn(Function):
@@ -877,8 +890,9 @@ class RepeatRowsFn(Function):
     @staticmethod
     def forward(ctx, x, l):
         ctx.l = l
+        x = _c(x)
         b, f = x.shape
-        return x.unsqueeze(1).expand(b, l, f).contiguous().view(b * l, f)
+        return ops.copy_rows(x, b * l, f, f, row_div=l)
 
     @staticmethod
     def backward(ctx, dy):

@@ -120,7 +120,8 @@ def conv1x1_fwd_stats(x, w, bias=None, res=None):
 def conv1x1_bnact_supported(x, cout):
     """geometries wfae_conv1x1_fwd_bnact / wfae_conv1x1_bwd_weight_bnact serve (the library re-checks and refuses the rest)"""
     nb, cin, h, wd = x.shape
-    return (h * wd) % 4 == 0 and h * wd >= 16 and cin % 4 == 0 and (cin >= 128 or cin >= cout)
+    swapped = cin < cout and cin < 128          # the weight gradient then computes dW^T (N = Cout columns)
+    return (h * wd) % 4 == 0 and h * wd >= 16 and cin % 4 == 0 and (cout % 4 == 0 or not swapped)
 
 
 def conv1x1_fwd_bnact(x, st, w, bias=None, res=None):
@@ -794,6 +795,16 @@ def add_bcast(x, p):
     inner = p.numel()
     _call("wfae_add_bcast", 0, 8 * x.numel(), _p(x), _p(p), _p(out), x.numel() // inner, inner, _stream())
     return out
+
+
+def copy_rows(src, rows, cols, src_ld, src_off=0, row_div=1, dst_ld=None, dst_off=0, zero_fill=False):
+    """dst (rows, dst_ld): dst[r][dst_off + c] = src[(r // row_div) * src_ld + src_off + c] (see wfae_copy_rows)"""
+    _chk(src)
+    dst_ld = cols if dst_ld is None else dst_ld
+    dst = torch.empty((rows, dst_ld), dtype=torch.float32, device=src.device)
+    _call("wfae_copy_rows", 0, 4 * rows * (cols + dst_ld), _p(src), _p(dst), rows, cols, src_ld, src_off, row_div, dst_ld,
+          dst_off, int(zero_fill), _stream())
+    return dst
 
 
 def sum_mid(x, a, m, bn):

@@ -522,44 +522,32 @@ __global__ __launch_bounds__(256) void gconv3_kernel(const float* __restrict__ x
 #pragma unroll
       for (int o = 0; o < CPG; ++o) acc[a][b][o] = 0.f;
 
-  // row-wise staging when the tile columns are whole 128-byte lines (W % 32 == 0: every layer of the model): 8 lanes
-  // fetch the 32 interior floats of a patch row as float4, the first / last of them also the halo element — the
-  // element-wise form below spent more instructions on index arithmetic (two integer divisions per element) than the
-  // 72 / 144 FMAs per channel the element feeds
-  const bool rowwise = (W & 31) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  // Staging: every load of the patch is issued before the first LDS store (branch-free: out-of-range elements read a
+  // clamped address and are zeroed afterwards).  The loop form "load, store, next element" made each of the ~10 (20)
+  // elements a thread stages a separate round trip to memory, and with 36 (72) rounds of resident blocks per launch those
+  // round trips, not bandwidth or FMA rate, set the time of the 4 / 8 channels-per-group layers.  (A row-wise float4
+  // variant of the staging measured no faster at 8 channels per group and 10 % slower at 4.)
+  constexpr int NEL = CIB * IH * IWU;
+  constexpr int NIT = (NEL + 255) / 256;
   for (int ci0 = 0; ci0 < CPG; ci0 += CIB) {
+    float sv[NIT];
+    int so[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int idx = t + i * 256;
+      const int c = idx / (IH * IWU);
+      const int r = idx - c * (IH * IWU);
+      const int ry = r / IWU, rx = r - ry * IWU;
+      const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
+      const bool ok = idx < NEL && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      sv[i] = xg[ok ? ((long)(ci0 + c) * H + iy) * W + ix : 0];
+      so[i] = idx < NEL ? (ok ? (c * IH + ry) * IW + rx : -1 - ((c * IH + ry) * IW + rx)) : (1 << 30);
+    }
     __syncthreads();
-    if (rowwise) {
-      const int j = t & 7;                       // float4 index within the row
-      for (int rr = t >> 3; rr < CIB * IH; rr += 32) {
-        const int c = rr / IH, ry = rr - c * IH;
-        const int iy = oy0 - 1 + ry;
-        const bool rok = iy >= 0 && iy < H;
-        const float* __restrict__ row = xg + ((long)(ci0 + c) * H + (rok ? iy : 0)) * W + ox0;
-        float4 v = *reinterpret_cast<const float4*>(row + 4 * j);
-        if (!rok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        float* d = &xs[c][ry][1 + 4 * j];
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        if (j == 0) {
-          const bool ok = rok && ox0 > 0;
-          const float h = row[ok ? -1 : 0];
-          xs[c][ry][0] = ok ? h : 0.f;
-        } else if (j == 7) {
-          const bool ok = rok && ox0 + TW < W;
-          const float h = row[ok ? TW : 0];
-          xs[c][ry][IWU - 1] = ok ? h : 0.f;
-        }
-      }
-    } else {
-      for (int idx = t; idx < CIB * IH * IWU; idx += 256) {
-        const int c = idx / (IH * IWU);
-        const int r = idx - c * (IH * IWU);
-        const int ry = r / IWU, rx = r - ry * IWU;
-        const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
-        float v = 0.f;
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = xg[((long)(ci0 + c) * H + iy) * W + ix];
-        xs[c][ry][rx] = v;
-      }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      float* xf = &xs[0][0][0];
+      if (so[i] != (1 << 30)) xf[so[i] >= 0 ? so[i] : -1 - so[i]] = so[i] >= 0 ? sv[i] : 0.f;
     }
     __syncthreads();
 #pragma unroll 1  // measured: 2 and 4 are slower at 4 / 8 channels per group (SGPR pressure of the weight loads)

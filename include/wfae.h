@@ -191,6 +191,16 @@ int wfae_bn_fold_eval(const float* gamma, const float* beta, const float* runnin
                       float* scale, float* shift, int C, wfae_stream_t stream);
 int wfae_bn_act_fwd(const float* x, const float* scale, const float* shift, float* y, int NB, int C,
                     int HW, int act, wfae_stream_t stream);
+/* wfae_bn_act_fwd that also reduces the BatchNorm sums of ITS OUTPUT y (the first Bottleneck after a Down/Up unit
+ * normalises y again): same fp64 partial layout as wfae_wino_out_stats, needs part_capacity >= 2 * C * NB * ceil(HW / 4096)
+ * doubles.  wfae_bn_stats_from_parts = the second half of wfae_bn_stats_train (mean / invstd / folded scale, shift,
+ * running-statistics update) on such partial sums; the sums are accumulated in fp64 like the separate pass, so the
+ * statistics agree with it to fp64 rounding. */
+int wfae_bn_act_fwd_stats(const float* x, const float* scale, const float* shift, float* y, int NB, int C, int HW, int act,
+                          double* part, int64_t part_capacity, int* splits_out, wfae_stream_t stream);
+int wfae_bn_stats_from_parts(const double* part, int splits, int NB, int C, int HW, const float* gamma, const float* beta,
+                             float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
+                             float* save_invstd, float* scale, float* shift, wfae_stream_t stream);
 int wfae_bn_act_bwd(const float* dy, const float* x, const float* gamma, const float* scale,
                     const float* shift, const float* save_mean, const float* save_invstd,
                     const float* res, float* dx, float* dgamma, float* dbeta, int NB, int C, int HW,
@@ -229,6 +239,11 @@ int wfae_wino_weights(int variant, const float* w, float* U, int Chi, int Clo, w
 int wfae_wino_in(int variant, const float* hi, float* V, int NB, int Chi, int Hlo, int Wlo, wfae_stream_t stream);
 int wfae_wino_in_t(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, wfae_stream_t stream);
 int wfae_wino_out(int variant, const float* M, float* lo, int NB, int Clo, int Hlo, int Wlo, wfae_stream_t stream);
+/* wfae_wino_out that also reduces the BatchNorm sums of its result (the BatchNorm of EncBlock.down / DecBlock.up follows
+ * the convolution directly, reference ae_64x8x8_lin.py:31-32,42-43): fp64 partial sums part[(split * Clo + c) * 2 +
+ * {0 = sum, 1 = sum of squares}], *splits_out rows; finish them with wfae_bn_stats_from_parts. */
+int wfae_wino_out_stats(int variant, const float* M, float* lo, int NB, int Clo, int Hlo, int Wlo, double* part,
+                        int64_t part_capacity, int* splits_out, wfae_stream_t stream);
 int wfae_wino_out_t(int variant, const float* lo, float* Mt, int NB, int Clo, int Hlo, int Wlo, wfae_stream_t stream);
 int wfae_wino_gemm_down(int variant, const float* U, const float* V, float* M, int NB, int Chi, int Clo, int Hlo, int Wlo,
                         wfae_stream_t stream);

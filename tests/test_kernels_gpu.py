@@ -519,3 +519,48 @@ def test_conv1x1_bnact_refuses_unserved_geometries(ops, dev):
         ops.conv1x1_fwd_bnact(x2, st, torch.randn(32, 128, 1, 1, device=dev))
     with pytest.raises(WfaeError):
         ops.conv1x1_bwd_weight_bnact(torch.randn(1, 32, 3, 3, device=dev), x2, st, torch.empty(32, 128, 1, 1, device=dev))
+
+
+@pytest.mark.parametrize("nb,c,h,w", [(2, 32, 24, 20), (3, 16, 12, 12), (4, 8, 96, 96), (1, 20, 7, 5)])
+def test_producer_side_batchnorm_sums(ops, dev, nb, c, h, w):
+    """wfae_bn_act_fwd_stats (the BatchNorm + GELU pass also reduces the sums of what it writes) and
+    wfae_bn_stats_from_parts: the output equals wfae_bn_act_fwd bit for bit, the statistics those of wfae_bn_stats_train
+    on that output to fp64-summation-order rounding (both accumulate fp32 sums of four in fp64)"""
+    torch.manual_seed(5)
+    x = (torch.randn(nb, c, h, w) * 2 + 0.5).to(dev)
+    g, b = (torch.rand(c) + 0.5).to(dev), torch.randn(c).to(dev)
+    st = ops.bn_stats_train(x, g, b, torch.zeros(c, device=dev), torch.ones(c, device=dev))
+    y0 = ops.bn_act_fwd(x, st, 1)
+    y1, sp = ops.bn_act_fwd_stats(x, st, 1)
+    assert torch.equal(y0, y1) and sp.splits >= nb
+    g2, b2 = (torch.rand(c) + 0.5).to(dev), torch.randn(c).to(dev)
+    rm0, rv0 = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    rm1, rv1 = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    s0 = ops.bn_stats_train(y0, g2, b2, rm0, rv0)
+    s1 = ops.bn_stats_from_parts(sp, tuple(y1.shape), g2, b2, rm1, rv1)
+    for name in ("mean", "invstd", "scale", "shift"):
+        assert relerr(getattr(s1, name), getattr(s0, name)) < 2e-7, name
+    assert relerr(rm1, rm0) < 2e-7 and relerr(rv1, rv0) < 2e-7
+
+
+def test_winograd_output_transform_sums(ops, dev):
+    """wfae_wino_out_stats: the output transform of the Winograd-domain 4x4 s2 convolution also reduces the BatchNorm sums
+    of its result (both Winograd variants)"""
+    torch.manual_seed(6)
+    for mode, nb, chi, clo, hlo in (("f42", 2, 16, 32, 8), ("f22", 3, 16, 16, 6), ("f42", 1, 32, 64, 24)):
+        ops.set_winograd(mode)
+        try:
+            pl = ops.wino_plan(nb, chi, clo, hlo, hlo)
+            assert pl is not None
+            x = torch.randn(nb, chi, 2 * hlo, 2 * hlo, device=dev)
+            wt = torch.randn(clo, chi, 4, 4, device=dev) * 0.1
+            U, V = ops.wino_weights(wt, pl), ops.wino_in(x, pl)
+            lo0 = ops.wino_down(U, V, pl)
+            lo1, sp = ops.wino_down(U, V, pl, stats=True)
+            assert torch.equal(lo0, lo1)
+            g, b = torch.ones(clo, device=dev), torch.zeros(clo, device=dev)
+            s0 = ops.bn_stats_train(lo0, g, b, torch.zeros(clo, device=dev), torch.ones(clo, device=dev))
+            s1 = ops.bn_stats_from_parts(sp, tuple(lo1.shape), g, b, torch.zeros(clo, device=dev), torch.ones(clo, device=dev))
+            assert relerr(s1.mean, s0.mean) < 2e-7 and relerr(s1.invstd, s0.invstd) < 2e-7
+        finally:
+            ops.set_winograd("auto")

@@ -1886,6 +1886,17 @@ int wfae_wino_out(int variant, const float* M, float* lo, int NB, int Clo, int H
   return wino_out(variant, M, lo, NB, Clo, Hlo, Wlo, (hipStream_t)stream);
 }
 
+int wfae_wino_out_stats(int variant, const float* M, float* lo, int NB, int Clo, int Hlo, int Wlo, double* part,
+                        int64_t part_capacity, int* splits_out, wfae_stream_t stream) {
+  WFAE_REQUIRE(M && lo && part && splits_out, WFAE_ERR_NULL_POINTER, "wino_out_stats: null pointer");
+  WFAE_WINO_TILE_CHECK("wino_out_stats", Clo);
+  const int splits = wino_out_stat_splits(variant, NB, Hlo, Wlo);
+  WFAE_REQUIRE(part_capacity >= (int64_t)splits * Clo * 2, WFAE_ERR_WORKSPACE, "wino_out_stats: part holds %lld doubles, needs %lld",
+               (long long)part_capacity, (long long)splits * Clo * 2);
+  *splits_out = splits;
+  return wino_out_stats(variant, M, lo, NB, Clo, Hlo, Wlo, part, (hipStream_t)stream);
+}
+
 int wfae_wino_in_t(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, wfae_stream_t stream) {
   WFAE_REQUIRE(dV && hi, WFAE_ERR_NULL_POINTER, "wino_in_t: null pointer");
   WFAE_WINO_TILE_CHECK("wino_in_t", Chi);

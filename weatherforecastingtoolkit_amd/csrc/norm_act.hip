@@ -195,16 +195,21 @@ __global__ void sum_finalize_kernel(const double* __restrict__ part, int splits,
 
 // ------------------------------------------------------- BN apply (+GELU)
 // grid.x = NB*C planes, grid.y = chunks of the HW plane
-template <int ACT>
+// STATS: the block also reduces the sum / sum of squares of the values it WRITES (fp64 accumulators fed with fp32 sums of
+// four, exactly like chan_reduce_kernel) and leaves them in part[(split * C + c) * 2 + {0,1}], split = n * gridDim.y +
+// blockIdx.y — the BatchNorm that reads y next (the first Bottleneck after a Down/Up unit) needs no statistics pass
+template <int ACT, bool STATS = false>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift, float* __restrict__ y,
-                                                         int C, int HW, int vec, int nt) {
+                                                         int C, int HW, int vec, int nt, double* __restrict__ part = nullptr) {
+  __shared__ double sm[16];
   const int plane = blockIdx.x;
   const int c = plane % C;
   const float a = scale[c], b = shift[c];
   const float* xp = x + (long)plane * HW;
   float* yp = y + (long)plane * HW;
+  double s1 = 0.0, s2 = 0.0;
   if (vec) {
     const int n4 = HW >> 2;
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n4; i += gridDim.y * blockDim.x) {
@@ -214,11 +219,63 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
       const vf4 o = {act_f<ACT>(v.x), act_f<ACT>(v.y), act_f<ACT>(v.z), act_f<ACT>(v.w)};
       if (nt) __builtin_nontemporal_store(o, reinterpret_cast<vf4*>(yp) + i);
       else reinterpret_cast<vf4*>(yp)[i] = o;
+      if constexpr (STATS) {
+        s1 += (double)((o.x + o.y) + (o.z + o.w));
+        s2 += (double)(fmaf(o.x, o.x, o.y * o.y) + fmaf(o.z, o.z, o.w * o.w));
+      }
     }
   } else {
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < HW; i += gridDim.y * blockDim.x) {
-      yp[i] = act_f<ACT>(fmaf(xp[i], a, b));
+      const float o = act_f<ACT>(fmaf(xp[i], a, b));
+      yp[i] = o;
+      if constexpr (STATS) {
+        s1 += o;
+        s2 += (double)o * o;
+      }
     }
+  }
+  if constexpr (STATS) {
+    const double r1 = block_sum(s1, sm);
+    const double r2 = block_sum(s2, sm);
+    if (threadIdx.x == 0) {
+      const long split = (long)(plane / C) * gridDim.y + blockIdx.y;
+      part[(split * C + c) * 2 + 0] = r1;
+      part[(split * C + c) * 2 + 1] = r2;
+    }
+  }
+}
+
+// finalize for producer-side partial sums part[(split * C + c) * 2 + {0,1}]: one 64-lane block per channel adds the
+// splits in a fixed order (lane-strided, then a wave reduction), then the arithmetic of bn_finalize_kernel
+__global__ __launch_bounds__(64) void bn_finalize_parts_kernel(const double* __restrict__ part, int splits, long count, int C,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float eps, float momentum, float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var, float* __restrict__ save_mean,
+                                                               float* __restrict__ save_invstd, float* __restrict__ scale,
+                                                               float* __restrict__ shift) {
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = threadIdx.x; s < splits; s += 64) {
+    s1 += part[((long)s * C + c) * 2 + 0];
+    s2 += part[((long)s * C + c) * 2 + 1];
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (threadIdx.x != 0) return;
+  const double mean = s1 / (double)count;
+  double var = s2 / (double)count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float meanf = (float)mean;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  save_mean[c] = meanf;
+  save_invstd[c] = invstd;
+  const float a = gamma[c] * invstd;
+  scale[c] = a;
+  shift[c] = beta[c] - meanf * a;
+  if (running_mean) {
+    const double unb = count > 1 ? var * ((double)count / (double)(count - 1)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
   }
 }
 
@@ -652,8 +709,8 @@ int wfae_bn_fold_eval(const float* gamma, const float* beta, const float* runnin
   return check_launch("bn_fold_eval");
 }
 
-int wfae_bn_act_fwd(const float* x, const float* scale, const float* shift, float* y, int NB, int C,
-                    int HW, int act, wfae_stream_t stream) {
+static int bn_act_fwd_impl(const float* x, const float* scale, const float* shift, float* y, int NB, int C, int HW, int act,
+                           double* part, int64_t part_capacity, int* splits_out, wfae_stream_t stream) {
   WFAE_REQUIRE(x && scale && shift && y, WFAE_ERR_NULL_POINTER, "bn_act_fwd: null pointer");
   WFAE_REQUIRE(NB > 0 && C > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "bn_act_fwd: bad shape");
   const int vec = (HW % 4 == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
@@ -663,13 +720,49 @@ int wfae_bn_act_fwd(const float* x, const float* scale, const float* shift, floa
   dim3 grid((unsigned)((long)NB * C), gy);
   hipStream_t st = (hipStream_t)stream;
   static const int nt_fwd = getenv("WFAE_BN_NT_FWD") ? atoi(getenv("WFAE_BN_NT_FWD")) : 0;   // A/B: nontemporal store of y
+  if (splits_out) {
+    const int64_t splits = (int64_t)NB * gy;
+    WFAE_REQUIRE(part && part_capacity >= splits * C * 2, WFAE_ERR_WORKSPACE, "bn_act_fwd_stats: part holds %lld doubles, needs %lld",
+                 (long long)part_capacity, (long long)(splits * C * 2));
+    WFAE_REQUIRE(splits < (1ll << 31), WFAE_ERR_BAD_SHAPE, "bn_act_fwd_stats: too many partial rows");
+    *splits_out = (int)splits;
+    if (act == 1)
+      hipLaunchKernelGGL((bn_act_fwd_kernel<1, true>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, part);
+    else if (act == 2)
+      hipLaunchKernelGGL((bn_act_fwd_kernel<2, true>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, part);
+    else
+      hipLaunchKernelGGL((bn_act_fwd_kernel<0, true>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, part);
+    return check_launch("bn_act_fwd_stats");
+  }
   if (act == 1)
-    hipLaunchKernelGGL((bn_act_fwd_kernel<1>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd);
+    hipLaunchKernelGGL((bn_act_fwd_kernel<1>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, (double*)nullptr);
   else if (act == 2)
-    hipLaunchKernelGGL((bn_act_fwd_kernel<2>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd);
+    hipLaunchKernelGGL((bn_act_fwd_kernel<2>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, (double*)nullptr);
   else
-    hipLaunchKernelGGL((bn_act_fwd_kernel<0>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd);
+    hipLaunchKernelGGL((bn_act_fwd_kernel<0>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, (double*)nullptr);
   return check_launch("bn_act_fwd");
+}
+
+int wfae_bn_act_fwd(const float* x, const float* scale, const float* shift, float* y, int NB, int C,
+                    int HW, int act, wfae_stream_t stream) {
+  return bn_act_fwd_impl(x, scale, shift, y, NB, C, HW, act, nullptr, 0, nullptr, stream);
+}
+
+int wfae_bn_act_fwd_stats(const float* x, const float* scale, const float* shift, float* y, int NB, int C, int HW, int act,
+                          double* part, int64_t part_capacity, int* splits_out, wfae_stream_t stream) {
+  WFAE_REQUIRE(part && splits_out, WFAE_ERR_NULL_POINTER, "bn_act_fwd_stats: null pointer");
+  return bn_act_fwd_impl(x, scale, shift, y, NB, C, HW, act, part, part_capacity, splits_out, stream);
+}
+
+int wfae_bn_stats_from_parts(const double* part, int splits, int NB, int C, int HW, const float* gamma, const float* beta,
+                             float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
+                             float* save_invstd, float* scale, float* shift, wfae_stream_t stream) {
+  WFAE_REQUIRE(part && gamma && beta && save_mean && save_invstd && scale && shift, WFAE_ERR_NULL_POINTER,
+               "bn_stats_from_parts: null pointer");
+  WFAE_REQUIRE(splits > 0 && NB > 0 && C > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "bn_stats_from_parts: bad shape");
+  hipLaunchKernelGGL(bn_finalize_parts_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, part, splits, (long)NB * HW, C, gamma,
+                     beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
+  return check_launch("bn_finalize_parts");
 }
 
 int wfae_bn_act_bwd(const float* dy, const float* x, const float* gamma, const float* scale,

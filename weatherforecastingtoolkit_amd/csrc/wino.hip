@@ -263,14 +263,52 @@ __global__ __launch_bounds__(256) void wino_in_t_kernel(const float* __restrict_
 }
 
 // M[N*N][Clo][T] -> lo (N,Clo,Hlo,Wlo):  Y = A^T M A
-template <typename WV>
+// STATS: the block also leaves the sum / sum of squares of the values it writes (one channel, <= 256 tiles) in
+// part[(split * Clo + l) * 2 + {0,1}], split = n * gridDim.x + blockIdx.x, for the BatchNorm that follows the convolution
+template <typename WV, bool STATS = false>
 __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ Mx, float* __restrict__ lo, int Clo,
-                                                       int Hlo, int Wlo, long T) {
+                                                       int Hlo, int Wlo, long T, double* __restrict__ part = nullptr) {
   constexpr int N = WV::N, M = WV::M;
   const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
   const int tl = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tl >= Timg) return;
   const int l = blockIdx.y, n = blockIdx.z;
+  if constexpr (STATS) {
+    __shared__ double sm[16];
+    double s1 = 0.0, s2 = 0.0;
+    if (tl < Timg) {
+      const int ty = tl / TW, tx = tl - ty * TW;
+      const long xi_stride = (long)Clo * T;
+      const float* __restrict__ src = Mx + (long)l * T + (long)n * Timg + tl;
+      float m[N][N], y[M][M];
+#pragma unroll
+      for (int u = 0; u < N; ++u)
+#pragma unroll
+        for (int v = 0; v < N; ++v) m[u][v] = src[(long)(u * N + v) * xi_stride];
+      sandwich<M, N>(m, y, [](int a, int i) { return WV::AT[a][i]; });
+      float* __restrict__ dst = lo + ((long)(n * Clo + l) * Hlo + M * ty) * Wlo + M * tx;
+#pragma unroll
+      for (int a = 0; a < M; ++a) {
+        if constexpr (M == 2) {
+          *reinterpret_cast<float2*>(dst + (long)a * Wlo) = make_float2(y[a][0], y[a][1]);
+          s1 += (double)(y[a][0] + y[a][1]);
+          s2 += (double)fmaf(y[a][0], y[a][0], y[a][1] * y[a][1]);
+        } else {
+          *reinterpret_cast<float4*>(dst + (long)a * Wlo) = make_float4(y[a][0], y[a][1], y[a][2], y[a][3]);
+          s1 += (double)((y[a][0] + y[a][1]) + (y[a][2] + y[a][3]));
+          s2 += (double)(fmaf(y[a][0], y[a][0], y[a][1] * y[a][1]) + fmaf(y[a][2], y[a][2], y[a][3] * y[a][3]));
+        }
+      }
+    }
+    const double r1 = block_sum(s1, sm);
+    const double r2 = block_sum(s2, sm);
+    if (threadIdx.x == 0) {
+      const long split = (long)n * gridDim.x + blockIdx.x;
+      part[(split * Clo + l) * 2 + 0] = r1;
+      part[(split * Clo + l) * 2 + 1] = r2;
+    }
+    return;
+  }
+  if (tl >= Timg) return;
   const int ty = tl / TW, tx = tl - ty * TW;
   const long xi_stride = (long)Clo * T;
   const float* __restrict__ src = Mx + (long)l * T + (long)n * Timg + tl;
@@ -417,8 +455,20 @@ int wino_in_t(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo,
 int wino_out(int variant, const float* Mx, float* lo, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
   const int M = variant ? 4 : 2;
   const long T = (long)NB * (Hlo / M) * (Wlo / M);
-  WFAE_WINO_DISPATCH(wino_out_kernel, tile_grid(NB, Clo, Hlo, Wlo, M), Mx, lo, Clo, Hlo, Wlo, T);
+  WFAE_WINO_DISPATCH(wino_out_kernel, tile_grid(NB, Clo, Hlo, Wlo, M), Mx, lo, Clo, Hlo, Wlo, T, (double*)nullptr);
   return check_launch("wino_out");
+}
+int wino_out_stats(int variant, const float* Mx, float* lo, int NB, int Clo, int Hlo, int Wlo, double* part, hipStream_t st) {
+  const int M = variant ? 4 : 2;
+  const long T = (long)NB * (Hlo / M) * (Wlo / M);
+  const dim3 grid = tile_grid(NB, Clo, Hlo, Wlo, M);
+  if (variant == 0) hipLaunchKernelGGL((wino_out_kernel<W22, true>), grid, dim3(256), 0, st, Mx, lo, Clo, Hlo, Wlo, T, part);
+  else hipLaunchKernelGGL((wino_out_kernel<W42, true>), grid, dim3(256), 0, st, Mx, lo, Clo, Hlo, Wlo, T, part);
+  return check_launch("wino_out_stats");
+}
+int wino_out_stat_splits(int variant, int NB, int Hlo, int Wlo) {
+  const int M = variant ? 4 : 2;
+  return NB * (int)tile_grid(NB, 1, Hlo, Wlo, M).x;
 }
 int wino_out_t(int variant, const float* lo, float* Mt, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
   const int M = variant ? 4 : 2;

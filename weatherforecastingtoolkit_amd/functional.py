@@ -67,6 +67,12 @@ FUSE_A3 = os.environ.get("WFAE_FUSE_A3", "1") == "1"
 FUSE_A3_MAXC = int(os.environ.get("WFAE_FUSE_A3_MAXC", "128"))
 
 
+# BatchNorm sums produced by the kernel that WRITES the tensor when that kernel is a streaming one (the Winograd output
+# transform in front of a unit's BatchNorm; the unit's BatchNorm+GELU pass in front of the first Bottleneck): fp64
+# accumulation like the separate statistics pass, so its results are reproduced to fp64 rounding.  WFAE_PRODUCER_STATS=0: off.
+PRODUCER_STATS = os.environ.get("WFAE_PRODUCER_STATS", "1") == "1"
+
+
 def set_wgrad_overlap(flag: bool):
     global _overlap
     _overlap = bool(flag)
@@ -170,7 +176,13 @@ def _bn_stats(x, bn, training):
 
 
 def _bn_stats_rows(sr, x, bn, training):
-    """_bn_stats of x when a producer epilogue may already have reduced its per-channel sums (ops.StatRows)"""
+    """_bn_stats of x when a producer kernel may already have reduced its per-channel sums (ops.StatRows: fp32 rows of
+    a GEMM epilogue; ops.StatParts: fp64 partials of a streaming producer)"""
+    if training and isinstance(sr, ops.StatParts):
+        st = ops.bn_stats_from_parts(sr, tuple(x.shape), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                                     bn.momentum)
+        bn._nbt_pending += 1
+        return st
     if training and sr is not None:
         st = ops.bn_stats_from_rows(sr, tuple(x.shape), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                                     bn.momentum)
@@ -211,12 +223,15 @@ def _down_plan(x, w):
     return ops.wino_plan(x.shape[0], w.shape[1], w.shape[0], x.shape[2] // 2, x.shape[3] // 2)
 
 
-def _down_forward(x, w):
-    """-> (t, pl, U, V): 4x4 s2 convolution of x; U, V are None on the direct path"""
+def _down_forward(x, w, stats=False):
+    """-> (t, pl, U, V[, StatParts of t]): 4x4 s2 convolution of x; U, V are None on the direct path"""
     pl = _down_plan(x, w)
     if pl is None:
-        return _down_fwd(x, w), None, None, None
+        return (_down_fwd(x, w), None, None, None) + ((None,) if stats else ())
     U, V = ops.wino_weights(w, pl), ops.wino_in(x, pl)
+    if stats:
+        t, sp = ops.wino_down(U, V, pl, stats=True)
+        return t, pl, U, V, sp
     return ops.wino_down(U, V, pl), pl, U, V
 
 
@@ -249,9 +264,13 @@ class DownUnitFn(Function):
     def forward(ctx, x, w, gamma, beta, bn):
         x = _c(x)
         training = _use_batch_stats(bn)
-        t, pl, U, V = _down_forward(x, w)
-        st = _bn_stats(t, bn, training)
-        a = ops.bn_act_fwd(t, st, 1)
+        prod = training and PRODUCER_STATS
+        t, pl, U, V, sp = _down_forward(x, w, stats=True) if prod else _down_forward(x, w) + (None,)
+        st = _bn_stats_rows(sp, t, bn, training)
+        if prod:    # the sums of `a` ride along for the BatchNorm of the first Bottleneck (EncBlock.forward hands them on)
+            a, bn._out_stats = ops.bn_act_fwd_stats(t, st, 1)
+        else:
+            a, bn._out_stats = ops.bn_act_fwd(t, st, 1), None
         ctx.save_for_backward(x, w, gamma, t, st.mean, st.invstd, st.scale, st.shift, _opt(U), _opt(V))
         ctx.training, ctx.beta, ctx.pl = training, beta, pl
         return a
@@ -279,7 +298,10 @@ class UpUnitFn(Function):
         else:
             t = ops.conv4x4s2_up(x, w)
         st = _bn_stats(t, bn, training)
-        a = ops.bn_act_fwd(t, st, 1)
+        if training and PRODUCER_STATS:
+            a, bn._out_stats = ops.bn_act_fwd_stats(t, st, 1)
+        else:
+            a, bn._out_stats = ops.bn_act_fwd(t, st, 1), None
         ctx.save_for_backward(x, w, gamma, t, st.mean, st.invstd, st.scale, st.shift, _opt(U), _opt(Mt))
         ctx.training, ctx.beta, ctx.pl = training, beta, pl
         return a
@@ -536,7 +558,7 @@ class BottleneckFn(Function):
         groups = mod.f[5].groups
         training = _use_batch_stats(bn1)
         fuse = training and STAT_FUSION
-        st1 = _bn_stats_rows(x_stats if fuse else None, x, bn1, training)
+        st1 = _bn_stats_rows(x_stats if (fuse or isinstance(x_stats, ops.StatParts)) else None, x, bn1, training)
         fuse_a1 = FUSE_A1 and not fuse and x.shape[1] <= FUSE_A1_MAXC and ops.conv1x1_bnact_supported(x, w1.shape[0])
         if fuse_a1:
             a1, sr2 = None, None

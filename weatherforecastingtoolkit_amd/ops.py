@@ -99,6 +99,14 @@ class StatRows:
         self.part, self.rows = part, rows
 
 
+class StatParts:
+    """fp64 partial BatchNorm sums left by a producer kernel: `part` = [splits][C][2] doubles (sum, sum of squares)"""
+    __slots__ = ("part", "splits")
+
+    def __init__(self, part, splits):
+        self.part, self.splits = part, splits
+
+
 def conv1x1_fwd_stats(x, w, bias=None, res=None):
     """conv1x1_fwd whose epilogue also reduces the per-channel sum / sum of squares of y (for the BatchNorm that
     follows).  -> (y, StatRows | None); None = this shape is not served, run bn_stats_train on y."""
@@ -321,13 +329,22 @@ def wino_out_t(lo, pl):
     return Mt
 
 
-def wino_down(U, V, pl):
-    """lo = Out(U * V)"""
+def wino_down(U, V, pl, stats=False):
+    """lo = Out(U * V); stats=True: -> (lo, StatParts of lo) — the output transform also reduces the BatchNorm sums"""
+    import ctypes
     M = _buf(pl.nM, V)
     lo = torch.empty((pl.nb, pl.clo, pl.hlo, pl.wlo), dtype=torch.float32, device=V.device)
     _call("wfae_wino_gemm_down", pl.gemm_flops, 4 * (pl.nU + pl.nV + pl.nM), pl.variant, _p(U), _p(V), _p(M), *pl.dims, _stream())
-    _call("wfae_wino_out", 0, 4 * (pl.nM + lo.numel()), pl.variant, _p(M), _p(lo), pl.nb, pl.clo, pl.hlo, pl.wlo, _stream())
-    return lo
+    if not stats:
+        _call("wfae_wino_out", 0, 4 * (pl.nM + lo.numel()), pl.variant, _p(M), _p(lo), pl.nb, pl.clo, pl.hlo, pl.wlo, _stream())
+        return lo
+    m = 4 if pl.variant else 2
+    cap = 2 * pl.clo * pl.nb * (((pl.hlo // m) * (pl.wlo // m) + 255) // 256)
+    part = torch.empty(cap, dtype=torch.float64, device=V.device)
+    splits = ctypes.c_int(0)
+    _call("wfae_wino_out_stats", 0, 4 * (pl.nM + lo.numel()), pl.variant, _p(M), _p(lo), pl.nb, pl.clo, pl.hlo, pl.wlo,
+          part.data_ptr(), cap, ctypes.cast(ctypes.pointer(splits), ctypes.c_void_p), _stream(), label="wfae_wino_out")
+    return lo, StatParts(part, splits.value)
 
 
 def wino_up(U, Mt, pl):
@@ -508,6 +525,31 @@ def bn_stats_from_rows(sr, shape, gamma, beta, running_mean, running_var, eps=1e
           momentum, _p(running_mean), _p(running_var), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
           ws.data_ptr(), ws.numel(), _stream(), label="wfae_bn_stats_train")
     return st
+
+
+def bn_stats_from_parts(sp, shape, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
+    """bn_stats_train of a tensor of `shape` (N, C, H, W) whose fp64 partial sums a producer kernel left in `sp`"""
+    _chk(gamma, beta, running_mean, running_var)
+    nb, c, h, wd = shape
+    st = BnStats(c, gamma.device)
+    _call("wfae_bn_stats_from_parts", 0, 8 * sp.part.numel(), sp.part.data_ptr(), sp.splits, nb, c, h * wd, _p(gamma), _p(beta),
+          eps, momentum, _p(running_mean), _p(running_var), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift), _stream(),
+          label="wfae_bn_stats_train")
+    return st
+
+
+def bn_act_fwd_stats(x, st, act=1):
+    """bn_act_fwd that also reduces the BatchNorm sums of its OUTPUT -> (y, StatParts)"""
+    import ctypes
+    _chk(x)
+    nb, c, h, wd = x.shape
+    y = torch.empty_like(x)
+    cap = 2 * c * nb * max(1, min(1024, (h * wd + 4095) // 4096 + 1))
+    part = torch.empty(cap, dtype=torch.float64, device=x.device)
+    splits = ctypes.c_int(0)
+    _call("wfae_bn_act_fwd_stats", 0, 8 * x.numel(), _p(x), _p(st.scale), _p(st.shift), _p(y), nb, c, h * wd, act,
+          part.data_ptr(), cap, ctypes.cast(ctypes.pointer(splits), ctypes.c_void_p), _stream(), label="wfae_bn_act_fwd")
+    return y, StatParts(part, splits.value)
 
 
 def bn_fold_eval(gamma, beta, running_mean, running_var, eps=1e-5):

@@ -37,6 +37,15 @@ def _residual_stack(width, depth, groups):
     return tnn.Sequential(*blocks)
 
 
+def _with_unit_stats(a, bn):
+    """hand the BatchNorm sums of a unit's output (reduced by the kernel that wrote it, functional.PRODUCER_STATS) to the
+    first Bottleneck through the tensor attribute Bottleneck.forward reads"""
+    sp, bn._out_stats = getattr(bn, "_out_stats", None), None
+    if sp is not None:
+        a._wfae_stats = sp
+    return a
+
+
 class Bottleneck(tnn.Module):
     """Pre-activation bottleneck  x + W3 . gelu(bn(G3x3 . gelu(bn(W1 . gelu(bn(x))))))  at a quarter of the width in
     the middle (reference ae_64x8x8_lin.py:7-22; `f.0 … f.8` are its Sequential indices).  Runs as ONE autograd
@@ -77,7 +86,7 @@ class EncBlock(tnn.Module):
 
     def forward(self, x):
         conv, bn, _ = self.down
-        return self.res(Fn.DownUnitFn.apply(x, conv.weight, bn.weight, bn.bias, bn))
+        return self.res(_with_unit_stats(Fn.DownUnitFn.apply(x, conv.weight, bn.weight, bn.bias, bn), bn))
 
 
 class DecBlock(tnn.Module):
@@ -91,7 +100,7 @@ class DecBlock(tnn.Module):
 
     def forward(self, x):
         convt, bn, _ = self.up
-        return self.res(Fn.UpUnitFn.apply(x, convt.weight, bn.weight, bn.bias, bn))
+        return self.res(_with_unit_stats(Fn.UpUnitFn.apply(x, convt.weight, bn.weight, bn.bias, bn), bn))
 
 
 class PosAwareAE_TF(tnn.Module):

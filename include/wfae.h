@@ -76,13 +76,14 @@ int wfae_conv1x1_fwd(const float* x, const float* w, const float* bias, const fl
                      wfae_stream_t stream);
 /* Same convolution with the BatchNorm statistics of y (the next layer of Bottleneck is always
  * BatchNorm2d, ae_64x8x8_lin.py:14-19) reduced in the epilogue instead of by a second pass over y:
- * stat_part (capacity stat_capacity floats) receives *stat_rows partial rows, sum[rows][Cout] followed by
- * sumsq[rows][Cout] (one row per 64-pixel wave tile); wfae_bn_stats_from_rows finishes them.  When the
+ * stat_part (capacity stat_capacity DOUBLES) receives *stat_rows partial rows, sum[rows][Cout] followed by
+ * sumsq[rows][Cout] (one row per 64-pixel wave tile, reduced in fp64 from fp32 sums of four — the arithmetic of the
+ * separate statistics pass, so its results are reproduced to fp64 rounding); wfae_bn_stats_from_rows finishes them.  When the
  * shape is not served by the vector epilogue *stat_rows is 0: y is still complete, run
  * wfae_bn_stats_train on it.  stat_rows is a HOST pointer. */
 int wfae_conv1x1_fwd_stats(const float* x, const float* w, const float* bias, const float* res,
                            int64_t res_img_stride, float* y, int NB, int Cin, int Cout, int HW,
-                           float* stat_part, int64_t stat_capacity, int* stat_rows, wfae_stream_t stream);
+                           double* stat_part, int64_t stat_capacity, int* stat_rows, wfae_stream_t stream);
 /* BatchNorm-apply + GELU fused into the 1x1 GEMM's operand loader (SURVEY.md 2.2 K3/K7/K8 "fused prologue"):
  * y = conv1x1(gelu(x * bn_scale[c] + bn_shift[c]), w) (+bias)(+res) and, for the backward pass,
  * dw (+)= dy * gelu(x * bn_scale + bn_shift)^T — the activated tensor of the reference's BN -> GELU -> Conv1x1 chain
@@ -93,7 +94,8 @@ int wfae_conv1x1_fwd_stats(const float* x, const float* w, const float* bias, co
  * (WFAE_ERR_UNSUPPORTED otherwise: run the two-kernel form). */
 int wfae_conv1x1_fwd_bnact(const float* x, const float* bn_scale, const float* bn_shift, const float* w,
                            const float* bias, const float* res, int64_t res_img_stride, float* y, int NB, int Cin,
-                           int Cout, int HW, wfae_stream_t stream);
+                           int Cout, int HW, double* stat_part, int64_t stat_capacity, int* stat_rows,
+                           wfae_stream_t stream);   /* stat_part / stat_rows: as wfae_conv1x1_fwd_stats, or both null */
 int wfae_conv1x1_bwd_weight_bnact(const float* dy, const float* x, const float* bn_scale, const float* bn_shift,
                                   float* dw, int NB, int Cin, int Cout, int HW, int accumulate, void* ws,
                                   size_t ws_bytes, wfae_stream_t stream);
@@ -182,7 +184,7 @@ int wfae_bn_stats_train(const float* x, int NB, int C, int HW, const float* gamm
                         float* running_var, float* save_mean, float* save_invstd, float* scale,
                         float* shift, void* ws, size_t ws_bytes, wfae_stream_t stream);
 /* wfae_bn_stats_train's second half on the partial rows of wfae_conv1x1_fwd_stats (same outputs) */
-int wfae_bn_stats_from_rows(const float* stat_part, int rows, int NB, int C, int HW, const float* gamma,
+int wfae_bn_stats_from_rows(const double* stat_part, int rows, int NB, int C, int HW, const float* gamma,
                             const float* beta, float eps, float momentum, float* running_mean,
                             float* running_var, float* save_mean, float* save_invstd, float* scale,
                             float* shift, void* ws, size_t ws_bytes, wfae_stream_t stream);
@@ -244,6 +246,9 @@ int wfae_wino_out(int variant, const float* M, float* lo, int NB, int Clo, int H
  * {0 = sum, 1 = sum of squares}], *splits_out rows; finish them with wfae_bn_stats_from_parts. */
 int wfae_wino_out_stats(int variant, const float* M, float* lo, int NB, int Clo, int Hlo, int Wlo, double* part,
                         int64_t part_capacity, int* splits_out, wfae_stream_t stream);
+/* the same for the adjoint input transform, whose result is the output of a ConvTranspose2d (DecBlock.up, :42-43) */
+int wfae_wino_in_t_stats(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, double* part,
+                         int64_t part_capacity, int* splits_out, wfae_stream_t stream);
 int wfae_wino_out_t(int variant, const float* lo, float* Mt, int NB, int Clo, int Hlo, int Wlo, wfae_stream_t stream);
 int wfae_wino_gemm_down(int variant, const float* U, const float* V, float* M, int NB, int Chi, int Clo, int Hlo, int Wlo,
                         wfae_stream_t stream);

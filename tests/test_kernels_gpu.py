@@ -80,9 +80,18 @@ def test_conv1x1_fused_bn_stats(ops, dev, nb, cin, cout, h, w, res, served):
     rm1, rv1 = rm0.clone(), rv0.clone()
     a = ops.bn_stats_train(y, gamma, beta, rm0, rv0)
     b = ops.bn_stats_from_rows(sr, tuple(y.shape), gamma, beta, rm1, rv1)
+    # fp64 partial sums (16-lane DPP reduction on doubles) fed with fp32 sums of four, like the separate pass
     for name in ("mean", "invstd", "scale", "shift"):
-        assert relerr(getattr(b, name), getattr(a, name)) < 2e-6, name
-    assert relerr(rm1, rm0) < 2e-6 and relerr(rv1, rv0) < 2e-6
+        assert relerr(getattr(b, name), getattr(a, name)) < 2e-7, name
+    assert relerr(rm1, rm0) < 2e-7 and relerr(rv1, rv0) < 2e-7
+    if cin % 4 == 0 and ops.conv1x1_bnact_supported(x, cout):   # the same epilogue behind the fused BN + GELU prologue
+        stx = ops.bn_stats_train(x, torch.ones(cin, device=dev), torch.zeros(cin, device=dev), torch.zeros(cin, device=dev),
+                                 torch.ones(cin, device=dev))
+        y2, sr2 = ops.conv1x1_fwd_bnact(x, stx, wt, None, r, stats=True)
+        assert torch.equal(y2, ops.conv1x1_fwd(ops.bn_act_fwd(x, stx, 1), wt, None, r)) and sr2 is not None
+        c2 = ops.bn_stats_from_rows(sr2, tuple(y2.shape), gamma, beta, torch.zeros(cout, device=dev), torch.ones(cout, device=dev))
+        d2 = ops.bn_stats_train(y2, gamma, beta, torch.zeros(cout, device=dev), torch.ones(cout, device=dev))
+        assert relerr(c2.mean, d2.mean) < 2e-7 and relerr(c2.invstd, d2.invstd) < 2e-7
 
 
 # -------------------------------------------------------------------- linear
@@ -547,7 +556,7 @@ def test_winograd_output_transform_sums(ops, dev):
     """wfae_wino_out_stats: the output transform of the Winograd-domain 4x4 s2 convolution also reduces the BatchNorm sums
     of its result (both Winograd variants)"""
     torch.manual_seed(6)
-    for mode, nb, chi, clo, hlo in (("f42", 2, 16, 32, 8), ("f22", 4, 16, 16, 6), ("f42", 1, 32, 64, 24)):
+    for mode, nb, chi, clo, hlo in (("f42", 2, 16, 32, 8), ("f22", 4, 16, 16, 6), ("f42", 1, 32, 64, 24), ("f42", 1, 16, 16, 40)):
         ops.set_winograd(mode)
         try:
             pl = ops.wino_plan(nb, chi, clo, hlo, hlo)
@@ -562,5 +571,15 @@ def test_winograd_output_transform_sums(ops, dev):
             s0 = ops.bn_stats_train(lo0, g, b, torch.zeros(clo, device=dev), torch.ones(clo, device=dev))
             s1 = ops.bn_stats_from_parts(sp, tuple(lo1.shape), g, b, torch.zeros(clo, device=dev), torch.ones(clo, device=dev))
             assert relerr(s1.mean, s0.mean) < 2e-7 and relerr(s1.invstd, s0.invstd) < 2e-7
+            # the adjoint input transform (ConvTranspose2d output) with its sums
+            lo = torch.randn(nb, clo, hlo, hlo, device=dev)
+            Mt = ops.wino_out_t(lo, pl)
+            hi0 = ops.wino_up(U, Mt, pl)
+            hi1, sph = ops.wino_up(U, Mt, pl, stats=True)
+            assert torch.equal(hi0, hi1)
+            gh, bh = torch.ones(chi, device=dev), torch.zeros(chi, device=dev)
+            h0 = ops.bn_stats_train(hi0, gh, bh, torch.zeros(chi, device=dev), torch.ones(chi, device=dev))
+            h1 = ops.bn_stats_from_parts(sph, tuple(hi1.shape), gh, bh, torch.zeros(chi, device=dev), torch.ones(chi, device=dev))
+            assert relerr(h1.mean, h0.mean) < 2e-7 and relerr(h1.invstd, h0.invstd) < 2e-7
         finally:
             ops.set_winograd("auto")

@@ -19,7 +19,7 @@ x = _frames(g).to(dev)
 rel = lambda u, v: float((u.double() - v.double()).abs().max() / (v.double().abs().max() + 1e-30))
 runs = {}
 for fuse in (False, True):
-    Fn.STAT_FUSION = fuse
+    Fn.STAT_FUSION = Fn.PRODUCER_STATS = fuse
     outs = {}
     hooks = [m.register_forward_hook(lambda mod, i, o, n=n: outs.__setitem__(n, o.detach().clone()))
              for n, m in net.named_modules() if isinstance(m, Bottleneck)]

@@ -114,7 +114,8 @@ int wino_out(int variant, const float* M, float* lo, int NB, int Clo, int Hlo, i
 int wino_out_t(int variant, const float* lo, float* Mt, int NB, int Clo, int Hlo, int Wlo, hipStream_t st);  // adjoint
 // wino_out that also leaves per-channel fp64 partial sums of lo in part[(split * Clo + l) * 2 + {0,1}]
 int wino_out_stats(int variant, const float* M, float* lo, int NB, int Clo, int Hlo, int Wlo, double* part, hipStream_t st);
-int wino_out_stat_splits(int variant, int NB, int Hlo, int Wlo);
+int wino_out_stat_splits(int variant, int NB, int Hlo, int Wlo);   // also the split count of wino_in_t_stats
+int wino_in_t_stats(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, double* part, hipStream_t st);
 int wino_weights(int variant, const float* w, float* U, int Clo, int Chi, hipStream_t st);                   // -> U[xi][Clo][4Chi]
 int wino_weights_t(int variant, const float* dU, float* dw, int Clo, int Chi, int beta, hipStream_t st);     // G^T dU G
 

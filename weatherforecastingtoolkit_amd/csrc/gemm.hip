@@ -85,10 +85,11 @@ struct GemmP {
   // 2: s_setprio 1 only around the multiply phase; 0: none
   int prio;
   // BatchNorm statistics of the result, fused into the E_BATCHED vector epilogue (kernels with two wave columns):
-  // stat_sum / stat_sq [2 * ntiles][M] receive, per output row m (= channel) and 64-column wave tile, the sum and the
+  // (fp64: the 16-lane DPP reduction runs on doubles, so the partial sums are exact to fp64 rounding like the separate
+  // statistics pass) stat_sum / stat_sq [2 * ntiles][M] receive, per output row m (= channel) and 64-column wave tile, the sum and the
   // sum of squares of the values stored by that wave; null = off
-  float* stat_sum;
-  float* stat_sq;
+  double* stat_sum;
+  double* stat_sq;
   // BatchNorm-apply + GELU prologue on the B operand (PRO kernels): B'(k,n) = gelu(B(k,n) * b_scale[c] + b_shift[c]) with
   // c the CHANNEL index of the element — k for B_NCONTIG (1x1 forward: B = x, k = input channel), n for B_KCONTIG
   // (1x1 weight gradient: B = x, n = input channel).  Applied between the global load and the LDS store, so the
@@ -131,6 +132,18 @@ __device__ __forceinline__ float4 load4u(const float* ptr) {
 // gelu(v * s + h) on four elements: exactly bn_act_fwd_kernel<GELU>'s arithmetic (norm_act.hip)
 __device__ __forceinline__ float4 bn_gelu4(float4 v, float s, float h) {
   return make_float4(gelu_f(fmaf(v.x, s, h)), gelu_f(fmaf(v.y, s, h)), gelu_f(fmaf(v.z, s, h)), gelu_f(fmaf(v.w, s, h)));
+}
+
+// the same inclusive prefix sum on doubles (two DPP moves per step); lane 15 of every row ends up with the row total
+#define WFAE_DPP_F64(v, CTRL)                                                                                    \
+  __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true),                       \
+                   __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true))
+__device__ __forceinline__ double dpp_row_sum(double v) {
+  v += WFAE_DPP_F64(v, 0x111);
+  v += WFAE_DPP_F64(v, 0x112);
+  v += WFAE_DPP_F64(v, 0x114);
+  v += WFAE_DPP_F64(v, 0x118);
+  return v;
 }
 
 // VEC: every operand/result row is 16-byte aligned and a multiple of 4 floats long, so all
@@ -1054,10 +1067,10 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
         }
         if constexpr (EK == E_BATCHED && WNW == 2) {
           if (p.stat_sum) {  // wave-uniform: every lane takes part in the shuffles
-            float s1 = 0.f, s2 = 0.f;
-            if (nok && m < p.M) {
-              s1 = (v.x + v.y) + (v.z + v.w);
-              s2 = fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);
+            double s1 = 0.0, s2 = 0.0;
+            if (nok && m < p.M) {   // fp32 sums of four enter the fp64 reduction, exactly as in chan_reduce_kernel
+              s1 = (double)((v.x + v.y) + (v.z + v.w));
+              s2 = (double)(fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w));
             }
             // the F4R = 16 lanes of one output row are one DPP row: four row_shr adds leave the total in its lane 15
             static_assert(F4R == 16, "one DPP row per output row");
@@ -1374,57 +1387,12 @@ int splitk_finish(const float* slab, float* out, const float* bias_n, long MN, i
 
 extern "C" {
 
-static int conv1x1_fwd_impl(const float* x, const float* w, const float* bias, const float* res,
-                            int64_t res_img_stride, float* y, int NB, int Cin, int Cout, int HW, float* stat_part,
-                            int64_t stat_capacity, int* stat_rows, wfae_stream_t stream) {
+static int conv1x1_fwd_impl(const float* x, const float* bn_scale, const float* bn_shift, const float* w, const float* bias,
+                            const float* res, int64_t res_img_stride, float* y, int NB, int Cin, int Cout, int HW,
+                            double* stat_part, int64_t stat_capacity, int* stat_rows, wfae_stream_t stream) {
   WFAE_REQUIRE(x && w && y, WFAE_ERR_NULL_POINTER, "conv1x1_fwd: null pointer");
   WFAE_REQUIRE(NB > 0 && Cin > 0 && Cout > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "conv1x1_fwd: bad shape");
   WFAE_REQUIRE((int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "conv1x1_fwd: NB*HW too large");
-  GemmP p = {};
-  p.A = w; p.B = x; p.C = y; p.bias = bias; p.res = res;
-  p.M = Cout; p.N = NB * HW; p.K = Cin; p.k_per_split = cdiv(Cin, BK) * BK;
-  p.a_hw = Cin; p.a_img = 0; p.a_ld = Cin;
-  p.b_hw = HW; p.b_img = (long)Cin * HW; p.b_ld = HW;
-  p.c_hw = HW; p.c_img = (long)Cout * HW; p.c_ld = HW; p.res_img = res_img_stride;
-  p.a_vec = (Cin % 4 == 0) && aligned16(w);
-  p.b_vec = (HW % 4 == 0) && aligned16(x);
-  p.c_vec = (HW % 4 == 0) && aligned16(y) && (!res || (aligned16(res) && res_img_stride % 4 == 0));
-  if (stat_rows) {
-    // the statistics ride in the vector epilogue of the two-wave-column kernels; anything else reports 0 rows and the
-    // caller runs wfae_bn_stats_train on y
-    const int ntiles = cdiv(p.N, BN);
-    const int64_t rows = 2 * (int64_t)ntiles;
-    const bool ok = stat_part && p.a_vec && p.b_vec && p.c_vec && pick_bm(p.M, ntiles) != 32 &&
-                    stat_capacity >= 2 * rows * Cout;
-    *stat_rows = ok ? (int)rows : 0;
-    if (ok) {
-      p.stat_sum = stat_part;
-      p.stat_sq = stat_part + rows * Cout;
-    }
-  }
-  return launch_gemm<A_KCONTIG, B_NCONTIG, E_BATCHED>(p, 1, (hipStream_t)stream, "conv1x1_fwd");
-}
-
-int wfae_conv1x1_fwd(const float* x, const float* w, const float* bias, const float* res,
-                     int64_t res_img_stride, float* y, int NB, int Cin, int Cout, int HW,
-                     wfae_stream_t stream) {
-  return conv1x1_fwd_impl(x, w, bias, res, res_img_stride, y, NB, Cin, Cout, HW, nullptr, 0, nullptr, stream);
-}
-
-int wfae_conv1x1_fwd_stats(const float* x, const float* w, const float* bias, const float* res,
-                           int64_t res_img_stride, float* y, int NB, int Cin, int Cout, int HW, float* stat_part,
-                           int64_t stat_capacity, int* stat_rows, wfae_stream_t stream) {
-  WFAE_REQUIRE(stat_part && stat_rows, WFAE_ERR_NULL_POINTER, "conv1x1_fwd_stats: null pointer");
-  return conv1x1_fwd_impl(x, w, bias, res, res_img_stride, y, NB, Cin, Cout, HW, stat_part, stat_capacity, stat_rows,
-                          stream);
-}
-
-int wfae_conv1x1_fwd_bnact(const float* x, const float* bn_scale, const float* bn_shift, const float* w,
-                           const float* bias, const float* res, int64_t res_img_stride, float* y, int NB, int Cin,
-                           int Cout, int HW, wfae_stream_t stream) {
-  WFAE_REQUIRE(x && bn_scale && bn_shift && w && y, WFAE_ERR_NULL_POINTER, "conv1x1_fwd_bnact: null pointer");
-  WFAE_REQUIRE(NB > 0 && Cin > 0 && Cout > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "conv1x1_fwd_bnact: bad shape");
-  WFAE_REQUIRE((int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "conv1x1_fwd_bnact: NB*HW too large");
   GemmP p = {};
   p.A = w; p.B = x; p.C = y; p.bias = bias; p.res = res;
   p.b_scale = bn_scale; p.b_shift = bn_shift;
@@ -1432,14 +1400,55 @@ int wfae_conv1x1_fwd_bnact(const float* x, const float* bn_scale, const float* b
   p.a_hw = Cin; p.a_img = 0; p.a_ld = Cin;
   p.b_hw = HW; p.b_img = (long)Cin * HW; p.b_ld = HW;
   p.c_hw = HW; p.c_img = (long)Cout * HW; p.c_ld = HW; p.res_img = res_img_stride;
-  const bool vec = (Cin % 4 == 0) && aligned16(w) && (HW % 4 == 0) && aligned16(x) && aligned16(y) &&
-                   (!res || (aligned16(res) && res_img_stride % 4 == 0));
-  WFAE_REQUIRE(vec, WFAE_ERR_UNSUPPORTED,
-               "conv1x1_fwd_bnact: needs Cin %% 4 == 0, HW %% 4 == 0 and 16-byte aligned tensors (Cin %d, HW %d)", Cin, HW);
-  p.a_vec = p.b_vec = p.c_vec = 1;
-  // one M tile of 256 rows when Cout fills it: every element of x is then loaded (and activated) exactly once
-  p.big_ok = 1;
-  return launch_gemm_v<A_KCONTIG, B_NCONTIG, E_BATCHED, true, 1>(p, 1, (hipStream_t)stream, "conv1x1_fwd_bnact");
+  p.a_vec = (Cin % 4 == 0) && aligned16(w);
+  p.b_vec = (HW % 4 == 0) && aligned16(x);
+  p.c_vec = (HW % 4 == 0) && aligned16(y) && (!res || (aligned16(res) && res_img_stride % 4 == 0));
+  const bool vec = p.a_vec && p.b_vec && p.c_vec;
+  if (bn_scale) {
+    WFAE_REQUIRE(vec, WFAE_ERR_UNSUPPORTED,
+                 "conv1x1_fwd_bnact: needs Cin %% 4 == 0, HW %% 4 == 0 and 16-byte aligned tensors (Cin %d, HW %d)", Cin, HW);
+    // one M tile of 256 rows when Cout fills it: every element of x is then loaded (and activated) exactly once
+    p.big_ok = 1;
+  }
+  if (stat_rows) {
+    // the statistics ride in the vector epilogue of the two-wave-column kernels; anything else reports 0 rows and the
+    // caller runs wfae_bn_stats_train on y
+    const int ntiles = cdiv(p.N, BN);
+    const int64_t rows = 2 * (int64_t)ntiles;
+    const bool ok = stat_part && vec && pick_bm(p.M, ntiles) != 32 && stat_capacity >= 2 * rows * Cout;
+    *stat_rows = ok ? (int)rows : 0;
+    if (ok) {
+      p.stat_sum = stat_part;
+      p.stat_sq = stat_part + rows * Cout;
+    }
+  }
+  if (bn_scale) return launch_gemm_v<A_KCONTIG, B_NCONTIG, E_BATCHED, true, 1>(p, 1, (hipStream_t)stream, "conv1x1_fwd_bnact");
+  return launch_gemm<A_KCONTIG, B_NCONTIG, E_BATCHED>(p, 1, (hipStream_t)stream, "conv1x1_fwd");
+}
+
+int wfae_conv1x1_fwd(const float* x, const float* w, const float* bias, const float* res,
+                     int64_t res_img_stride, float* y, int NB, int Cin, int Cout, int HW,
+                     wfae_stream_t stream) {
+  return conv1x1_fwd_impl(x, nullptr, nullptr, w, bias, res, res_img_stride, y, NB, Cin, Cout, HW, nullptr, 0, nullptr, stream);
+}
+
+int wfae_conv1x1_fwd_stats(const float* x, const float* w, const float* bias, const float* res,
+                           int64_t res_img_stride, float* y, int NB, int Cin, int Cout, int HW, double* stat_part,
+                           int64_t stat_capacity, int* stat_rows, wfae_stream_t stream) {
+  WFAE_REQUIRE(stat_part && stat_rows, WFAE_ERR_NULL_POINTER, "conv1x1_fwd_stats: null pointer");
+  return conv1x1_fwd_impl(x, nullptr, nullptr, w, bias, res, res_img_stride, y, NB, Cin, Cout, HW, stat_part, stat_capacity,
+                          stat_rows, stream);
+}
+
+int wfae_conv1x1_fwd_bnact(const float* x, const float* bn_scale, const float* bn_shift, const float* w,
+                           const float* bias, const float* res, int64_t res_img_stride, float* y, int NB, int Cin,
+                           int Cout, int HW, double* stat_part, int64_t stat_capacity, int* stat_rows,
+                           wfae_stream_t stream) {
+  WFAE_REQUIRE(x && bn_scale && bn_shift && w && y, WFAE_ERR_NULL_POINTER, "conv1x1_fwd_bnact: null pointer");
+  WFAE_REQUIRE((stat_part != nullptr) == (stat_rows != nullptr), WFAE_ERR_NULL_POINTER,
+               "conv1x1_fwd_bnact: stat_part and stat_rows go together");
+  return conv1x1_fwd_impl(x, bn_scale, bn_shift, w, bias, res, res_img_stride, y, NB, Cin, Cout, HW, stat_part, stat_capacity,
+                          stat_rows, stream);
 }
 
 int wfae_conv1x1_bwd_weight_bnact(const float* dy, const float* x, const float* bn_scale, const float* bn_shift,
@@ -1901,6 +1910,17 @@ int wfae_wino_in_t(int variant, const float* dV, float* hi, int NB, int Chi, int
   WFAE_REQUIRE(dV && hi, WFAE_ERR_NULL_POINTER, "wino_in_t: null pointer");
   WFAE_WINO_TILE_CHECK("wino_in_t", Chi);
   return wino_in_t(variant, dV, hi, NB, Chi, Hlo, Wlo, (hipStream_t)stream);
+}
+
+int wfae_wino_in_t_stats(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, double* part,
+                         int64_t part_capacity, int* splits_out, wfae_stream_t stream) {
+  WFAE_REQUIRE(dV && hi && part && splits_out, WFAE_ERR_NULL_POINTER, "wino_in_t_stats: null pointer");
+  WFAE_WINO_TILE_CHECK("wino_in_t_stats", Chi);
+  const int splits = wino_out_stat_splits(variant, NB, Hlo, Wlo);
+  WFAE_REQUIRE(part_capacity >= (int64_t)splits * Chi * 2, WFAE_ERR_WORKSPACE, "wino_in_t_stats: part holds %lld doubles, needs %lld",
+               (long long)part_capacity, (long long)splits * Chi * 2);
+  *splits_out = splits;
+  return wino_in_t_stats(variant, dV, hi, NB, Chi, Hlo, Wlo, part, (hipStream_t)stream);
 }
 
 int wfae_wino_gemm_down(int variant, const float* U, const float* V, float* M, int NB, int Chi, int Clo, int Hlo, int Wlo,

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(RT) void chan_reduce_kernel(const float* __restrict
 
 // partial rows of a producer epilogue (wfae_conv1x1_fwd_stats): sum[P][C], sq[P][C] -> fp64 partials in the layout
 // chan_reduce_kernel writes, part[(c * splits + s) * 2 + {0,1}]; block (c / 64, s) adds the rows p = s, s + splits, ...
-__global__ __launch_bounds__(256) void stat_rows_reduce_kernel(const float* __restrict__ sum, const float* __restrict__ sq,
+__global__ __launch_bounds__(256) void stat_rows_reduce_kernel(const double* __restrict__ sum, const double* __restrict__ sq,
                                                                double* __restrict__ part, int P, int C, int splits) {
   __shared__ double sm[2][4][64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -103,8 +103,8 @@ __global__ __launch_bounds__(256) void stat_rows_reduce_kernel(const float* __re
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
     for (long p = s + (long)rg * splits; p < P; p += 4l * splits) {
-      s1 += (double)sum[p * C + c];
-      s2 += (double)sq[p * C + c];
+      s1 += sum[p * C + c];
+      s2 += sq[p * C + c];
     }
   sm[0][rg][cl] = s1;
   sm[1][rg][cl] = s2;
@@ -673,7 +673,7 @@ int wfae_bn_stats_train(const float* x, int NB, int C, int HW, const float* gamm
   return check_launch("bn_finalize");
 }
 
-int wfae_bn_stats_from_rows(const float* stat_part, int rows, int NB, int C, int HW, const float* gamma,
+int wfae_bn_stats_from_rows(const double* stat_part, int rows, int NB, int C, int HW, const float* gamma,
                             const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                             float* save_mean, float* save_invstd, float* scale, float* shift, void* ws, size_t ws_bytes,
                             wfae_stream_t stream) {

@@ -127,14 +127,20 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 // neighbouring tiles (tile patches are 2N = 2M+2 wide at stride 2M) are gathered from them — no atomics.
 // hi row 2M*ty + r belongs to phase p = (r & 1) ^ 1 and phase-row i = (r + 1 - p) / 2 of tile ty; row r = 0 also is
 // phase-row M of tile ty-1, row r = 2M-1 also phase-row 0 of tile ty+1 (same for columns).
-template <typename WV>
+// STATS: the block also leaves the sum / sum of squares of the values it writes (one channel of one image, <= 256 blocks
+// of 2M x 2M) in part[(split * Chi + h) * 2 + {0,1}], split = n * gridDim.x + blockIdx.x — for the BatchNorm that follows
+// a ConvTranspose2d (DecBlock.up)
+template <typename WV, bool STATS = false>
 __global__ __launch_bounds__(256) void wino_in_t_kernel(const float* __restrict__ dV, float* __restrict__ hi, int Chi,
-                                                        int Hlo, int Wlo, long T) {
+                                                        int Hlo, int Wlo, long T, double* __restrict__ part = nullptr) {
   constexpr int N = WV::N, M = WV::M, BS = 2 * M;
   const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
-  const int tl = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tl >= Timg) return;
+  const int tl0 = blockIdx.x * blockDim.x + threadIdx.x;
   const int h = blockIdx.y, n = blockIdx.z;
+  const bool active = tl0 < Timg;
+  if (!STATS && !active) return;
+  const int tl = active ? tl0 : 0;   // STATS: idle lanes of the last block recompute tile 0 (stores and sums masked) and
+                                     // take part in the block reduction
   const int ty = tl / TW, tx = tl - ty * TW;
   const int W = 2 * Wlo;
   const long xi_stride = 4L * Chi * T;
@@ -255,11 +261,27 @@ __global__ __launch_bounds__(256) void wino_in_t_kernel(const float* __restrict_
       o[r][c] += a;
     }
   float* __restrict__ out = hi + ((long)(n * Chi + h) * (2 * Hlo) + BS * ty) * W + BS * tx;
+  double s1 = 0.0, s2 = 0.0;
 #pragma unroll
   for (int r = 0; r < BS; ++r)
 #pragma unroll
-    for (int c4 = 0; c4 < BS; c4 += 4)
-      *reinterpret_cast<float4*>(out + (long)r * W + c4) = make_float4(o[r][c4], o[r][c4 + 1], o[r][c4 + 2], o[r][c4 + 3]);
+    for (int c4 = 0; c4 < BS; c4 += 4) {
+      if (active) *reinterpret_cast<float4*>(out + (long)r * W + c4) = make_float4(o[r][c4], o[r][c4 + 1], o[r][c4 + 2], o[r][c4 + 3]);
+      if (STATS && active) {
+        s1 += (double)((o[r][c4] + o[r][c4 + 1]) + (o[r][c4 + 2] + o[r][c4 + 3]));
+        s2 += (double)(fmaf(o[r][c4], o[r][c4], o[r][c4 + 1] * o[r][c4 + 1]) + fmaf(o[r][c4 + 2], o[r][c4 + 2], o[r][c4 + 3] * o[r][c4 + 3]));
+      }
+    }
+  if constexpr (STATS) {
+    __shared__ double sm[16];
+    const double r1 = block_sum(s1, sm);
+    const double r2 = block_sum(s2, sm);
+    if (threadIdx.x == 0) {
+      const long split = (long)n * gridDim.x + blockIdx.x;
+      part[(split * Chi + h) * 2 + 0] = r1;
+      part[(split * Chi + h) * 2 + 1] = r2;
+    }
+  }
 }
 
 // M[N*N][Clo][T] -> lo (N,Clo,Hlo,Wlo):  Y = A^T M A
@@ -449,8 +471,16 @@ int wino_in(int variant, const float* hi, float* V, int NB, int Chi, int Hlo, in
 int wino_in_t(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
   const int M = variant ? 4 : 2;
   const long T = (long)NB * (Hlo / M) * (Wlo / M);
-  WFAE_WINO_DISPATCH(wino_in_t_kernel, tile_grid(NB, Chi, Hlo, Wlo, M), dV, hi, Chi, Hlo, Wlo, T);
+  WFAE_WINO_DISPATCH(wino_in_t_kernel, tile_grid(NB, Chi, Hlo, Wlo, M), dV, hi, Chi, Hlo, Wlo, T, (double*)nullptr);
   return check_launch("wino_in_t");
+}
+int wino_in_t_stats(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, double* part, hipStream_t st) {
+  const int M = variant ? 4 : 2;
+  const long T = (long)NB * (Hlo / M) * (Wlo / M);
+  const dim3 grid = tile_grid(NB, Chi, Hlo, Wlo, M);
+  if (variant == 0) hipLaunchKernelGGL((wino_in_t_kernel<W22, true>), grid, dim3(256), 0, st, dV, hi, Chi, Hlo, Wlo, T, part);
+  else hipLaunchKernelGGL((wino_in_t_kernel<W42, true>), grid, dim3(256), 0, st, dV, hi, Chi, Hlo, Wlo, T, part);
+  return check_launch("wino_in_t_stats");
 }
 int wino_out(int variant, const float* Mx, float* lo, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
   const int M = variant ? 4 : 2;

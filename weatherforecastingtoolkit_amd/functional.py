@@ -40,14 +40,14 @@ _overlap = False
 _side = {}
 
 
-# BatchNorm statistics of 1x1-convolution outputs reduced in the GEMM epilogue instead of by a pass over the tensor
-# (WFAE_STAT_FUSION=1).  OFF by default: the fused sums are as accurate as the separate pass (both within 1e-7 of fp64,
-# tools/debug_stats.py) but not correctly ROUNDED — the separate pass accumulates in fp64 and, like torch's CPU
-# BatchNorm, returns the correctly rounded mean, so its statistics agree with the reference's bit for bit in most
-# channels.  A 1-ulp difference of a channel mean is a coherent perturbation of that whole channel, and at B = 1 the
-# 40-layer batch-statistics network with an L1 loss amplifies it: gradient norms moved from 5e-6 (median) / 9e-5 (max)
-# of the reference's to 2.7e-4 / 4.2e-3 (tools/debug_gradnorm.py), for 0.3-1.5 % of step time.  Parity first.
-STAT_FUSION = os.environ.get("WFAE_STAT_FUSION", "0") == "1"
+# BatchNorm statistics of 1x1-convolution outputs reduced in the GEMM epilogue instead of by a pass over the tensor.
+# Round 1 built this with fp32 partial sums (four DPP adds per 64-column wave row) and left it off: the fp32 partials
+# are as accurate as the separate pass but not ROUNDED like it, and a 1-ulp difference of a channel mean was enough to
+# push a near-tie pixel of the L1 loss across its kink.  The partials are now reduced in fp64 from
+# fp32 sums of four — the arithmetic of the separate pass (chan_reduce_kernel) — so the statistics are reproduced to
+# fp64 rounding (2e-7 asserted in test_conv1x1_fwd_stats_epilogue).  WFAE_STAT_FUSION=0: separate passes.
+STAT_FUSION = os.environ.get("WFAE_STAT_FUSION", "1") == "1"
+
 
 # BatchNorm-apply + GELU of a Bottleneck's FIRST BatchNorm (the C-channel residual stream: 70 % of the BN/GELU bytes)
 # inside the operand loaders of the two GEMMs that consume it (forward C -> C/4 convolution, its weight gradient):
@@ -292,12 +292,16 @@ class UpUnitFn(Function):
         training = _use_batch_stats(bn)
         pl = ops.wino_plan(x.shape[0], w.shape[1], w.shape[0], x.shape[2], x.shape[3])
         U = Mt = None
+        sp = None
         if pl is not None:
             U, Mt = ops.wino_weights(w, pl), ops.wino_out_t(x, pl)
-            t = ops.wino_up(U, Mt, pl)
+            if training and PRODUCER_STATS:
+                t, sp = ops.wino_up(U, Mt, pl, stats=True)
+            else:
+                t = ops.wino_up(U, Mt, pl)
         else:
             t = ops.conv4x4s2_up(x, w)
-        st = _bn_stats(t, bn, training)
+        st = _bn_stats_rows(sp, t, bn, training)
         if training and PRODUCER_STATS:
             a, bn._out_stats = ops.bn_act_fwd_stats(t, st, 1)
         else:
@@ -549,7 +553,9 @@ class BottleneckFn(Function):
         """`x_stats`: the BatchNorm sums of x if the kernel that produced x already reduced them (the previous
         Bottleneck's last 1x1 convolution); `mod._out_stats` receives those of y when `mod.emit_stats` is set.  In
         training mode the statistics of the two 1x1 outputs (t1 here, y for the next block) ride in the GEMM
-        epilogues instead of costing a pass over the tensor each — when STAT_FUSION is on (default off, see above)."""
+        epilogues (fp64 partial sums, STAT_FUSION) instead of costing a pass over the tensor each; the first and — for
+        C <= 128 — the third BatchNorm + GELU are applied inside the loaders of the GEMMs that consume them
+        (FUSE_A1 / FUSE_A3), so a1 / a3 are neither written nor saved."""
         xc = _c(x)
         if xc is not x:
             x_stats = None
@@ -558,11 +564,11 @@ class BottleneckFn(Function):
         groups = mod.f[5].groups
         training = _use_batch_stats(bn1)
         fuse = training and STAT_FUSION
+        emit = fuse and getattr(mod, "emit_stats", False)
         st1 = _bn_stats_rows(x_stats if (fuse or isinstance(x_stats, ops.StatParts)) else None, x, bn1, training)
-        fuse_a1 = FUSE_A1 and not fuse and x.shape[1] <= FUSE_A1_MAXC and ops.conv1x1_bnact_supported(x, w1.shape[0])
-        if fuse_a1:
-            a1, sr2 = None, None
-            t1 = ops.conv1x1_fwd_bnact(x, st1, w1)
+        if FUSE_A1 and x.shape[1] <= FUSE_A1_MAXC and ops.conv1x1_bnact_supported(x, w1.shape[0]):
+            a1 = None
+            t1, sr2 = ops.conv1x1_fwd_bnact(x, st1, w1, stats=True) if fuse else (ops.conv1x1_fwd_bnact(x, st1, w1), None)
         else:
             a1 = ops.bn_act_fwd(x, st1, 1)
             t1, sr2 = ops.conv1x1_fwd_stats(a1, w1) if fuse else (ops.conv1x1_fwd(a1, w1), None)
@@ -570,15 +576,13 @@ class BottleneckFn(Function):
         a2 = ops.bn_act_fwd(t1, st2, 1)
         t2 = _g3_fwd(a2, wg, groups)
         st3 = _bn_stats(t2, bn3, training)
-        if FUSE_A3 and not fuse and w3.shape[0] <= FUSE_A3_MAXC and ops.conv1x1_bnact_supported(t2, w3.shape[0]):
+        if FUSE_A3 and w3.shape[0] <= FUSE_A3_MAXC and ops.conv1x1_bnact_supported(t2, w3.shape[0]):
             a3 = None
-            y, mod._out_stats = ops.conv1x1_fwd_bnact(t2, st3, w3, None, x), None
+            y, mod._out_stats = ops.conv1x1_fwd_bnact(t2, st3, w3, None, x, stats=True) if emit else \
+                (ops.conv1x1_fwd_bnact(t2, st3, w3, None, x), None)
         else:
             a3 = ops.bn_act_fwd(t2, st3, 1)
-            if fuse and getattr(mod, "emit_stats", False):
-                y, mod._out_stats = ops.conv1x1_fwd_stats(a3, w3, None, x)
-            else:
-                y, mod._out_stats = ops.conv1x1_fwd(a3, w3, None, x), None
+            y, mod._out_stats = ops.conv1x1_fwd_stats(a3, w3, None, x) if emit else (ops.conv1x1_fwd(a3, w3, None, x), None)
         ctx.save_for_backward(x, _opt(a1), t1, a2, t2, _opt(a3), g1, w1, g2, wg, g3, w3,
                               st1.mean, st1.invstd, st1.scale, st1.shift,
                               st2.mean, st2.invstd, st2.scale, st2.shift,

@@ -92,7 +92,7 @@ def conv1x1_fwd(x, w, bias=None, res=None, res_broadcast=False):
 
 
 class StatRows:
-    """partial BatchNorm sums written by a producer epilogue: `part` = sum[rows][C] ++ sumsq[rows][C]"""
+    """partial BatchNorm sums written by a GEMM epilogue: `part` (float64) = sum[rows][C] ++ sumsq[rows][C]"""
     __slots__ = ("part", "rows")
 
     def __init__(self, part, rows):
@@ -107,6 +107,11 @@ class StatParts:
         self.part, self.splits = part, splits
 
 
+def _stat_rows_buffer(nb, hw, cout, device):
+    cap = 4 * ((nb * hw + 127) // 128) * cout
+    return torch.empty(cap, dtype=torch.float64, device=device), cap
+
+
 def conv1x1_fwd_stats(x, w, bias=None, res=None):
     """conv1x1_fwd whose epilogue also reduces the per-channel sum / sum of squares of y (for the BatchNorm that
     follows).  -> (y, StatRows | None); None = this shape is not served, run bn_stats_train on y."""
@@ -115,12 +120,11 @@ def conv1x1_fwd_stats(x, w, bias=None, res=None):
     nb, cin, h, wd = x.shape
     cout = w.shape[0]
     y = torch.empty((nb, cout, h, wd), dtype=x.dtype, device=x.device)
-    cap = 4 * ((nb * h * wd + 127) // 128) * cout
-    part = torch.empty(cap, dtype=torch.float32, device=x.device)
+    part, cap = _stat_rows_buffer(nb, h * wd, cout, x.device)
     rows = ctypes.c_int(0)
     _call("wfae_conv1x1_fwd_stats", 2 * nb * h * wd * cin * cout,
           4 * (nb * h * wd * (cin + cout) + cin * cout) + (0 if res is None else 4 * nb * h * wd * cout),
-          _p(x), _p(w), _p(bias), _p(res), cout * h * wd, _p(y), nb, cin, cout, h * wd, _p(part), cap,
+          _p(x), _p(w), _p(bias), _p(res), cout * h * wd, _p(y), nb, cin, cout, h * wd, part.data_ptr(), cap,
           ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream(), label="wfae_conv1x1_fwd")
     return y, (StatRows(part, rows.value) if rows.value > 0 else None)
 
@@ -132,17 +136,26 @@ def conv1x1_bnact_supported(x, cout):
     return (h * wd) % 4 == 0 and h * wd >= 16 and cin % 4 == 0 and (cout % 4 == 0 or not swapped)
 
 
-def conv1x1_fwd_bnact(x, st, w, bias=None, res=None):
+def conv1x1_fwd_bnact(x, st, w, bias=None, res=None, stats=False):
     """conv1x1_fwd(bn_act_fwd(x, st, GELU), w): the activated tensor is rebuilt in the GEMM's operand loader and never
-    written (reference chain BN -> GELU -> Conv2d 1x1, pipeline/models/ae_64x8x8_lin.py:14-15)"""
+    written (reference chain BN -> GELU -> Conv2d 1x1, pipeline/models/ae_64x8x8_lin.py:14-15).  stats=True: the
+    epilogue also reduces the BatchNorm sums of y -> (y, StatRows | None)"""
+    import ctypes
     _chk(x, w, bias, res)
     nb, cin, h, wd = x.shape
     cout = w.shape[0]
     y = torch.empty((nb, cout, h, wd), dtype=x.dtype, device=x.device)
-    _call("wfae_conv1x1_fwd_bnact", 2 * nb * h * wd * cin * cout,
-          4 * (nb * h * wd * (cin + cout) + cin * cout) + (0 if res is None else 4 * nb * h * wd * cout),
-          _p(x), _p(st.scale), _p(st.shift), _p(w), _p(bias), _p(res), cout * h * wd, _p(y), nb, cin, cout, h * wd, _stream())
-    return y
+    fl = 2 * nb * h * wd * cin * cout
+    by = 4 * (nb * h * wd * (cin + cout) + cin * cout) + (0 if res is None else 4 * nb * h * wd * cout)
+    if not stats:
+        _call("wfae_conv1x1_fwd_bnact", fl, by, _p(x), _p(st.scale), _p(st.shift), _p(w), _p(bias), _p(res), cout * h * wd, _p(y),
+              nb, cin, cout, h * wd, None, 0, None, _stream())
+        return y
+    part, cap = _stat_rows_buffer(nb, h * wd, cout, x.device)
+    rows = ctypes.c_int(0)
+    _call("wfae_conv1x1_fwd_bnact", fl, by, _p(x), _p(st.scale), _p(st.shift), _p(w), _p(bias), _p(res), cout * h * wd, _p(y),
+          nb, cin, cout, h * wd, part.data_ptr(), cap, ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream())
+    return y, (StatRows(part, rows.value) if rows.value > 0 else None)
 
 
 def conv1x1_bwd_weight_bnact(dy, x, st, dw, accumulate=False):
@@ -347,13 +360,22 @@ def wino_down(U, V, pl, stats=False):
     return lo, StatParts(part, splits.value)
 
 
-def wino_up(U, Mt, pl):
-    """hi = In^T(U^T * Mt)"""
+def wino_up(U, Mt, pl, stats=False):
+    """hi = In^T(U^T * Mt); stats=True: -> (hi, StatParts of hi)"""
+    import ctypes
     dV = _buf(pl.nV, Mt)
     hi = torch.empty((pl.nb, pl.chi, 2 * pl.hlo, 2 * pl.wlo), dtype=torch.float32, device=Mt.device)
     _call("wfae_wino_gemm_up", pl.gemm_flops, 4 * (pl.nU + pl.nV + pl.nM), pl.variant, _p(U), _p(Mt), _p(dV), *pl.dims, _stream())
-    _call("wfae_wino_in_t", 0, 4 * (pl.nV + hi.numel()), pl.variant, _p(dV), _p(hi), pl.nb, pl.chi, pl.hlo, pl.wlo, _stream())
-    return hi
+    if not stats:
+        _call("wfae_wino_in_t", 0, 4 * (pl.nV + hi.numel()), pl.variant, _p(dV), _p(hi), pl.nb, pl.chi, pl.hlo, pl.wlo, _stream())
+        return hi
+    m = 4 if pl.variant else 2
+    cap = 2 * pl.chi * pl.nb * (((pl.hlo // m) * (pl.wlo // m) + 255) // 256)
+    part = torch.empty(cap, dtype=torch.float64, device=Mt.device)
+    splits = ctypes.c_int(0)
+    _call("wfae_wino_in_t_stats", 0, 4 * (pl.nV + hi.numel()), pl.variant, _p(dV), _p(hi), pl.nb, pl.chi, pl.hlo, pl.wlo,
+          part.data_ptr(), cap, ctypes.cast(ctypes.pointer(splits), ctypes.c_void_p), _stream(), label="wfae_wino_in_t")
+    return hi, StatParts(part, splits.value)
 
 
 def wino_wgrad(Mt, V, dw, pl, accumulate=False):
@@ -521,7 +543,7 @@ def bn_stats_from_rows(sr, shape, gamma, beta, running_mean, running_var, eps=1e
     nb, c, h, wd = shape
     st = BnStats(c, gamma.device)
     ws = workspace()
-    _call("wfae_bn_stats_from_rows", 0, 4 * sr.part.numel(), _p(sr.part), sr.rows, nb, c, h * wd, _p(gamma), _p(beta), eps,
+    _call("wfae_bn_stats_from_rows", 0, 8 * sr.part.numel(), sr.part.data_ptr(), sr.rows, nb, c, h * wd, _p(gamma), _p(beta), eps,
           momentum, _p(running_mean), _p(running_var), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
           ws.data_ptr(), ws.numel(), _stream(), label="wfae_bn_stats_train")
     return st

@@ -257,6 +257,34 @@ int wfae_wino_gemm_up(int variant, const float* U, const float* Mt, float* dV, i
 int wfae_wino_gemm_wgrad(int variant, const float* Mt, const float* V, float* dw, int NB, int Chi, int Clo, int Hlo,
                          int Wlo, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
 
+/* ---- The three Winograd-domain products on the bf16 matrix pipe at fp32 accuracy ("split" operands).
+ * v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate; v_mfma_f32_32x32x16_bf16 at 16x that.  An fp32 value is
+ * exactly h + m + l with three bf16 values (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)) and bf16 x bf16 is exact
+ * in fp32, so the six products ah bh, ah bm, am bh, ah bl, al bh, am bm accumulated in fp32 carry the fp32 product to
+ * 2^-23 relative — the error of the fp32 MFMA path (tests/test_kernels_gpu.py::test_split_gemm_matches_fp32_accuracy) at
+ * 16/6 of its rate.  A split operand is three planes of bf16 bit patterns (uint16_t), the h plane first, each plane
+ * the fp32 layout's element count long; the *_split transforms write them directly (6 bytes per element instead of 4),
+ * the GEMM outputs stay fp32 and go through wino_out / wino_in_t / the G^T dU G reduction unchanged.
+ *   wino_weights_split: U3 [3][xi][Clo][4Chi] and Ut3 [3][xi][4Chi][Clo] (the up product contracts over Clo)
+ *   wino_in_split / wino_out_t_split: V3 [3][xi][4Chi][T], Mt3 [3][xi][Clo][T]
+ * wfae_wino_split_supported: 1 when wfae_wino_sizes accepts the geometry and 4 Chi, Clo and T are multiples of 32.
+ * wfae_split_bf16x3 / wfae_split_gemm: the conversion and the batched product on their own (C[y] = A[y] B[y], A [M][K];
+ * b_kind 0: B [K][N], b_kind 1: B [N][K]; K % 32 == 0, N % 8 == 0 for b_kind 0; planes batches*M*K resp. batches*K*N
+ * elements apart). */
+int wfae_wino_split_supported(int variant, int NB, int Chi, int Clo, int Hlo, int Wlo);
+int wfae_wino_weights_split(int variant, const float* w, uint16_t* U3, uint16_t* Ut3, int Chi, int Clo, wfae_stream_t stream);
+int wfae_wino_in_split(int variant, const float* hi, uint16_t* V3, int NB, int Chi, int Hlo, int Wlo, wfae_stream_t stream);
+int wfae_wino_out_t_split(int variant, const float* lo, uint16_t* Mt3, int NB, int Clo, int Hlo, int Wlo, wfae_stream_t stream);
+int wfae_wino_gemm_down_split(int variant, const uint16_t* U3, const uint16_t* V3, float* M, int NB, int Chi, int Clo, int Hlo,
+                              int Wlo, wfae_stream_t stream);
+int wfae_wino_gemm_up_split(int variant, const uint16_t* Ut3, const uint16_t* Mt3, float* dV, int NB, int Chi, int Clo, int Hlo,
+                            int Wlo, wfae_stream_t stream);
+int wfae_wino_gemm_wgrad_split(int variant, const uint16_t* Mt3, const uint16_t* V3, float* dw, int NB, int Chi, int Clo,
+                               int Hlo, int Wlo, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
+int wfae_split_bf16x3(const float* x, uint16_t* planes, int64_t n, wfae_stream_t stream);
+int wfae_split_gemm(int b_kind, const uint16_t* A3, const uint16_t* B3, float* C, int M, int N, int K, int batches,
+                    wfae_stream_t stream);
+
 /* ---- 4x4 stride-1 convolution on the MFMA GEMM (PatchGAN layer 4: Conv2d(256, 512, 4, stride=1, padding=1,
  * bias=False), pipeline/models/autoencoderkl/losses/model.py:137).
  * fwd, transposed = 0: x (NB,Cin,H,W) -> y (NB,Cout,H+2pad-3,W+2pad-3);

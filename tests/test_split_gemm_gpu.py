@@ -1,0 +1,96 @@
+"""GPU: the split-operand GEMMs (csrc/splitgemm.hip) — fp32 values as three bf16 planes, six bf16 MFMA products with
+fp32 accumulation.  The claim under test is ACCURACY: the result is as close to the fp64 product as the fp32-MFMA
+kernels' (and torch's fp32 matmul), so the default fp32 path may run on the bf16 matrix pipe."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from weatherforecastingtoolkit_amd import ops as o
+    return o
+
+
+def _planes_to_f32(p3):
+    """(3, ...) int16 bf16 bit patterns -> three fp32 tensors"""
+    return [(p.to(torch.int32) << 16).view(torch.float32) for p in p3]
+
+
+def test_split_is_exact(ops, dev):
+    """x == h + m + l bit for bit, over 40 binades, both signs, including values whose bf16 rounding carries"""
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(1 << 20, generator=g) - 0.5) * torch.exp2(torch.randint(-20, 20, (1 << 20,), generator=g).float())
+    x[:4] = torch.tensor([0.0, 1.0, -1.0, 1.9999999])
+    x = x.to(dev)
+    h, m, l = _planes_to_f32(ops.split_bf16x3(x))
+    assert torch.equal((h + m) + l, x)
+    assert float((m.abs() > h.abs() * 2.0 ** -8).sum()) == 0 and float((l.abs() > h.abs() * 2.0 ** -16).sum()) == 0
+
+
+def _err(c, ref64, scale64):
+    return float(((c.double() - ref64).abs() / scale64).max())
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("y,m,n,k", [(1, 256, 128, 32), (3, 300, 200, 96), (2, 64, 136, 64), (1, 512, 384, 2048), (2, 40, 8, 32)])
+def test_split_gemm_matches_fp32_accuracy(ops, dev, kind, y, m, n, k):
+    """C = A B from split operands against fp64: the error (relative to sum |a||b|, the natural scale of a dot product)
+    is within 1.5x of torch's own fp32 matmul on the same data, at every tile tail (M, N not multiples of the 256 x 128
+    tile, several batches)"""
+    g = torch.Generator().manual_seed(1000 * kind + m + n + k)
+    a = (torch.randn(y, m, k, generator=g) * torch.exp2(torch.randint(-6, 6, (y, m, 1), generator=g).float())).to(dev)
+    b = torch.randn(y, k, n, generator=g).to(dev)
+    ref = a.double() @ b.double()
+    scale = a.double().abs() @ b.double().abs()
+    a3 = ops.split_bf16x3(a)
+    b3 = ops.split_bf16x3(b if kind == 0 else b.transpose(1, 2).contiguous())
+    c = ops.split_gemm(a3, b3, kind)
+    e_split, e_f32 = _err(c, ref, scale), _err(a @ b, ref, scale)
+    assert e_split <= 1.5 * e_f32 + 3e-8, (e_split, e_f32)
+    assert e_split < 4e-7
+
+
+@pytest.mark.parametrize("mode,nb,chi,clo,hlo,wlo", [("f42", 2, 64, 128, 16, 16), ("f42", 4, 32, 64, 16, 24), ("f22", 2, 16, 32, 16, 16),
+                                                      ("f42", 8, 256, 512, 24, 24), ("f22", 8, 8, 32, 4, 4)])
+def test_winograd_on_split_gemms_matches_fp32_mfma_accuracy(ops, dev, mode, nb, chi, clo, hlo, wlo):
+    """the three 4x4 stride-2 products through the split GEMMs: against an fp64 convolution their error is that of the
+    fp32-MFMA Winograd path (within 1.5x), and the split entry points are the ones that ran"""
+    g = torch.Generator().manual_seed(7)
+    hi = (torch.rand(nb, chi, 2 * hlo, 2 * wlo, generator=g) - 0.5).to(dev)
+    lo = (torch.rand(nb, clo, hlo, wlo, generator=g) - 0.5).to(dev)
+    w = ((torch.rand(clo, chi, 4, 4, generator=g) - 0.5) * 0.2).to(dev)
+    hr, wr = hi.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = F.conv2d(hr, wr, stride=2, padding=1)
+    ref.backward(lo.double())
+    res = {}
+    ops.set_winograd(mode)
+    try:
+        for split in (False, True):
+            ops.set_split_gemm(split)
+            pl = ops.wino_plan(nb, chi, clo, hlo, wlo)
+            assert pl is not None and pl.split == split
+            dw = torch.empty_like(w)
+            ops.conv4x4s2_wgrad(lo, hi, dw)
+            res[split] = (ops.conv4x4s2_down(hi, w), ops.conv4x4s2_up(lo, w), dw)
+    finally:
+        ops.set_winograd("auto")
+        ops.set_split_gemm(True)
+    for i, r64 in enumerate((ref, hr.grad, wr.grad)):
+        r64 = r64.detach()
+        rms = float(r64.pow(2).mean().sqrt())
+        e_f32 = float((res[False][i].double() - r64).abs().max()) / rms
+        e_split = float((res[True][i].double() - r64).abs().max()) / rms
+        assert e_split <= 1.5 * e_f32 + 1e-7, (i, e_split, e_f32)
+
+
+def test_split_gemm_refuses_unserved_shapes(ops, dev):
+    from weatherforecastingtoolkit_amd import _lib
+    a3 = torch.zeros(3, 1, 32, 48, dtype=torch.int16, device=dev)   # K = 48 is not a multiple of 32
+    b3 = torch.zeros(3, 1, 48, 64, dtype=torch.int16, device=dev)
+    with pytest.raises(_lib.WfaeError):
+        ops.split_gemm(a3, b3, 0)
+    assert _lib.load().wfae_wino_split_supported(1, 1, 256, 512, 8, 8) == 0    # T = 4 tiles
+    assert _lib.load().wfae_wino_split_supported(1, 32, 256, 512, 96, 96) == 1

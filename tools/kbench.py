@@ -72,6 +72,35 @@ def main():
                 report(f"conv4x4 {nm:5s} hi {chi}@{2 * hlo} lo {clo}@{hlo}", ms, fl, by)
                 acc("conv4_" + nm, ms)
             del hi, lo, w, dw
+    if "wino" in only:
+        # the Winograd pieces one by one, fp32 MFMA GEMMs against the split-operand bf16 GEMMs (splitgemm.hip)
+        for chi, clo, hlo in [(256, 512, S // 4), (512, 1024, S // 8), (1024, 1024, S // 16), (128, 256, S // 2)]:
+            hi, lo, w = rnd(B, chi, 2 * hlo, 2 * hlo), rnd(B, clo, hlo, hlo), rnd(clo, chi, 4, 4)
+            dw = torch.empty_like(w)
+            for split in (False, True):
+                ops.set_split_gemm(split)
+                pl = ops.wino_plan(B, chi, clo, hlo, hlo)
+                assert pl is not None and pl.split == split, (pl, split)
+                U, V, Mt = ops.wino_weights(w, pl), ops.wino_in(hi, pl), ops.wino_out_t(lo, pl)
+                eb = 6 if split else 4
+                tag = f"{'split' if split else 'fp32 '} hi {chi}@{2 * hlo} lo {clo}@{hlo} F{'42' if pl.variant else '22'}"
+                for nm, fn, by in [("weights", lambda: ops.wino_weights(w, pl), 4 * w.numel() + (2 if split else 1) * eb * pl.nU),
+                                   ("in", lambda: ops.wino_in(hi, pl), 4 * hi.numel() + eb * pl.nV),
+                                   ("out_t", lambda: ops.wino_out_t(lo, pl), 4 * lo.numel() + eb * pl.nM)]:
+                    ms = timeit(fn, R)
+                    report(f"wino {nm:8s} {tag}", ms, 0, by)
+                    acc(f"wino_{nm}_{'split' if split else 'fp32'}", ms)
+                ops.profile_start()
+                for _ in range(R):
+                    ops.wino_down(U, V, pl); ops.wino_up(U, Mt, pl); ops.wino_wgrad(Mt, V, dw, pl)
+                rec = ops.profile_stop()
+                for nm in ("wfae_wino_gemm_down", "wfae_wino_gemm_up", "wfae_wino_gemm_wgrad"):
+                    ms = rec[nm][1] / rec[nm][0]
+                    report(f"{nm[5:]:19s} {tag}", ms, pl.gemm_flops, eb * (pl.nU + pl.nV) + 4 * pl.nM)
+                    acc(f"{nm[5:]}_{'split' if split else 'fp32'}", ms)
+                del U, V, Mt
+            ops.set_split_gemm(True)
+            del hi, lo, w, dw
     stages = [(256, S // 2), (512, S // 4), (1024, S // 8), (1024, S // 16), (1024, S // 8), (512, S // 4),
               (256, S // 2), (128, S)]
     if "conv1" in only:

@@ -99,6 +99,19 @@ __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// x == h + m + l exactly, each a bf16 (round to nearest even; both residuals are exact fp32 differences): the operand form
+// of the split GEMMs (splitgemm.hip)
+__device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+  const __bf16 bh = (__bf16)x;
+  const float r1 = x - (float)bh;
+  const __bf16 bm = (__bf16)r1;
+  const float r2 = r1 - (float)bm;
+  const __bf16 bl = (__bf16)r2;
+  h = __builtin_bit_cast(unsigned short, bh);
+  m = __builtin_bit_cast(unsigned short, bm);
+  l = __builtin_bit_cast(unsigned short, bl);
+}
+
 // Conv2d(C, 1, 3, padding=1): the decoder's full-resolution output convolution (c1conv.hip)
 int c1conv3_fwd(const float* x, const float* w, const float* bias, float* y, int NB, int C, int H, int W, hipStream_t st);
 int c1_wgrad_mfma(int flip, const float* big, const float* small, float* dw, int NB, int C, int H, int W, int accumulate,
@@ -117,6 +130,13 @@ int wino_out_stats(int variant, const float* M, float* lo, int NB, int Clo, int 
 int wino_out_stat_splits(int variant, int NB, int Hlo, int Wlo);   // also the split count of wino_in_t_stats
 int wino_in_t_stats(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, double* part, hipStream_t st);
 int wino_weights(int variant, const float* w, float* U, int Clo, int Chi, hipStream_t st);                   // -> U[xi][Clo][4Chi]
+// bf16-plane forms of the GEMM operands (splitgemm.hip) and the GEMM itself
+int wino_in_split(int variant, const float* hi, unsigned short* V3, int NB, int Chi, int Hlo, int Wlo, hipStream_t st);
+int wino_out_t_split(int variant, const float* lo, unsigned short* Mt3, int NB, int Clo, int Hlo, int Wlo, hipStream_t st);
+int wino_weights_split(int variant, const float* w, unsigned short* U3, unsigned short* Ut3, int Clo, int Chi, hipStream_t st);
+int split_gemm(int kind, const unsigned short* A, const unsigned short* B, float* C, int M, int N, int K, long a_plane,
+               long b_plane, long a_y, long b_y, long c_y, int batches, int k_per_split, int splits, long c_split,
+               hipStream_t st, const char* what);
 int wino_weights_t(int variant, const float* dU, float* dw, int Clo, int Chi, int beta, hipStream_t st);     // G^T dU G
 
 // out = (beta ? out : 0) + sum over `splits` partial slabs of MN floats (+ bias_n[i % N]); fixed order.

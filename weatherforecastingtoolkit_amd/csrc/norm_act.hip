@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 
 // finalize for producer-side partial sums part[(split * C + c) * 2 + {0,1}]: one 64-lane block per channel adds the
 // splits in a fixed order (lane-strided, then a wave reduction), then the arithmetic of bn_finalize_kernel
-__global__ __launch_bounds__(64) void bn_finalize_parts_kernel(const double* __restrict__ part, int splits, long count, int C,
+__global__ __launch_bounds__(64) void bn_finalize_parts_kernel(const double* __restrict__ part, int splits, long ss, long cs,
+                                                               long count, int C,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float eps, float momentum, float* __restrict__ running_mean,
                                                                float* __restrict__ running_var, float* __restrict__ save_mean,
@@ -256,8 +257,8 @@ __global__ __launch_bounds__(64) void bn_finalize_parts_kernel(const double* __r
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
   for (int s = threadIdx.x; s < splits; s += 64) {
-    s1 += part[((long)s * C + c) * 2 + 0];
-    s2 += part[((long)s * C + c) * 2 + 1];
+    s1 += part[((long)s * ss + (long)c * cs) * 2 + 0];
+    s2 += part[((long)s * ss + (long)c * cs) * 2 + 1];
   }
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
@@ -692,9 +693,9 @@ int wfae_bn_stats_from_rows(const double* stat_part, int rows, int NB, int C, in
                      stat_part + (long)rows * C, (double*)ws, rows, C, splits);
   int rc = check_launch("stat_rows_reduce");
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, splits,
-                     (long)NB * HW, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
-                     save_invstd, scale, shift);
+  hipLaunchKernelGGL(bn_finalize_parts_kernel, dim3(C), dim3(64), 0, st, (const double*)ws, splits, 1l, (long)splits,
+                     (long)NB * HW, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale,
+                     shift);
   return check_launch("bn_finalize");
 }
 
@@ -760,8 +761,8 @@ int wfae_bn_stats_from_parts(const double* part, int splits, int NB, int C, int 
   WFAE_REQUIRE(part && gamma && beta && save_mean && save_invstd && scale && shift, WFAE_ERR_NULL_POINTER,
                "bn_stats_from_parts: null pointer");
   WFAE_REQUIRE(splits > 0 && NB > 0 && C > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "bn_stats_from_parts: bad shape");
-  hipLaunchKernelGGL(bn_finalize_parts_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, part, splits, (long)NB * HW, C, gamma,
-                     beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
+  hipLaunchKernelGGL(bn_finalize_parts_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, part, splits, (long)C, 1l, (long)NB * HW,
+                     C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
   return check_launch("bn_finalize_parts");
 }
 

@@ -63,9 +63,25 @@ __device__ __forceinline__ void sandwich(const float (&in)[CA][CA], float (&out)
     }
 }
 
+// operand store of the transforms that feed GEMMs: fp32, or (SPLIT) the three bf16 planes h + m + l == v of
+// splitgemm.hip, `plane` elements apart
+template <bool SPLIT>
+__device__ __forceinline__ void put_operand(void* __restrict__ base, long idx, long plane, float v) {
+  if constexpr (!SPLIT) {
+    static_cast<float*>(base)[idx] = v;
+  } else {
+    unsigned short h, m, l;
+    split3(v, h, m, l);
+    unsigned short* __restrict__ o = static_cast<unsigned short*>(base) + idx;
+    o[0] = h;
+    o[plane] = m;
+    o[2 * plane] = l;
+  }
+}
+
 // hi (N,Chi,2Hlo,2Wlo) -> V[N*N][4Chi][T]
-template <typename WV>
-__global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ hi, float* __restrict__ V, int Chi,
+template <typename WV, bool SPLIT = false>
+__global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ hi, void* __restrict__ V, int Chi,
                                                       int Hlo, int Wlo, long T) {
   constexpr int N = WV::N, M = WV::M, PSZ = 2 * N;
   const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
@@ -113,11 +129,11 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < N; ++j) d[i][j] = rowbuf[i][2 * j + q];
       sandwich<N, N>(d, v, [](int a, int i) { return WV::BT[a][i]; });
-      float* __restrict__ dst = V + ((long)(p * 2 + q) * Chi + h) * T + t;
+      const long dst = ((long)(p * 2 + q) * Chi + h) * T + t;
 #pragma unroll
       for (int u = 0; u < N; ++u)
 #pragma unroll
-        for (int w = 0; w < N; ++w) dst[(long)(u * N + w) * xi_stride] = v[u][w];
+        for (int w = 0; w < N; ++w) put_operand<SPLIT>(V, dst + (long)(u * N + w) * xi_stride, (long)(N * N) * xi_stride, v[u][w]);
     }
   }
 }
@@ -349,8 +365,8 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 }
 
 // adjoint of wino_out: lo (N,Clo,Hlo,Wlo) -> Mt[N*N][Clo][T]:  Mt = A Y A^T
-template <typename WV>
-__global__ __launch_bounds__(256) void wino_out_t_kernel(const float* __restrict__ lo, float* __restrict__ Mt, int Clo,
+template <typename WV, bool SPLIT = false>
+__global__ __launch_bounds__(256) void wino_out_t_kernel(const float* __restrict__ lo, void* __restrict__ Mt, int Clo,
                                                          int Hlo, int Wlo, long T) {
   constexpr int N = WV::N, M = WV::M;
   const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
@@ -372,21 +388,24 @@ __global__ __launch_bounds__(256) void wino_out_t_kernel(const float* __restrict
   }
   sandwich<N, M>(y, m, [](int u, int a) { return WV::AT[a][u]; });   // A = (A^T)^T
   const long xi_stride = (long)Clo * T;
-  float* __restrict__ dst = Mt + (long)l * T + (long)n * Timg + tl;
+  const long dst = (long)l * T + (long)n * Timg + tl;
 #pragma unroll
   for (int u = 0; u < N; ++u)
 #pragma unroll
-    for (int v = 0; v < N; ++v) dst[(long)(u * N + v) * xi_stride] = m[u][v];
+    for (int v = 0; v < N; ++v) put_operand<SPLIT>(Mt, dst + (long)(u * N + v) * xi_stride, (long)(N * N) * xi_stride, m[u][v]);
 }
 
 // w (Clo,Chi,4,4) -> U[N*N][Clo][4Chi]:  U = G g G^T per phase, g[a][b] = w[2a+p][2b+q]
-template <typename WV>
-__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int Clo,
+// SPLIT: bf16 planes; TRANSPOSED: U^T[N*N][4Chi][Clo] (the A operand of the up GEMM with K = Clo contiguous), consecutive
+// threads own consecutive lo channels
+template <typename WV, bool SPLIT = false, bool TRANSPOSED = false>
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, void* __restrict__ U, int Clo,
                                                            int Chi) {
   constexpr int N = WV::N;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)Clo * Chi) return;
-  const int h = (int)(i % Chi), l = (int)(i / Chi);
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i0 >= (long)Clo * Chi) return;
+  const int h = TRANSPOSED ? (int)(i0 / Clo) : (int)(i0 % Chi), l = TRANSPOSED ? (int)(i0 % Clo) : (int)(i0 / Chi);
+  const long i = (long)l * Chi + h;
   float g[16];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -404,11 +423,12 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
 #pragma unroll
         for (int b = 0; b < 2; ++b) gg[a][b] = g[(2 * a + p) * 4 + 2 * b + q];
       sandwich<N, 2>(gg, u, [](int a, int i2) { return WV::G[a][i2]; });
-      float* __restrict__ dst = U + (long)l * K4 + (long)(p * 2 + q) * Chi + h;
+      const long c = (long)(p * 2 + q) * Chi + h;
+      const long dst = TRANSPOSED ? c * Clo + l : (long)l * K4 + c;
 #pragma unroll
       for (int a = 0; a < N; ++a)
 #pragma unroll
-        for (int b = 0; b < N; ++b) dst[(long)(a * N + b) * xi_stride] = u[a][b];
+        for (int b = 0; b < N; ++b) put_operand<SPLIT>(U, dst + (long)(a * N + b) * xi_stride, (long)(N * N) * xi_stride, u[a][b]);
     }
 }
 
@@ -465,8 +485,37 @@ namespace wfae {
 int wino_in(int variant, const float* hi, float* V, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
   const int M = variant ? 4 : 2;
   const long T = (long)NB * (Hlo / M) * (Wlo / M);
-  WFAE_WINO_DISPATCH(wino_in_kernel, tile_grid(NB, Chi, Hlo, Wlo, M), hi, V, Chi, Hlo, Wlo, T);
+  WFAE_WINO_DISPATCH(wino_in_kernel, tile_grid(NB, Chi, Hlo, Wlo, M), hi, (void*)V, Chi, Hlo, Wlo, T);
   return check_launch("wino_in");
+}
+// the *_split forms write the three bf16 planes of splitgemm.hip (plane stride = the operand's element count)
+int wino_in_split(int variant, const float* hi, unsigned short* V3, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
+  const int M = variant ? 4 : 2;
+  const long T = (long)NB * (Hlo / M) * (Wlo / M);
+  const dim3 grid = tile_grid(NB, Chi, Hlo, Wlo, M);
+  if (variant == 0) hipLaunchKernelGGL((wino_in_kernel<W22, true>), grid, dim3(256), 0, st, hi, (void*)V3, Chi, Hlo, Wlo, T);
+  else hipLaunchKernelGGL((wino_in_kernel<W42, true>), grid, dim3(256), 0, st, hi, (void*)V3, Chi, Hlo, Wlo, T);
+  return check_launch("wino_in_split");
+}
+int wino_out_t_split(int variant, const float* lo, unsigned short* Mt3, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
+  const int M = variant ? 4 : 2;
+  const long T = (long)NB * (Hlo / M) * (Wlo / M);
+  const dim3 grid = tile_grid(NB, Clo, Hlo, Wlo, M);
+  if (variant == 0) hipLaunchKernelGGL((wino_out_t_kernel<W22, true>), grid, dim3(256), 0, st, lo, (void*)Mt3, Clo, Hlo, Wlo, T);
+  else hipLaunchKernelGGL((wino_out_t_kernel<W42, true>), grid, dim3(256), 0, st, lo, (void*)Mt3, Clo, Hlo, Wlo, T);
+  return check_launch("wino_out_t_split");
+}
+// U3 [3][N*N][Clo][4Chi] and its transpose Ut3 [3][N*N][4Chi][Clo]
+int wino_weights_split(int variant, const float* w, unsigned short* U3, unsigned short* Ut3, int Clo, int Chi, hipStream_t st) {
+  const dim3 grid(cdiv((long)Clo * Chi, 256));
+  if (variant == 0) {
+    hipLaunchKernelGGL((wino_weights_kernel<W22, true, false>), grid, dim3(256), 0, st, w, (void*)U3, Clo, Chi);
+    hipLaunchKernelGGL((wino_weights_kernel<W22, true, true>), grid, dim3(256), 0, st, w, (void*)Ut3, Clo, Chi);
+  } else {
+    hipLaunchKernelGGL((wino_weights_kernel<W42, true, false>), grid, dim3(256), 0, st, w, (void*)U3, Clo, Chi);
+    hipLaunchKernelGGL((wino_weights_kernel<W42, true, true>), grid, dim3(256), 0, st, w, (void*)Ut3, Clo, Chi);
+  }
+  return check_launch("wino_weights_split");
 }
 int wino_in_t(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
   const int M = variant ? 4 : 2;
@@ -503,11 +552,11 @@ int wino_out_stat_splits(int variant, int NB, int Hlo, int Wlo) {
 int wino_out_t(int variant, const float* lo, float* Mt, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
   const int M = variant ? 4 : 2;
   const long T = (long)NB * (Hlo / M) * (Wlo / M);
-  WFAE_WINO_DISPATCH(wino_out_t_kernel, tile_grid(NB, Clo, Hlo, Wlo, M), lo, Mt, Clo, Hlo, Wlo, T);
+  WFAE_WINO_DISPATCH(wino_out_t_kernel, tile_grid(NB, Clo, Hlo, Wlo, M), lo, (void*)Mt, Clo, Hlo, Wlo, T);
   return check_launch("wino_out_t");
 }
 int wino_weights(int variant, const float* w, float* U, int Clo, int Chi, hipStream_t st) {
-  WFAE_WINO_DISPATCH(wino_weights_kernel, dim3(cdiv((long)Clo * Chi, 256)), w, U, Clo, Chi);
+  WFAE_WINO_DISPATCH(wino_weights_kernel, dim3(cdiv((long)Clo * Chi, 256)), w, (void*)U, Clo, Chi);
   return check_launch("wino_weights");
 }
 int wino_weights_t(int variant, const float* dU, float* dw, int Clo, int Chi, int beta, hipStream_t st) {

@@ -50,7 +50,19 @@ BYTES_PER_FRAME_384 = 7.365e9   # fused-minimum HBM traffic, SURVEY.md §8(d)
 PEAK_FP32 = 157.3e12            # MI355X_MICROARCH.md: fp32 vector = fp32 matrix
 PEAK_HBM = 8.0e12
 
+PEAK_BF16 = 2500.0e12           # dense bf16 MFMA (MI355X_MICROARCH.md)
+
+# labels whose launches run ONE kernel are ranked together (rocprofv3's kernel-trace stats rank by kernel): with the split
+# operands the down and up products of the Winograd layers are the same sgemm3_kernel<B = K x N>
+KERNEL_GROUP_SPLIT = {"wfae_wino_gemm_down": "split_gemm[B=KxN]", "wfae_wino_gemm_up": "split_gemm[B=KxN]",
+                      "wfae_wino_gemm_wgrad": "split_gemm[B=NxK]"}
+
 KERNEL_OF = {
+    "split_gemm[B=KxN]": "sgemm3_kernel<0> (Winograd-domain GEMMs M_xi = U_xi V_xi and dV_xi = U_xi^T Mt_xi of the 4x4 s2 "
+                         "layers, 25 per launch: fp32 operands as three bf16 planes, six v_mfma_f32_32x32x16_bf16 products "
+                         "per fp32 product, fp32 accumulation — csrc/splitgemm.hip)",
+    "split_gemm[B=NxK]": "sgemm3_kernel<1> (Winograd-domain weight-gradient GEMMs dU_xi = Mt_xi V_xi^T, split-K, the same "
+                         "split-operand bf16 MFMA scheme)",
     "wfae_bn_act_bwd[dx]": "bn_act_bwd_dx_kernel<GELU> (BatchNorm + GELU backward: dx from dy, x (+ residual-branch gradient), "
                            "HBM-bound streaming kernel)",
     "wfae_bn_act_bwd[reduce]": "bn_act_bwd_reduce_kernel<GELU> (per-channel sums of dU and dU*xhat, fp64 accumulation)",
@@ -134,6 +146,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run weight gradients on the main stream")
+    ap.add_argument("--fp32-mfma-only", action="store_true",
+                    help="keep the Winograd-domain GEMMs on v_mfma_f32_32x32x2_f32 (no split bf16 operands)")
     ap.add_argument("--precision", choices=["highest", "medium"], default="highest",
                     help="'medium' = bf16 MFMA operands (BASELINE config 5's arithmetic; NOT the headline "
                          "configuration — the line is then labelled dtype bf16)")
@@ -157,6 +171,8 @@ def main():
 
     Fn.set_wgrad_overlap(not args.no_overlap)
     ops.set_float32_matmul_precision(args.precision)
+    if args.fp32_mfma_only:
+        ops.set_split_gemm(False)
     torch.manual_seed(0)  # identical random-init weights on every rank (then broadcast anyway)
     net = PosAwareAE_TF(img_size=args.img_size).to(dev).train()
     opt = FusedAdamW(net.parameters(), lr=5e-5, betas=(0.9, 0.999), weight_decay=1e-4)
@@ -214,6 +230,18 @@ def main():
             step(time_exchange=True)
         prof = ops.profile_stop()
         Fn.set_wgrad_overlap(not args.no_overlap)
+    # the same step with every GEMM on the fp32 MFMA instruction (reported beside the headline, never as `value`)
+    strict = None
+    if args.precision == "highest" and ops.split_gemm_enabled():
+        ops.set_split_gemm(False)
+        step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        strict = (time.perf_counter() - t1) / args.steps
+        ops.set_split_gemm(True)
     ranks_seen, xchg_ms = 1, None
     if world > 1:
         ones = torch.ones(1, device=dev)
@@ -241,13 +269,23 @@ def main():
                                    f"{'fp32' if args.precision == 'highest' else 'bf16 MFMA operands / fp32 tensors'}, "
                                    "fwd + L1 + bwd + AdamW + cosine-warmup LR",
                        "batch_per_gpu": B, "global_batch": B * world, "img_size": S,
-                       "parallelism": f"dp{world}", "params": sum(p.numel() for p in net.parameters())},
+                       "parallelism": f"dp{world}", "params": sum(p.numel() for p in net.parameters()),
+                       "matmul": ("fp32 tensors, fp32 accumulation; the Winograd-domain GEMMs of the 4x4 stride-2 layers "
+                                  "multiply on the bf16 matrix pipe with every fp32 operand carried EXACTLY as three bf16 "
+                                  "planes (six products per fp32 product: error vs fp64 that of the fp32 MFMA kernels, "
+                                  "tests/test_split_gemm_gpu.py); every other GEMM on v_mfma_f32_32x32x2_f32"
+                                  if args.precision == "highest" and ops.split_gemm_enabled() else
+                                  "v_mfma_f32_32x32x2_f32 everywhere" if args.precision == "highest" else
+                                  "bf16-rounded MFMA operands")},
             "final_loss": final_loss,
             "peak_mem_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
             "step_roofline": {"fp32_fraction": FLOPS_PER_FRAME_384 * scale * fps / world / PEAK_FP32,
                               "hbm_fraction": BYTES_PER_FRAME_384 * scale * fps / world / PEAK_HBM,
                               "binding": "fp32 MFMA/VALU (AI ~127 FLOP/B, SURVEY.md §8d)"},
         }
+        if strict is not None:
+            out["fp32_mfma_only"] = {"ms_per_step": 1e3 * strict, "value": world * B / strict, "unit": "frames/s",
+                                     "note": "same step, same run, WFAE_SPLIT_GEMM=0: every GEMM on v_mfma_f32_32x32x2_f32"}
         if world > 1:
             out["dp"] = {"ranks_seen": ranks_seen, "backend": backend, "overlap": bool(dp._hooks),
                          "grad_exchange_ms_per_step": xchg_ms,
@@ -255,13 +293,24 @@ def main():
         if prof:
             tot_ms = sum(v[1] for v in prof.values())
             fam = sorted(prof.items(), key=lambda kv: -kv[1][1])
-            # the dominant kernel of THIS run: the label with the largest total event-timed duration (entry points
-            # that launch two kernels are timed per kernel through ops' `phases` labels)
-            name, (calls, ms, fl, by) = fam[0]
+            # the dominant kernel of THIS run: the kernel with the largest total event-timed duration (entry points
+            # that launch two kernels are timed per kernel through ops' `phases` labels; entry points that share one
+            # kernel are added up)
+            split_on = ops.split_gemm_enabled() and args.precision == "highest"
+            grp = {}
+            for k, v in prof.items():
+                gk = KERNEL_GROUP_SPLIT.get(k, k) if split_on else k
+                g0 = grp.setdefault(gk, [0, 0.0, 0.0, 0.0])
+                for i in range(4):
+                    g0[i] += v[i]
+            name, (calls, ms, fl, by) = max(grp.items(), key=lambda kv: kv[1][1])
             exec_flops_step = sum(v[2] for v in prof.values()) / args.steps
             out["step_roofline"]["executed_flops_fraction"] = exec_flops_step / (dt / args.steps) / PEAK_FP32
             out["step_roofline"]["executed_gflop_per_frame"] = exec_flops_step / B / 1e9
-            if fl > 0:
+            if name.startswith("split_gemm"):
+                # executed work: six bf16 MFMA products per fp32 product of the transform-domain GEMMs
+                ach, peak, unit, bound = 6 * fl / (ms * 1e-3) / 1e12, PEAK_BF16 / 1e12, "TFLOP/s", "mfma"
+            elif fl > 0:
                 ach, peak, unit, bound = fl / (ms * 1e-3) / 1e12, PEAK_FP32 / 1e12, "TFLOP/s", "mfma"
             else:
                 ach, peak, unit, bound = by / (ms * 1e-3) / 1e9, PEAK_HBM / 1e9, "GB/s", "hbm"
@@ -283,6 +332,12 @@ def main():
                                "traffic_source": tsrc, "launches": calls, "avg_launch_ms": ms / calls,
                                "algorithmic_per_launch": (fl if fl > 0 else by) / calls,
                                "share_of_kernel_time": ms / tot_ms}
+            if name.startswith("split_gemm"):
+                out["roofline"]["algorithmic_per_launch"] = 6 * fl / calls
+                out["roofline"]["fp32_equivalent_tflops"] = fl / (ms * 1e-3) / 1e12
+                out["roofline"]["note"] = ("achieved = executed bf16 MFMA FLOPs (6 products per fp32 product of the Winograd-domain "
+                                           "GEMMs) against the dense bf16 peak; fp32_equivalent_tflops = the same work counted "
+                                           "once, comparable with the 157.3 TF fp32 MFMA peak the other GEMMs run on")
             if name.startswith("wfae_wino_gemm"):
                 # the kernel's own work is 2*M*N*K of the transform-domain GEMMs (what `achieved` counts); the
                 # convolution it implements has 32/12.5 (F(4x4,2x2)) or 32/18 (F(2x2,2x2)) as many direct-form FLOPs

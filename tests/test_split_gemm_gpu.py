@@ -35,7 +35,7 @@ def _err(c, ref64, scale64):
 
 
 @pytest.mark.parametrize("kind", [0, 1])
-@pytest.mark.parametrize("y,m,n,k", [(1, 256, 128, 32), (3, 300, 200, 96), (2, 64, 136, 64), (1, 512, 384, 2048), (2, 40, 8, 32)])
+@pytest.mark.parametrize("y,m,n,k", [(1, 256, 128, 32), (3, 300, 200, 96), (2, 64, 136, 64), (1, 512, 384, 2048), (2, 40, 8, 32), (9, 300, 200, 64)])
 def test_split_gemm_matches_fp32_accuracy(ops, dev, kind, y, m, n, k):
     """C = A B from split operands against fp64: the error (relative to sum |a||b|, the natural scale of a dot product)
     is within 1.5x of torch's own fp32 matmul on the same data, at every tile tail (M, N not multiples of the 256 x 128

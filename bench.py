@@ -344,7 +344,8 @@ def main():
                 # — that is the rate the whole-step fp32_fraction above is built from
                 out["roofline"]["note"] = "achieved counts executed (Winograd-domain) FLOPs, not direct-form FLOPs"
             out["kernel_breakdown"] = [
-                {"entry_point": k, "calls_per_step": v[0] / args.steps, "ms_per_step": v[1] / args.steps,
+                {"entry_point": k, "kernel": (KERNEL_GROUP_SPLIT.get(k, k) if split_on else k),
+                 "calls_per_step": v[0] / args.steps, "ms_per_step": v[1] / args.steps,
                  "tflops": (v[2] / (v[1] * 1e-3) / 1e12) if v[2] else None,
                  "gbps": v[3] / (v[1] * 1e-3) / 1e9} for k, v in fam[:16]]
         if world == 1 and not args.no_cpu_baseline:

@@ -64,6 +64,14 @@ enum { WFAE_PRECISION_FP32 = 0, WFAE_PRECISION_BF16 = 1 };
 int wfae_set_matmul_precision(int mode);
 int wfae_get_matmul_precision(void);
 
+/* fp32 GEMMs on the bf16 matrix pipe ("split" operands, see the Winograd section below): at WFAE_PRECISION_FP32 the
+ * MFMA-bound GEMMs carry every fp32 operand exactly as three bf16 values and multiply with six
+ * v_mfma_f32_32x32x16_bf16 per fp32 product — fp32 accuracy at up to 16/6 of the fp32 instruction's rate.  On by
+ * default (environment WFAE_SPLIT_GEMM=0 turns it off at load); 0 keeps every GEMM on v_mfma_f32_32x32x2_f32.
+ * Process-wide; read at launch. */
+int wfae_set_split_gemm(int on);
+int wfae_get_split_gemm(void);
+
 /* ---- 1x1 convolution as an fp32-MFMA GEMM on NCHW ------------------------
  * replaces nn.Conv2d(C, C/4, 1) / (C/4, C, 1) in Bottleneck
  * (pipeline/models/ae_64x8x8_lin.py:15,19) and the latent projections

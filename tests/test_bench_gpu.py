@@ -30,12 +30,16 @@ def test_bench_json_contract(dev):
     # recomputable from the line alone: achieved = algorithmic work per launch / average launch duration
     scale = 1e9 if ro["unit"] == "GB/s" else 1e12
     assert abs(ro["algorithmic_per_launch"] / (ro["avg_launch_ms"] * 1e-3) / scale - ro["achieved"]) < 1e-6 * ro["achieved"]
-    # the dominant kernel is the label with the largest event-timed total of THIS run
-    top = max(d["kernel_breakdown"], key=lambda k: k["ms_per_step"])
-    assert top["entry_point"] == ro["entry_point"]
+    # the dominant kernel is the one with the largest event-timed total of THIS run (entry points that launch the same
+    # kernel — the split-operand Winograd GEMMs — are added up, as rocprofv3's per-kernel statistics do)
+    tot = {}
+    for k in d["kernel_breakdown"]:
+        tot[k["kernel"]] = tot.get(k["kernel"], 0.0) + k["ms_per_step"]
+    assert max(tot, key=tot.get) == ro["entry_point"]
+    assert "matmul" in d["config"] and d["fp32_mfma_only"]["value"] > 0
     ts = ro["traffic_source"]
     assert ts is None or (ts["stale"] == (ro["traffic"] is None) or ro["traffic"] is None)
     sr = d["step_roofline"]
-    assert 0 < sr["executed_flops_fraction"] < sr["fp32_fraction"] * 1.0001 < 1.0
+    assert 0 < sr["executed_flops_fraction"] < sr["fp32_fraction"] * 1.0001
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "warm" in cb["sample"]

@@ -1,6 +1,7 @@
 // api.hip — library-level entry points of libwfae.so (version, errors, workspace sizing).
 #include "common.h"
 #include <atomic>
+#include <stdlib.h>
 
 namespace wfae {
 
@@ -8,6 +9,19 @@ namespace wfae {
 // (which the reference sets once at start-up, experiments/ae_v2/train.py:270): 0 = fp32 MFMA, 1 = bf16 operands
 static std::atomic<int> g_matmul_precision{0};
 int matmul_precision() { return g_matmul_precision.load(std::memory_order_relaxed); }
+
+// fp32 GEMMs on the bf16 matrix pipe with exact three-plane operands (splitgemm.hip; in-register split in gemm.hip):
+// on by default, WFAE_SPLIT_GEMM=0 or wfae_set_split_gemm(0) keeps every GEMM on v_mfma_f32_32x32x2_f32
+static std::atomic<int> g_split_gemm{-1};
+bool split_gemm_enabled() {
+  int v = g_split_gemm.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("WFAE_SPLIT_GEMM");
+    v = (e && e[0] == '0') ? 0 : 1;
+    g_split_gemm.store(v, std::memory_order_relaxed);
+  }
+  return v == 1 && matmul_precision() == WFAE_PRECISION_FP32;
+}
 
 char* err_buf() {
   static thread_local char buf[512] = "ok";
@@ -36,6 +50,13 @@ int wfae_set_matmul_precision(int mode) {
 }
 
 int wfae_get_matmul_precision(void) { return wfae::matmul_precision(); }
+
+int wfae_set_split_gemm(int on) {
+  wfae::g_split_gemm.store(on ? 1 : 0, std::memory_order_relaxed);
+  return WFAE_OK;
+}
+
+int wfae_get_split_gemm(void) { return wfae::split_gemm_enabled() ? 1 : 0; }
 
 const char* wfae_last_error_string(void) { return wfae::err_buf(); }
 

@@ -12,6 +12,7 @@ namespace wfae {
 char* err_buf();
 int fail(int code, const char* fmt, ...);
 int matmul_precision();  // api.hip: WFAE_PRECISION_*
+bool split_gemm_enabled();  // api.hip: fp32 GEMMs on the bf16 pipe with split operands (only at WFAE_PRECISION_FP32)
 
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();

@@ -156,7 +156,7 @@ __device__ __forceinline__ double dpp_row_sum(double v) {
 // but the operand fragments are rounded to bf16 (v_cvt_pk_bf16_f32, RNE) after the LDS read and one
 // v_mfma_f32_32x32x16_bf16 consumes a whole 16-deep stage (fp32 accumulation).
 template <int BM, int WMW, int WNW, int AK, int BKD, int EK, bool VEC, int MF, int PREC = 0, int PRO = 0>
-__global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP || PREC == 1) ? 3 : 4))) void gemm_kernel(GemmP p) {
+__global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP || PREC != 0) ? 3 : 4))) void gemm_kernel(GemmP p) {
   static_assert(WMW * WNW == 4, "4 waves");
   // PRO 1: prologue on the B operand; PRO 2: on a K-contiguous A operand (the weight gradient with swapped roles)
   static_assert(PRO == 0 || (VEC && (BKD == B_NCONTIG || BKD == B_KCONTIG)), "prologue: vector kernels, plain B kinds");
@@ -933,6 +933,57 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
       return;
     }
+    if constexpr (PREC == 2) {
+      // fp32 product on the bf16 pipe (splitgemm.hip): every fragment value is split into its three bf16 planes in
+      // registers (exact: x == h + m + l), six MFMAs per tile and stage.  ~5.5 VALU instructions per value: the stage
+      // becomes VALU-bound at about half the fp32 instruction's 2048 matrix-pipe cycles.
+      static_assert(BK == 16, "one 16-deep v_mfma_f32_32x32x16_bf16 k-slab per stage");
+      vecA af[8];
+      vecB bfr[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        af[q] = *reinterpret_cast<const vecA*>(&As[buf][lh * 8 + q][wm0 + l31 * TM]);
+        bfr[q] = *reinterpret_cast<const vecB*>(&Bs[buf][lh * 8 + q][wn0 + l31 * TN]);
+      }
+      bf16x8 a3[TM][3], b3[TN][3];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float x = af[q][i];
+          const __bf16 h = (__bf16)x;
+          const float r1 = x - (float)h;
+          const __bf16 m = (__bf16)r1;
+          a3[i][0][q] = h;
+          a3[i][1][q] = m;
+          a3[i][2][q] = (__bf16)(r1 - (float)m);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const float x = bfr[q][j];
+          const __bf16 h = (__bf16)x;
+          const float r1 = x - (float)h;
+          const __bf16 m = (__bf16)r1;
+          b3[j][0][q] = h;
+          b3[j][1][q] = m;
+          b3[j][2][q] = (__bf16)(r1 - (float)m);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc_t c = acc[i][j];   // smallest terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i][2], b3[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i][0], b3[j][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i][1], b3[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i][1], b3[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i][0], b3[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i][0], b3[j][0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+      return;
+    }
     constexpr int NSTEP = BK / 2;
     vecA a[2];
     vecB b[2];
@@ -1307,6 +1358,23 @@ int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what,
         hipLaunchKernelGGL((gemm_kernel<32, 1, 4, AK, BKD, EK, true, 32, 1, PRO>), grid, block, dyn_lds, st, p);
       }
       return check_launch(what);
+    }
+    if constexpr (BKD == B_NCONTIG || BKD == B_KCONTIG) {
+      // fp32 products on the bf16 matrix pipe, operands split in registers (PREC 2): for the MFMA-bound shapes
+      static const int split_min_k = env_int("WFAE_SPLIT_MIN_K", 128);
+      static const int split_min_m = env_int("WFAE_SPLIT_MIN_M", 64);
+      if (wfae::split_gemm_enabled() && p.K >= split_min_k && p.M >= split_min_m) {
+        const int bm = pick_bm(p.M, (long)ntiles * ydim * zdim);
+        if (bm == 128) {
+          dim3 grid(cdiv(p.M, 128) * ntiles, ydim, zdim);
+          hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, true, 32, 2, PRO>), grid, block, dyn_lds, st, p);
+          return check_launch(what);
+        } else if (bm == 64) {
+          dim3 grid(cdiv(p.M, 64) * ntiles, ydim, zdim);
+          hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK, true, 32, 2, PRO>), grid, block, dyn_lds, st, p);
+          return check_launch(what);
+        }
+      }
     }
     // measured (tools/kbench.py): pays for the gather GEMMs once the grid fills the 512 resident slots twice
     constexpr bool gather = BKD == B_DOWN || BKD == B_UP || BKD == B_WGRAD;

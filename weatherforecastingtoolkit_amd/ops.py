@@ -297,9 +297,11 @@ _SPLIT_GEMM = os.environ.get("WFAE_SPLIT_GEMM", "1") != "0"
 
 
 def set_split_gemm(on):
-    """switch the split-operand Winograd GEMMs on / off (plans are cached per setting)"""
+    """switch the split-operand GEMMs (Winograd-domain products and the in-register split of the generic GEMM kernel)
+    on / off (plans are cached per setting)"""
     global _SPLIT_GEMM
     _SPLIT_GEMM = bool(on)
+    _lib.call("wfae_set_split_gemm", int(_SPLIT_GEMM))
 
 
 def split_gemm_enabled():

@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run weight gradients on the main stream")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra fp32-MFMA-only timing (profiling runs)")
     ap.add_argument("--fp32-mfma-only", action="store_true",
                     help="keep the Winograd-domain GEMMs on v_mfma_f32_32x32x2_f32 (no split bf16 operands)")
     ap.add_argument("--precision", choices=["highest", "medium"], default="highest",
@@ -232,7 +233,7 @@ def main():
         Fn.set_wgrad_overlap(not args.no_overlap)
     # the same step with every GEMM on the fp32 MFMA instruction (reported beside the headline, never as `value`)
     strict = None
-    if args.precision == "highest" and ops.split_gemm_enabled():
+    if args.precision == "highest" and ops.split_gemm_enabled() and not args.no_fp32_leg:
         ops.set_split_gemm(False)
         step()
         fence()

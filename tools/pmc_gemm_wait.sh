@@ -9,9 +9,9 @@ W=sys.argv[1]
 f=sorted(glob.glob(f'gpurun_out/pmc_wait_{W}/*/*counter_collection.csv'), key=os.path.getmtime)[-1]
 d=collections.defaultdict(dict)
 for r in csv.DictReader(open(f)):
-    if 'gemm_kernel<' not in r['Kernel_Name']: continue
+    if 'gemm_kernel<' not in r['Kernel_Name'] and 'sgemm3_kernel<' not in r['Kernel_Name']: continue
     k=r['Dispatch_Id']
-    d[k]['name']=r['Kernel_Name'].split('gemm_kernel')[1][:34]
+    d[k]['name']=r['Kernel_Name'].split('gemm')[-1][:40]
     d[k][r['Counter_Name']]=float(r['Counter_Value'])
     d[k]['dur']=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
     d[k]['grid']=r.get('Grid_Size','')

@@ -556,8 +556,10 @@ def test_winograd_output_transform_sums(ops, dev):
     """wfae_wino_out_stats: the output transform of the Winograd-domain 4x4 s2 convolution also reduces the BatchNorm sums
     of its result (both Winograd variants)"""
     torch.manual_seed(6)
-    for mode, nb, chi, clo, hlo in (("f42", 2, 16, 32, 8), ("f22", 4, 16, 16, 6), ("f42", 1, 32, 64, 24), ("f42", 1, 16, 16, 40)):
+    for mode, nb, chi, clo, hlo in (("f42", 2, 16, 32, 8), ("f22", 4, 16, 16, 6), ("f42", 1, 32, 64, 24), ("f42", 1, 16, 16, 40),
+                                    ("f42", 2, 16, 16, 72)):
         ops.set_winograd(mode)
+        keep, ops.WINO_STATS_MIN_TILES = ops.WINO_STATS_MIN_TILES, 0   # the sum-reducing kernels also on small images
         try:
             pl = ops.wino_plan(nb, chi, clo, hlo, hlo)
             assert pl is not None
@@ -583,3 +585,9 @@ def test_winograd_output_transform_sums(ops, dev):
             assert relerr(h1.mean, h0.mean) < 2e-7 and relerr(h1.invstd, h0.invstd) < 2e-7
         finally:
             ops.set_winograd("auto")
+            ops.WINO_STATS_MIN_TILES = keep
+    # default policy: images of fewer than 256 tiles leave the sums to the statistics pass
+    pl = ops.wino_plan(2, 16, 32, 8, 8)
+    x, wt = torch.randn(2, 16, 16, 16, device=dev), torch.randn(32, 16, 4, 4, device=dev) * 0.1
+    lo, sp = ops.wino_down(ops.wino_weights(wt, pl), ops.wino_in(x, pl), pl, stats=True)
+    assert sp is None and lo.shape == (2, 32, 8, 8)

@@ -68,7 +68,7 @@ ep = next((e for e, sig in fam.items() if "gemm_kernel<" in top["Name"] and sig 
 if ep is None:
     for key, e in (("bn_act_bwd_dx_kernel", "wfae_bn_act_bwd[dx]"), ("bn_act_bwd_reduce_kernel", "wfae_bn_act_bwd[reduce]"),
                    ("bn_act_fwd_kernel", "wfae_bn_act_fwd"), ("chan_reduce_kernel", "wfae_bn_stats_train"),
-                   ("sgemm3_kernel<0, 0>", "split_gemm[B=KxN]"), ("sgemm3_kernel<1, 0>", "split_gemm[B=NxK]")):
+                   ("sgemm3_kernel<0,", "split_gemm[B=KxN]"), ("sgemm3_kernel<1,", "split_gemm[B=NxK]")):
         if key in top["Name"]:
             ep = e
 if ep is not None and ep not in out and top["Name"] in F:
@@ -81,7 +81,7 @@ if ep is not None and ep not in out and top["Name"] in F:
 # measured on (bench.py reports `traffic` only while that tag matches the sources it runs)
 for key, e in (("bn_act_bwd_dx_kernel", "wfae_bn_act_bwd[dx]"), ("bn_act_bwd_reduce_kernel", "wfae_bn_act_bwd[reduce]"),
                ("bn_act_fwd_kernel", "wfae_bn_act_fwd"), ("chan_reduce_kernel<0>", "wfae_bn_stats_train"),
-               ("sgemm3_kernel<0, 0>", "split_gemm[B=KxN]"), ("sgemm3_kernel<1, 0>", "split_gemm[B=NxK]")):
+               ("sgemm3_kernel<0,", "split_gemm[B=KxN]"), ("sgemm3_kernel<1,", "split_gemm[B=NxK]")):
     n = fs = ws_ = 0
     for k in F:
         if key in k:

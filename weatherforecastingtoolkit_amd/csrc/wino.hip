@@ -79,15 +79,36 @@ __device__ __forceinline__ void put_operand(void* __restrict__ base, long idx, l
   }
 }
 
+// thread -> (channel c, image n, tile tl) of the transform kernels without a block reduction.  Two launch shapes
+// (pick_grid): large images — one block per (<= 256 tiles, channel, image), the blocks in flight work on neighbouring
+// channels of one image (contiguous input); small images (< 256 tiles) — consecutive threads own consecutive t = (image,
+// tile) of one channel, so that a wave still writes 64 consecutive elements of an operand row: a 24 x 24 image has 36 tiles,
+// 72 bytes of a row, which left 220 of 256 lanes idle and every cache line of the operand shared by two blocks
+// (wino_in on 1024 ch @ 48 x 48, B = 32: 0.51 -> 0.25 ms).  false: nothing to do for this thread.
+__device__ __forceinline__ bool tile_of_thread(int C, int Timg, long T, int& c, int& n, int& tl) {
+  if (gridDim.y * gridDim.z > 1) {
+    tl = blockIdx.x * blockDim.x + threadIdx.x;
+    c = blockIdx.y;
+    n = blockIdx.z;
+    return tl < Timg;
+  }
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  c = (int)(idx / T);
+  if (c >= C) return false;
+  const int tt = (int)(idx - (long)c * T);
+  n = tt / Timg;
+  tl = tt - n * Timg;
+  return true;
+}
+
 // hi (N,Chi,2Hlo,2Wlo) -> V[N*N][4Chi][T]
 template <typename WV, bool SPLIT = false>
 __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ hi, void* __restrict__ V, int Chi,
                                                       int Hlo, int Wlo, long T) {
   constexpr int N = WV::N, M = WV::M, PSZ = 2 * N;
   const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
-  const int tl = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tl >= Timg) return;
-  const int h = blockIdx.y, n = blockIdx.z;
+  int h, n, tl;
+  if (!tile_of_thread(Chi, Timg, T, h, n, tl)) return;
   const int ty = tl / TW, tx = tl - ty * TW;
   const int H = 2 * Hlo, W = 2 * Wlo;
   const float* __restrict__ src = hi + (long)(n * Chi + h) * H * W;
@@ -151,9 +172,17 @@ __global__ __launch_bounds__(256) void wino_in_t_kernel(const float* __restrict_
                                                         int Hlo, int Wlo, long T, double* __restrict__ part = nullptr) {
   constexpr int N = WV::N, M = WV::M, BS = 2 * M;
   const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
-  const int tl0 = blockIdx.x * blockDim.x + threadIdx.x;
-  const int h = blockIdx.y, n = blockIdx.z;
-  const bool active = tl0 < Timg;
+  // STATS: one block per (<= 256 tiles, channel, image) for the block reduction; else the flat (channel, tile) index
+  int h, n, tl0;
+  bool active;
+  if constexpr (STATS) {
+    tl0 = blockIdx.x * blockDim.x + threadIdx.x;
+    h = blockIdx.y;
+    n = blockIdx.z;
+    active = tl0 < Timg;
+  } else {
+    active = tile_of_thread(Chi, Timg, T, h, n, tl0);
+  }
   if (!STATS && !active) return;
   const int tl = active ? tl0 : 0;   // STATS: idle lanes of the last block recompute tile 0 (stores and sums masked) and
                                      // take part in the block reduction
@@ -308,8 +337,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
                                                        int Hlo, int Wlo, long T, double* __restrict__ part = nullptr) {
   constexpr int N = WV::N, M = WV::M;
   const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
-  const int tl = blockIdx.x * blockDim.x + threadIdx.x;
-  const int l = blockIdx.y, n = blockIdx.z;
+  int l = blockIdx.y, n = blockIdx.z, tl = blockIdx.x * blockDim.x + threadIdx.x;
   if constexpr (STATS) {
     __shared__ double sm[16];
     double s1 = 0.0, s2 = 0.0;
@@ -346,7 +374,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
     }
     return;
   }
-  if (tl >= Timg) return;
+  if (!tile_of_thread(Clo, Timg, T, l, n, tl)) return;
   const int ty = tl / TW, tx = tl - ty * TW;
   const long xi_stride = (long)Clo * T;
   const float* __restrict__ src = Mx + (long)l * T + (long)n * Timg + tl;
@@ -370,9 +398,8 @@ __global__ __launch_bounds__(256) void wino_out_t_kernel(const float* __restrict
                                                          int Hlo, int Wlo, long T) {
   constexpr int N = WV::N, M = WV::M;
   const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
-  const int tl = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tl >= Timg) return;
-  const int l = blockIdx.y, n = blockIdx.z;
+  int l, n, tl;
+  if (!tile_of_thread(Clo, Timg, T, l, n, tl)) return;
   const int ty = tl / TW, tx = tl - ty * TW;
   const float* __restrict__ src = lo + ((long)(n * Clo + l) * Hlo + M * ty) * Wlo + M * tx;
   float y[M][M], m[N][N];
@@ -471,6 +498,13 @@ __global__ __launch_bounds__(256) void wino_weights_t_kernel(const float* __rest
 }
 
 inline dim3 tile_grid(int NB, int C, int Hlo, int Wlo, int M) { return dim3(cdiv((long)(Hlo / M) * (Wlo / M), 256), C, NB); }
+// the kernels without a block reduction (tile_of_thread): per (channel, image) blocks for images of >= 256 tiles, else one
+// thread per (channel, image, tile) with the tiles of all images fastest
+inline dim3 flat_grid(int NB, int C, int Hlo, int Wlo, int M) {
+  const long Timg = (long)(Hlo / M) * (Wlo / M);
+  if (Timg >= 256 || (long)C * NB == 1) return tile_grid(NB, C, Hlo, Wlo, M);
+  return dim3(cdiv((long)C * NB * Timg, 256), 1, 1);
+}
 
 }  // namespace
 
@@ -485,14 +519,14 @@ namespace wfae {
 int wino_in(int variant, const float* hi, float* V, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
   const int M = variant ? 4 : 2;
   const long T = (long)NB * (Hlo / M) * (Wlo / M);
-  WFAE_WINO_DISPATCH(wino_in_kernel, tile_grid(NB, Chi, Hlo, Wlo, M), hi, (void*)V, Chi, Hlo, Wlo, T);
+  WFAE_WINO_DISPATCH(wino_in_kernel, flat_grid(NB, Chi, Hlo, Wlo, M), hi, (void*)V, Chi, Hlo, Wlo, T);
   return check_launch("wino_in");
 }
 // the *_split forms write the three bf16 planes of splitgemm.hip (plane stride = the operand's element count)
 int wino_in_split(int variant, const float* hi, unsigned short* V3, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
   const int M = variant ? 4 : 2;
   const long T = (long)NB * (Hlo / M) * (Wlo / M);
-  const dim3 grid = tile_grid(NB, Chi, Hlo, Wlo, M);
+  const dim3 grid = flat_grid(NB, Chi, Hlo, Wlo, M);
   if (variant == 0) hipLaunchKernelGGL((wino_in_kernel<W22, true>), grid, dim3(256), 0, st, hi, (void*)V3, Chi, Hlo, Wlo, T);
   else hipLaunchKernelGGL((wino_in_kernel<W42, true>), grid, dim3(256), 0, st, hi, (void*)V3, Chi, Hlo, Wlo, T);
   return check_launch("wino_in_split");
@@ -500,7 +534,7 @@ int wino_in_split(int variant, const float* hi, unsigned short* V3, int NB, int 
 int wino_out_t_split(int variant, const float* lo, unsigned short* Mt3, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
   const int M = variant ? 4 : 2;
   const long T = (long)NB * (Hlo / M) * (Wlo / M);
-  const dim3 grid = tile_grid(NB, Clo, Hlo, Wlo, M);
+  const dim3 grid = flat_grid(NB, Clo, Hlo, Wlo, M);
   if (variant == 0) hipLaunchKernelGGL((wino_out_t_kernel<W22, true>), grid, dim3(256), 0, st, lo, (void*)Mt3, Clo, Hlo, Wlo, T);
   else hipLaunchKernelGGL((wino_out_t_kernel<W42, true>), grid, dim3(256), 0, st, lo, (void*)Mt3, Clo, Hlo, Wlo, T);
   return check_launch("wino_out_t_split");
@@ -520,7 +554,7 @@ int wino_weights_split(int variant, const float* w, unsigned short* U3, unsigned
 int wino_in_t(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
   const int M = variant ? 4 : 2;
   const long T = (long)NB * (Hlo / M) * (Wlo / M);
-  WFAE_WINO_DISPATCH(wino_in_t_kernel, tile_grid(NB, Chi, Hlo, Wlo, M), dV, hi, Chi, Hlo, Wlo, T, (double*)nullptr);
+  WFAE_WINO_DISPATCH(wino_in_t_kernel, flat_grid(NB, Chi, Hlo, Wlo, M), dV, hi, Chi, Hlo, Wlo, T, (double*)nullptr);
   return check_launch("wino_in_t");
 }
 int wino_in_t_stats(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, double* part, hipStream_t st) {
@@ -534,7 +568,7 @@ int wino_in_t_stats(int variant, const float* dV, float* hi, int NB, int Chi, in
 int wino_out(int variant, const float* Mx, float* lo, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
   const int M = variant ? 4 : 2;
   const long T = (long)NB * (Hlo / M) * (Wlo / M);
-  WFAE_WINO_DISPATCH(wino_out_kernel, tile_grid(NB, Clo, Hlo, Wlo, M), Mx, lo, Clo, Hlo, Wlo, T, (double*)nullptr);
+  WFAE_WINO_DISPATCH(wino_out_kernel, flat_grid(NB, Clo, Hlo, Wlo, M), Mx, lo, Clo, Hlo, Wlo, T, (double*)nullptr);
   return check_launch("wino_out");
 }
 int wino_out_stats(int variant, const float* Mx, float* lo, int NB, int Clo, int Hlo, int Wlo, double* part, hipStream_t st) {
@@ -552,7 +586,7 @@ int wino_out_stat_splits(int variant, int NB, int Hlo, int Wlo) {
 int wino_out_t(int variant, const float* lo, float* Mt, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
   const int M = variant ? 4 : 2;
   const long T = (long)NB * (Hlo / M) * (Wlo / M);
-  WFAE_WINO_DISPATCH(wino_out_t_kernel, tile_grid(NB, Clo, Hlo, Wlo, M), lo, (void*)Mt, Clo, Hlo, Wlo, T);
+  WFAE_WINO_DISPATCH(wino_out_t_kernel, flat_grid(NB, Clo, Hlo, Wlo, M), lo, (void*)Mt, Clo, Hlo, Wlo, T);
   return check_launch("wino_out_t");
 }
 int wino_weights(int variant, const float* w, float* U, int Clo, int Chi, hipStream_t st) {

@@ -403,6 +403,11 @@ def wino_out_t(lo, pl):
     return Mt
 
 
+# tiles per image below which the Winograd output / adjoint input transforms leave the BatchNorm sums to the ordinary
+# statistics pass (the sum-reducing kernels need one block per (channel, image); tests set 0 to exercise them on small shapes)
+WINO_STATS_MIN_TILES = 256
+
+
 def wino_down(U, V, pl, stats=False):
     """lo = Out(U * V); stats=True: -> (lo, StatParts of lo) — the output transform also reduces the BatchNorm sums"""
     import ctypes
@@ -413,10 +418,13 @@ def wino_down(U, V, pl, stats=False):
               _p(M), *pl.dims, _stream(), label="wfae_wino_gemm_down")
     else:
         _call("wfae_wino_gemm_down", pl.gemm_flops, 4 * (pl.nU + pl.nV + pl.nM), pl.variant, _p(U), _p(V), _p(M), *pl.dims, _stream())
-    if not stats:
-        _call("wfae_wino_out", 0, 4 * (pl.nM + lo.numel()), pl.variant, _p(M), _p(lo), pl.nb, pl.clo, pl.hlo, pl.wlo, _stream())
-        return lo
     m = 4 if pl.variant else 2
+    # images of fewer than 256 tiles: the transform runs one thread per (channel, image, tile) (full waves, whole cache
+    # lines of M) and the sums of the small result are taken by the ordinary statistics pass
+    small = (pl.hlo // m) * (pl.wlo // m) < WINO_STATS_MIN_TILES
+    if not stats or small:
+        _call("wfae_wino_out", 0, 4 * (pl.nM + lo.numel()), pl.variant, _p(M), _p(lo), pl.nb, pl.clo, pl.hlo, pl.wlo, _stream())
+        return (lo, None) if stats else lo
     cap = 2 * pl.clo * pl.nb * (((pl.hlo // m) * (pl.wlo // m) + 255) // 256)
     part = torch.empty(cap, dtype=torch.float64, device=V.device)
     splits = ctypes.c_int(0)
@@ -435,10 +443,11 @@ def wino_up(U, Mt, pl, stats=False):
               Mt.data_ptr(), _p(dV), *pl.dims, _stream(), label="wfae_wino_gemm_up")
     else:
         _call("wfae_wino_gemm_up", pl.gemm_flops, 4 * (pl.nU + pl.nV + pl.nM), pl.variant, _p(U), _p(Mt), _p(dV), *pl.dims, _stream())
-    if not stats:
-        _call("wfae_wino_in_t", 0, 4 * (pl.nV + hi.numel()), pl.variant, _p(dV), _p(hi), pl.nb, pl.chi, pl.hlo, pl.wlo, _stream())
-        return hi
     m = 4 if pl.variant else 2
+    small = (pl.hlo // m) * (pl.wlo // m) < WINO_STATS_MIN_TILES
+    if not stats or small:
+        _call("wfae_wino_in_t", 0, 4 * (pl.nV + hi.numel()), pl.variant, _p(dV), _p(hi), pl.nb, pl.chi, pl.hlo, pl.wlo, _stream())
+        return (hi, None) if stats else hi
     cap = 2 * pl.chi * pl.nb * (((pl.hlo // m) * (pl.wlo // m) + 255) // 256)
     part = torch.empty(cap, dtype=torch.float64, device=Mt.device)
     splits = ctypes.c_int(0)

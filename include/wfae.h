@@ -275,22 +275,28 @@ int wfae_wino_gemm_wgrad(int variant, const float* Mt, const float* V, float* dw
  * the GEMM outputs stay fp32 and go through wino_out / wino_in_t / the G^T dU G reduction unchanged.
  *   wino_weights_split: U3 [3][xi][Clo][4Chi] and Ut3 [3][xi][4Chi][Clo] (the up product contracts over Clo)
  *   wino_in_split / wino_out_t_split: V3 [3][xi][4Chi][T], Mt3 [3][xi][Clo][T]
+ * `planes` = 3: the exact split above.  `planes` = 1: only the h plane is written / read — bf16-rounded operands with
+ * fp32 accumulation, i.e. WFAE_PRECISION_BF16's arithmetic with 2-byte operand storage for the matrix work (one MFMA
+ * product per tile; the GEMMs turn HBM-bound).  Buffers hold `planes` planes.
  * wfae_wino_split_supported: 1 when wfae_wino_sizes accepts the geometry and 4 Chi, Clo and T are multiples of 32.
  * wfae_split_bf16x3 / wfae_split_gemm: the conversion and the batched product on their own (C[y] = A[y] B[y], A [M][K];
  * b_kind 0: B [K][N], b_kind 1: B [N][K]; K % 32 == 0, N % 8 == 0 for b_kind 0; planes batches*M*K resp. batches*K*N
  * elements apart). */
 int wfae_wino_split_supported(int variant, int NB, int Chi, int Clo, int Hlo, int Wlo);
-int wfae_wino_weights_split(int variant, const float* w, uint16_t* U3, uint16_t* Ut3, int Chi, int Clo, wfae_stream_t stream);
-int wfae_wino_in_split(int variant, const float* hi, uint16_t* V3, int NB, int Chi, int Hlo, int Wlo, wfae_stream_t stream);
-int wfae_wino_out_t_split(int variant, const float* lo, uint16_t* Mt3, int NB, int Clo, int Hlo, int Wlo, wfae_stream_t stream);
-int wfae_wino_gemm_down_split(int variant, const uint16_t* U3, const uint16_t* V3, float* M, int NB, int Chi, int Clo, int Hlo,
-                              int Wlo, wfae_stream_t stream);
-int wfae_wino_gemm_up_split(int variant, const uint16_t* Ut3, const uint16_t* Mt3, float* dV, int NB, int Chi, int Clo, int Hlo,
-                            int Wlo, wfae_stream_t stream);
-int wfae_wino_gemm_wgrad_split(int variant, const uint16_t* Mt3, const uint16_t* V3, float* dw, int NB, int Chi, int Clo,
-                               int Hlo, int Wlo, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
-int wfae_split_bf16x3(const float* x, uint16_t* planes, int64_t n, wfae_stream_t stream);
-int wfae_split_gemm(int b_kind, const uint16_t* A3, const uint16_t* B3, float* C, int M, int N, int K, int batches,
+int wfae_wino_weights_split(int variant, const float* w, uint16_t* U3, uint16_t* Ut3, int planes, int Chi, int Clo,
+                            wfae_stream_t stream);
+int wfae_wino_in_split(int variant, const float* hi, uint16_t* V3, int planes, int NB, int Chi, int Hlo, int Wlo,
+                       wfae_stream_t stream);
+int wfae_wino_out_t_split(int variant, const float* lo, uint16_t* Mt3, int planes, int NB, int Clo, int Hlo, int Wlo,
+                          wfae_stream_t stream);
+int wfae_wino_gemm_down_split(int variant, const uint16_t* U3, const uint16_t* V3, float* M, int planes, int NB, int Chi, int Clo,
+                              int Hlo, int Wlo, wfae_stream_t stream);
+int wfae_wino_gemm_up_split(int variant, const uint16_t* Ut3, const uint16_t* Mt3, float* dV, int planes, int NB, int Chi, int Clo,
+                            int Hlo, int Wlo, wfae_stream_t stream);
+int wfae_wino_gemm_wgrad_split(int variant, const uint16_t* Mt3, const uint16_t* V3, float* dw, int planes, int NB, int Chi,
+                               int Clo, int Hlo, int Wlo, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
+int wfae_split_bf16x3(const float* x, uint16_t* out, int64_t n, int planes, wfae_stream_t stream);
+int wfae_split_gemm(int b_kind, int planes, const uint16_t* A3, const uint16_t* B3, float* C, int M, int N, int K, int batches,
                     wfae_stream_t stream);
 
 /* ---- 4x4 stride-1 convolution on the MFMA GEMM (PatchGAN layer 4: Conv2d(256, 512, 4, stride=1, padding=1,

@@ -79,24 +79,27 @@ for variant in (0, 1):
 expect(lib.wfae_wino_sizes(1, 32, 256, 512, 0, 96, ctypes.cast(out, ctypes.c_void_p)), ANY_FAIL, "wino_sizes Hlo=0")
 # --- split-operand GEMMs: argument validation, the support query and the full host paths (tile / K-split / workspace carving)
 UNS = codes.get("WFAE_ERR_UNSUPPORTED", -3)
-expect(lib.wfae_split_gemm(0, None, Q, R, 64, 64, 64, 1, None), NULL, "split_gemm null")
-expect(lib.wfae_split_gemm(2, P, Q, R, 64, 64, 64, 1, None), SHAPE, "split_gemm bad kind")
-expect(lib.wfae_split_gemm(0, P, Q, R, 64, 64, 48, 1, None), UNS, "split_gemm K % 32")
-expect(lib.wfae_split_gemm(0, P + 2, Q, R, 64, 64, 64, 1, None), SHAPE, "split_gemm misaligned planes")
-expect(lib.wfae_split_bf16x3(P, None, 16, None), NULL, "split_bf16x3 null")
-expect(lib.wfae_split_bf16x3(P, Q, 0, None), SHAPE, "split_bf16x3 n = 0")
+expect(lib.wfae_split_gemm(0, 3, None, Q, R, 64, 64, 64, 1, None), NULL, "split_gemm null")
+expect(lib.wfae_split_gemm(2, 3, P, Q, R, 64, 64, 64, 1, None), SHAPE, "split_gemm bad kind")
+expect(lib.wfae_split_gemm(0, 3, P, Q, R, 64, 64, 48, 1, None), UNS, "split_gemm K % 32")
+expect(lib.wfae_split_gemm(0, 3, P + 2, Q, R, 64, 64, 64, 1, None), SHAPE, "split_gemm misaligned planes")
+expect(lib.wfae_split_gemm(0, 2, P, Q, R, 64, 64, 64, 1, None), SHAPE, "split_gemm planes = 2")
+expect(lib.wfae_split_bf16x3(P, None, 16, 3, None), NULL, "split_bf16x3 null")
+expect(lib.wfae_split_bf16x3(P, Q, 0, 3, None), SHAPE, "split_bf16x3 n = 0")
 assert lib.wfae_wino_split_supported(1, 32, 256, 512, 96, 96) == 1 and lib.wfae_wino_split_supported(1, 1, 256, 512, 8, 8) == 0
 assert lib.wfae_wino_split_supported(1, 32, 12, 512, 96, 96) == 0 and lib.wfae_wino_split_supported(7, 32, 256, 512, 96, 96) == 0
 checked += 2
-expect(lib.wfae_wino_gemm_down_split(1, P, Q, R, 1, 256, 512, 8, 8, None), UNS, "wino_gemm_down_split unsupported geometry")
-expect(lib.wfae_wino_gemm_wgrad_split(1, P, Q, R, 32, 256, 512, 96, 96, 0, WS, 16, None), WSP, "wino_gemm_wgrad_split short workspace")
-for key in [(32, 256, 512, 96, 96), (32, 1024, 1024, 24, 24), (32, 128, 256, 192, 192)]:
-    expect(lib.wfae_wino_weights_split(1, P, Q, R, key[1], key[2], None), ANY_FAIL, f"wino_weights_split {key}")
-    expect(lib.wfae_wino_in_split(1, P, Q, key[0], key[1], key[3], key[4], None), ANY_FAIL, f"wino_in_split {key}")
-    expect(lib.wfae_wino_out_t_split(1, P, Q, key[0], key[2], key[3], key[4], None), ANY_FAIL, f"wino_out_t_split {key}")
-    expect(lib.wfae_wino_gemm_down_split(1, P, Q, R, *key, None), ANY_FAIL, f"wino_gemm_down_split {key}")
-    expect(lib.wfae_wino_gemm_up_split(1, P, Q, R, *key, None), ANY_FAIL, f"wino_gemm_up_split {key}")
-    expect(lib.wfae_wino_gemm_wgrad_split(1, P, Q, R, *key, 0, WS, big, None), ANY_FAIL, f"wino_gemm_wgrad_split {key}")
+expect(lib.wfae_wino_gemm_down_split(1, P, Q, R, 3, 1, 256, 512, 8, 8, None), UNS, "wino_gemm_down_split unsupported geometry")
+expect(lib.wfae_wino_gemm_wgrad_split(1, P, Q, R, 3, 32, 256, 512, 96, 96, 0, WS, 16, None), WSP, "wino_gemm_wgrad_split short workspace")
+for planes in (3, 1):
+  for key in [(32, 256, 512, 96, 96), (32, 1024, 1024, 24, 24), (32, 128, 256, 192, 192)]:
+    expect(lib.wfae_wino_weights_split(1, P, Q, R, planes, key[1], key[2], None), ANY_FAIL, f"wino_weights_split {key}")
+    expect(lib.wfae_wino_in_split(1, P, Q, planes, key[0], key[1], key[3], key[4], None), ANY_FAIL, f"wino_in_split {key}")
+    expect(lib.wfae_wino_out_t_split(1, P, Q, planes, key[0], key[2], key[3], key[4], None), ANY_FAIL, f"wino_out_t_split {key}")
+    expect(lib.wfae_wino_gemm_down_split(1, P, Q, R, planes, *key, None), ANY_FAIL, f"wino_gemm_down_split {key}")
+    expect(lib.wfae_wino_gemm_up_split(1, P, Q, R, planes, *key, None), ANY_FAIL, f"wino_gemm_up_split {key}")
+    expect(lib.wfae_wino_gemm_wgrad_split(1, P, Q, R, planes, *key, 0, WS, big, None), ANY_FAIL, f"wino_gemm_wgrad_split {key}")
+expect(lib.wfae_wino_gemm_up_split(1, P, Q, R, 2, 32, 256, 512, 96, 96, None), SHAPE, "wino_gemm_up_split planes = 2")
 assert lib.wfae_set_split_gemm(0) == 0 and lib.wfae_get_split_gemm() == 0 and lib.wfae_set_split_gemm(1) == 0 and lib.wfae_get_split_gemm() == 1
 checked += 1
 expect(lib.wfae_conv4x4s2_down(P, Q, R, 32, 256, 512, 96, 96, None), ANY_FAIL, "conv4x4s2_down")

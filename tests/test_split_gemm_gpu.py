@@ -94,3 +94,44 @@ def test_split_gemm_refuses_unserved_shapes(ops, dev):
         ops.split_gemm(a3, b3, 0)
     assert _lib.load().wfae_wino_split_supported(1, 1, 256, 512, 8, 8) == 0    # T = 4 tiles
     assert _lib.load().wfae_wino_split_supported(1, 32, 256, 512, 96, 96) == 1
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_one_plane_gemm_is_the_bf16_operand_product(ops, dev, kind):
+    """planes = 1: the h plane alone — the product of the bf16-rounded operands with fp32 accumulation ('medium'
+    precision with 2-byte operand storage): equal to an fp64 product of the rounded operands to fp32 accumulation error"""
+    g = torch.Generator().manual_seed(11 + kind)
+    a = torch.randn(3, 300, 96, generator=g).to(dev)
+    b = torch.randn(3, 96, 200, generator=g).to(dev)
+    a1, b1 = ops.split_bf16x3(a, planes=1), ops.split_bf16x3(b if kind == 0 else b.transpose(1, 2).contiguous(), planes=1)
+    assert a1.shape[0] == 1 and torch.equal(_planes_to_f32(a1)[0], a.bfloat16().float())
+    c = ops.split_gemm(a1, b1, kind)
+    ar, br = a.bfloat16().double(), b.bfloat16().double()
+    ref, scale = ar @ br, ar.abs() @ br.abs()
+    assert _err(c, ref, scale) < 2e-7
+
+
+def test_winograd_medium_precision_on_one_plane_operands(ops, dev):
+    """'medium' matmul precision: the Winograd products read 2-byte operands (the h plane written by the transforms) and
+    agree with the fp32-storage bf16 path (operands rounded behind the LDS read) — the same rounded values, another
+    accumulation order"""
+    g = torch.Generator().manual_seed(5)
+    nb, chi, clo, hlo = 4, 64, 128, 16
+    hi = (torch.rand(nb, chi, 2 * hlo, 2 * hlo, generator=g) - 0.5).to(dev)
+    lo = (torch.rand(nb, clo, hlo, hlo, generator=g) - 0.5).to(dev)
+    w = ((torch.rand(clo, chi, 4, 4, generator=g) - 0.5) * 0.2).to(dev)
+    res = {}
+    ops.set_float32_matmul_precision("medium")
+    try:
+        for split in (False, True):
+            ops.set_split_gemm(split)
+            pl = ops.wino_plan(nb, chi, clo, hlo, hlo)
+            assert pl is not None and pl.split == split and (not split or pl.planes == 1)
+            dw = torch.empty_like(w)
+            ops.conv4x4s2_wgrad(lo, hi, dw)
+            res[split] = (ops.conv4x4s2_down(hi, w), ops.conv4x4s2_up(lo, w), dw)
+    finally:
+        ops.set_float32_matmul_precision("highest")
+        ops.set_split_gemm(True)
+    for a, b in zip(res[False], res[True]):
+        assert float((a - b).abs().max() / a.abs().max()) < 2e-6

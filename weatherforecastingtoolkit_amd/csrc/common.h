@@ -132,12 +132,13 @@ int wino_out_stat_splits(int variant, int NB, int Hlo, int Wlo);   // also the s
 int wino_in_t_stats(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, double* part, hipStream_t st);
 int wino_weights(int variant, const float* w, float* U, int Clo, int Chi, hipStream_t st);                   // -> U[xi][Clo][4Chi]
 // bf16-plane forms of the GEMM operands (splitgemm.hip) and the GEMM itself
-int wino_in_split(int variant, const float* hi, unsigned short* V3, int NB, int Chi, int Hlo, int Wlo, hipStream_t st);
-int wino_out_t_split(int variant, const float* lo, unsigned short* Mt3, int NB, int Clo, int Hlo, int Wlo, hipStream_t st);
-int wino_weights_split(int variant, const float* w, unsigned short* U3, unsigned short* Ut3, int Clo, int Chi, hipStream_t st);
-int split_gemm(int kind, const unsigned short* A, const unsigned short* B, float* C, int M, int N, int K, long a_plane,
-               long b_plane, long a_y, long b_y, long c_y, int batches, int k_per_split, int splits, long c_split,
-               hipStream_t st, const char* what);
+int wino_in_split(int variant, const float* hi, unsigned short* V3, int planes, int NB, int Chi, int Hlo, int Wlo, hipStream_t st);
+int wino_out_t_split(int variant, const float* lo, unsigned short* Mt3, int planes, int NB, int Clo, int Hlo, int Wlo, hipStream_t st);
+int wino_weights_split(int variant, const float* w, unsigned short* U3, unsigned short* Ut3, int planes, int Clo, int Chi,
+                       hipStream_t st);
+int split_gemm(int kind, int planes, const unsigned short* A, const unsigned short* B, float* C, int M, int N, int K,
+               long a_plane, long b_plane, long a_y, long b_y, long c_y, int batches, int k_per_split, int splits,
+               long c_split, hipStream_t st, const char* what);
 int wino_weights_t(int variant, const float* dU, float* dw, int Clo, int Chi, int beta, hipStream_t st);     // G^T dU G
 
 // out = (beta ? out : 0) + sum over `splits` partial slabs of MN floats (+ bias_n[i % N]); fixed order.

@@ -2064,7 +2064,8 @@ int wfae_wino_gemm_wgrad(int variant, const float* Mt, const float* V, float* dw
   return wino_weights_t(variant, dU, dw, Clo, Chi, accumulate ? 1 : 0, st);
 }
 
-// ---- the same three products on the bf16 matrix pipe with fp32-exact split operands (splitgemm.hip) ----
+// ---- the same three products on the bf16 matrix pipe with split operands (splitgemm.hip): planes = 3 — the exact fp32
+// split, planes = 1 — the h plane alone = bf16-rounded operands (WFAE_PRECISION_BF16's arithmetic) ----
 int wfae_wino_split_supported(int variant, int NB, int Chi, int Clo, int Hlo, int Wlo) {
   WinoGeom g;
   if (!wino_geom(variant, NB, Chi, Clo, Hlo, Wlo, &g)) return 0;
@@ -2073,47 +2074,54 @@ int wfae_wino_split_supported(int variant, int NB, int Chi, int Clo, int Hlo, in
 
 #define WFAE_WINO_SPLIT_GEOM(what)                                                                            \
   WinoGeom g;                                                                                                 \
+  WFAE_REQUIRE(planes == 1 || planes == 3, WFAE_ERR_BAD_SHAPE, what ": planes must be 1 or 3");                 \
   WFAE_REQUIRE(wfae_wino_split_supported(variant, NB, Chi, Clo, Hlo, Wlo) && wino_geom(variant, NB, Chi, Clo, Hlo, Wlo, &g), \
                WFAE_ERR_UNSUPPORTED, what ": needs the Winograd geometry with 4 Chi, Clo and the tile count multiples of 32")
 
-int wfae_wino_weights_split(int variant, const float* w, uint16_t* U3, uint16_t* Ut3, int Chi, int Clo, wfae_stream_t stream) {
+int wfae_wino_weights_split(int variant, const float* w, uint16_t* U3, uint16_t* Ut3, int planes, int Chi, int Clo,
+                            wfae_stream_t stream) {
   WFAE_REQUIRE(w && U3 && Ut3, WFAE_ERR_NULL_POINTER, "wino_weights_split: null pointer");
-  WFAE_REQUIRE((variant == 0 || variant == 1) && Chi > 0 && Clo > 0, WFAE_ERR_BAD_SHAPE, "wino_weights_split: bad shape");
-  return wino_weights_split(variant, w, U3, Ut3, Clo, Chi, (hipStream_t)stream);
+  WFAE_REQUIRE((variant == 0 || variant == 1) && Chi > 0 && Clo > 0 && (planes == 1 || planes == 3), WFAE_ERR_BAD_SHAPE,
+               "wino_weights_split: bad shape");
+  return wino_weights_split(variant, w, U3, Ut3, planes, Clo, Chi, (hipStream_t)stream);
 }
 
-int wfae_wino_in_split(int variant, const float* hi, uint16_t* V3, int NB, int Chi, int Hlo, int Wlo, wfae_stream_t stream) {
+int wfae_wino_in_split(int variant, const float* hi, uint16_t* V3, int planes, int NB, int Chi, int Hlo, int Wlo,
+                       wfae_stream_t stream) {
   WFAE_REQUIRE(hi && V3, WFAE_ERR_NULL_POINTER, "wino_in_split: null pointer");
   WFAE_WINO_TILE_CHECK("wino_in_split", Chi);
-  return wino_in_split(variant, hi, V3, NB, Chi, Hlo, Wlo, (hipStream_t)stream);
+  WFAE_REQUIRE(planes == 1 || planes == 3, WFAE_ERR_BAD_SHAPE, "wino_in_split: planes must be 1 or 3");
+  return wino_in_split(variant, hi, V3, planes, NB, Chi, Hlo, Wlo, (hipStream_t)stream);
 }
 
-int wfae_wino_out_t_split(int variant, const float* lo, uint16_t* Mt3, int NB, int Clo, int Hlo, int Wlo, wfae_stream_t stream) {
+int wfae_wino_out_t_split(int variant, const float* lo, uint16_t* Mt3, int planes, int NB, int Clo, int Hlo, int Wlo,
+                          wfae_stream_t stream) {
   WFAE_REQUIRE(lo && Mt3, WFAE_ERR_NULL_POINTER, "wino_out_t_split: null pointer");
   WFAE_WINO_TILE_CHECK("wino_out_t_split", Clo);
-  return wino_out_t_split(variant, lo, Mt3, NB, Clo, Hlo, Wlo, (hipStream_t)stream);
+  WFAE_REQUIRE(planes == 1 || planes == 3, WFAE_ERR_BAD_SHAPE, "wino_out_t_split: planes must be 1 or 3");
+  return wino_out_t_split(variant, lo, Mt3, planes, NB, Clo, Hlo, Wlo, (hipStream_t)stream);
 }
 
-int wfae_wino_gemm_down_split(int variant, const uint16_t* U3, const uint16_t* V3, float* M, int NB, int Chi, int Clo, int Hlo,
-                              int Wlo, wfae_stream_t stream) {
+int wfae_wino_gemm_down_split(int variant, const uint16_t* U3, const uint16_t* V3, float* M, int planes, int NB, int Chi, int Clo,
+                              int Hlo, int Wlo, wfae_stream_t stream) {
   WFAE_REQUIRE(U3 && V3 && M, WFAE_ERR_NULL_POINTER, "wino_gemm_down_split: null pointer");
   WFAE_WINO_SPLIT_GEOM("wino_gemm_down_split");
   // M_xi (Clo x T) = U_xi (Clo x 4Chi) * V_xi (4Chi x T)
-  return split_gemm(0, U3, V3, M, Clo, (int)g.T, g.K4, (long)g.nU, (long)g.nV, (long)Clo * g.K4, (long)g.K4 * g.T,
+  return split_gemm(0, planes, U3, V3, M, Clo, (int)g.T, g.K4, (long)g.nU, (long)g.nV, (long)Clo * g.K4, (long)g.K4 * g.T,
                     (long)Clo * g.T, g.NX, g.K4, 1, 0, (hipStream_t)stream, "wino_gemm_down_split");
 }
 
-int wfae_wino_gemm_up_split(int variant, const uint16_t* Ut3, const uint16_t* Mt3, float* dV, int NB, int Chi, int Clo, int Hlo,
-                            int Wlo, wfae_stream_t stream) {
+int wfae_wino_gemm_up_split(int variant, const uint16_t* Ut3, const uint16_t* Mt3, float* dV, int planes, int NB, int Chi, int Clo,
+                            int Hlo, int Wlo, wfae_stream_t stream) {
   WFAE_REQUIRE(Ut3 && Mt3 && dV, WFAE_ERR_NULL_POINTER, "wino_gemm_up_split: null pointer");
   WFAE_WINO_SPLIT_GEOM("wino_gemm_up_split");
   // dV_xi (4Chi x T) = U_xi^T (4Chi x Clo) * Mt_xi (Clo x T)
-  return split_gemm(0, Ut3, Mt3, dV, g.K4, (int)g.T, Clo, (long)g.nU, (long)g.nM, (long)Clo * g.K4, (long)Clo * g.T,
+  return split_gemm(0, planes, Ut3, Mt3, dV, g.K4, (int)g.T, Clo, (long)g.nU, (long)g.nM, (long)Clo * g.K4, (long)Clo * g.T,
                     (long)g.K4 * g.T, g.NX, Clo, 1, 0, (hipStream_t)stream, "wino_gemm_up_split");
 }
 
-int wfae_wino_gemm_wgrad_split(int variant, const uint16_t* Mt3, const uint16_t* V3, float* dw, int NB, int Chi, int Clo,
-                               int Hlo, int Wlo, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream) {
+int wfae_wino_gemm_wgrad_split(int variant, const uint16_t* Mt3, const uint16_t* V3, float* dw, int planes, int NB, int Chi,
+                               int Clo, int Hlo, int Wlo, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream) {
   WFAE_REQUIRE(Mt3 && V3 && dw, WFAE_ERR_NULL_POINTER, "wino_gemm_wgrad_split: null pointer");
   WFAE_WINO_SPLIT_GEOM("wino_gemm_wgrad_split");
   const size_t slab = g.nU * sizeof(float);
@@ -2131,7 +2139,7 @@ int wfae_wino_gemm_wgrad_split(int variant, const uint16_t* Mt3, const uint16_t*
   while (want > 1 && (size_t)want * slab > ws_bytes - slab) --want;
   const int k_per_split = cdiv(steps, (int)want) * 32;
   const int splits = cdiv(g.T, k_per_split);
-  int rc = split_gemm(1, Mt3, V3, slabs, Clo, g.K4, (int)g.T, (long)g.nM, (long)g.nV, (long)Clo * g.T, (long)g.K4 * g.T,
+  int rc = split_gemm(1, planes, Mt3, V3, slabs, Clo, g.K4, (int)g.T, (long)g.nM, (long)g.nV, (long)Clo * g.T, (long)g.K4 * g.T,
                       (long)Clo * g.K4, g.NX, k_per_split, splits, (long)g.nU, st, "wino_gemm_wgrad_split");
   if (rc) return rc;
   rc = splitk_finish(slabs, dU, nullptr, (long)g.nU, g.K4, splits, 0, st);

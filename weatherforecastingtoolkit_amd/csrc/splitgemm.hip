@@ -48,8 +48,8 @@ struct SgP {
 constexpr int SBM = 256, SBN = 128, SBK = 32, SNT = 512;
 constexpr int A_PLANE_B = SBM * 64;
 constexpr int B_PLANE_B = SBN * 64;   // either image: 128 rows x 64 B or 32 k-rows x 256 B
-constexpr int A_STAGE_B = 3 * A_PLANE_B;
-constexpr int STAGE_B = 3 * (A_PLANE_B + B_PLANE_B);
+// NP planes per operand: 3 = the exact fp32 split (six products per tile), 1 = the h plane alone = bf16-rounded operands
+// with fp32 accumulation (torch's 'medium' matmul precision; one product per tile, operands 2 bytes per element)
 
 __device__ __forceinline__ unsigned off_row(int r, int c) { return (unsigned)(r * 64 + ((c ^ ((r >> 2) & 3)) << 4)); }
 __device__ __forceinline__ unsigned off_tr(int k, int ch) {
@@ -59,8 +59,11 @@ __device__ __forceinline__ unsigned off_tr(int k, int ch) {
 // DMA: operand tiles go from global memory straight into the LDS stage (global_load_lds_dwordx4: no staging registers, no
 // ds_write instructions); a wave-instruction fills 1 KiB of LDS lane-linearly, so every lane loads the 16-byte chunk that
 // the swizzled image keeps at its position.
-template <int BKIND, int DBG = 0, bool DMA = false>
+template <int BKIND, int DBG = 0, bool DMA = false, int NP = 3>
 __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
+  static_assert(NP == 3 || (NP == 1 && !DMA && DBG == 0), "one plane: register-staged loader only");
+  constexpr int A_STAGE_B = NP * A_PLANE_B;
+  constexpr int STAGE_B = NP * (A_PLANE_B + B_PLANE_B);
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // XCD-aware placement.  Workgroups go round-robin over the 8 XCDs in launch order (x fastest, then y, z), each XCD
@@ -108,10 +111,10 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
     b_dst = a_dst;
     b_step = SBK;
   }
-  u32x4 ra[3][2], rb[3];
+  u32x4 ra[NP][2], rb[NP];
   auto load_global = [&]() {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < NP; ++pl) {
       ra[pl][0] = *reinterpret_cast<const u32x4*>(a_src0 + pl * p.a_plane);
       ra[pl][1] = *reinterpret_cast<const u32x4*>(a_src1 + pl * p.a_plane);
       rb[pl] = *reinterpret_cast<const u32x4*>(b_src + pl * p.b_plane);
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
   auto store_lds = [&](int buf) {
     unsigned char* s = smem + buf * STAGE_B;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < NP; ++pl) {
       *reinterpret_cast<u32x4*>(s + pl * A_PLANE_B + a_dst) = ra[pl][0];
       *reinterpret_cast<u32x4*>(s + pl * A_PLANE_B + a_dst + 128 * 64) = ra[pl][1];
       *reinterpret_cast<u32x4*>(s + A_STAGE_B + pl * B_PLANE_B + b_dst) = rb[pl];
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
 
   // fragments of one 16-deep k-slab: 2 x 3 A rows-of-planes and 2 x 3 B ones (48 registers)
   struct Frag {
-    bf16x8 a[2][3], b[2][3];
+    bf16x8 a[2][NP], b[2][NP];
   };
   auto read_frag = [&](Frag& f, int buf, int ks) {
     const unsigned char* s = smem + buf * STAGE_B;
@@ -161,13 +164,13 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < NP; ++pl)
         f.a[i][pl] = *reinterpret_cast<const bf16x8*>(s + pl * A_PLANE_B + a_rd + i * (32 * 64) + a_c);
     if constexpr (BKIND == 0) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NP; ++pl) {
           s16x4 part[2];
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf) {
@@ -184,17 +187,19 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
           f.b[j][pl] = *reinterpret_cast<const bf16x8*>(s + A_STAGE_B + pl * B_PLANE_B + b_rd_row + j * (32 * 64) + a_c);
     }
   };
   auto mfma_tile = [&](const Frag& f, int i, int j) {
     f32x16 c = acc[i][j];   // smallest terms first
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][2], f.b[j][0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][2], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][1], c, 0, 0, 0);
+    if constexpr (NP == 3) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][2], f.b[j][0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][2], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][1], c, 0, 0, 0);
+    }
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][0], c, 0, 0, 0);
     acc[i][j] = c;
   };
@@ -202,16 +207,7 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        f32x16 c = acc[i][j];   // smallest terms first
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][2], f.b[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][0], c, 0, 0, 0);
-        acc[i][j] = c;
-      }
+      for (int j = 0; j < 2; ++j) mfma_tile(f, i, j);
   };
 
   if constexpr (DMA) {
@@ -253,7 +249,7 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
     };
     auto dma_stage = [&](int buf) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) dma_plane(buf, pl);
+      for (int pl = 0; pl < NP; ++pl) dma_plane(buf, pl);
     };
     auto dma_advance = [&](bool more) {
       d_a[0] += more ? SBK : 0;
@@ -367,18 +363,20 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
     }
 }
 
-__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, unsigned short* __restrict__ o, long n) {
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, unsigned short* __restrict__ o, long n, int planes) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   unsigned short h, m, l;
   split3(x[i], h, m, l);
   o[i] = h;
-  o[n + i] = m;
-  o[2 * n + i] = l;
+  if (planes == 3) {
+    o[n + i] = m;
+    o[2 * n + i] = l;
+  }
 }
 
 template <int BKIND>
-int launch_sgemm3(SgP& p, int batches, int splits, hipStream_t st, const char* what) {
+int launch_sgemm3(SgP& p, int planes, int batches, int splits, hipStream_t st, const char* what) {
   p.mtiles = cdiv(p.M, SBM);
   const long tiles = (long)p.mtiles * cdiv(p.N, SBN);
   WFAE_REQUIRE(tiles < (1l << 31) && batches <= 65535 && splits <= 65535, WFAE_ERR_BAD_SHAPE, "%s: grid too large", what);
@@ -387,6 +385,10 @@ int launch_sgemm3(SgP& p, int batches, int splits, hipStream_t st, const char* w
   // nor the ds_write instructions are what the kernel waits for — PMC: matrix pipe busy 0.59 at a clock of 1.67 GHz
   // (the fp32 MFMA GEMM: 0.75 at 2.11 GHz; the chip gives clock back under bf16 MFMA load).
   static const int dma = getenv("WFAE_SPLIT_DMA") ? atoi(getenv("WFAE_SPLIT_DMA")) : 0;
+  if (planes == 1) {
+    hipLaunchKernelGGL((sgemm3_kernel<BKIND, 0, false, 1>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
+    return check_launch(what);
+  }
   static const int dbg = getenv("WFAE_SPLIT_DBG") ? atoi(getenv("WFAE_SPLIT_DBG")) : 0;   // timing probes, wrong results
   if (dbg == 1) hipLaunchKernelGGL((sgemm3_kernel<BKIND, 1>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
   else if (dbg == 3) hipLaunchKernelGGL((sgemm3_kernel<BKIND, 3>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
@@ -402,9 +404,10 @@ int launch_sgemm3(SgP& p, int batches, int splits, hipStream_t st, const char* w
 namespace wfae {
 
 // C[y] (M x N) = A[y] (M x K, rows) * B[y]; kind 0: B is K x N (N contiguous), kind 1: B is N x K (K contiguous)
-int split_gemm(int kind, const unsigned short* A, const unsigned short* B, float* C, int M, int N, int K, long a_plane,
-               long b_plane, long a_y, long b_y, long c_y, int batches, int k_per_split, int splits, long c_split,
-               hipStream_t st, const char* what) {
+int split_gemm(int kind, int planes, const unsigned short* A, const unsigned short* B, float* C, int M, int N, int K,
+               long a_plane, long b_plane, long a_y, long b_y, long c_y, int batches, int k_per_split, int splits,
+               long c_split, hipStream_t st, const char* what) {
+  WFAE_REQUIRE(planes == 1 || planes == 3, WFAE_ERR_BAD_SHAPE, "%s: planes must be 3 (exact fp32 split) or 1 (bf16 operands)", what);
   WFAE_REQUIRE(K % SBK == 0 && k_per_split % SBK == 0 && (kind == 1 || N % 8 == 0) && M > 0 && N >= 8, WFAE_ERR_UNSUPPORTED,
                "%s: the split GEMM needs K %% 32 == 0 and 16-byte operand rows", what);
   SgP p = {};
@@ -414,28 +417,28 @@ int split_gemm(int kind, const unsigned short* A, const unsigned short* B, float
   p.M = M; p.N = N; p.K = K;
   p.lda = K; p.ldb = kind == 0 ? N : K; p.ldc = N;
   p.k_per_split = k_per_split;
-  return kind == 0 ? launch_sgemm3<0>(p, batches, splits, st, what) : launch_sgemm3<1>(p, batches, splits, st, what);
+  return kind == 0 ? launch_sgemm3<0>(p, planes, batches, splits, st, what) : launch_sgemm3<1>(p, planes, batches, splits, st, what);
 }
 
 }  // namespace wfae
 
 extern "C" {
 
-int wfae_split_bf16x3(const float* x, uint16_t* planes, int64_t n, wfae_stream_t stream) {
-  WFAE_REQUIRE(x && planes, WFAE_ERR_NULL_POINTER, "split_bf16x3: null pointer");
-  WFAE_REQUIRE(n > 0 && n < (1ll << 39), WFAE_ERR_BAD_SHAPE, "split_bf16x3: bad size");
-  hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, planes, (long)n);
+int wfae_split_bf16x3(const float* x, uint16_t* out, int64_t n, int planes, wfae_stream_t stream) {
+  WFAE_REQUIRE(x && out, WFAE_ERR_NULL_POINTER, "split_bf16x3: null pointer");
+  WFAE_REQUIRE(n > 0 && n < (1ll << 39) && (planes == 1 || planes == 3), WFAE_ERR_BAD_SHAPE, "split_bf16x3: bad size / planes");
+  hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, (long)n, planes);
   return check_launch("split_bf16x3");
 }
 
-int wfae_split_gemm(int b_kind, const uint16_t* A3, const uint16_t* B3, float* C, int M, int N, int K, int batches,
+int wfae_split_gemm(int b_kind, int planes, const uint16_t* A3, const uint16_t* B3, float* C, int M, int N, int K, int batches,
                     wfae_stream_t stream) {
   WFAE_REQUIRE(A3 && B3 && C, WFAE_ERR_NULL_POINTER, "split_gemm: null pointer");
   WFAE_REQUIRE((b_kind == 0 || b_kind == 1) && M > 0 && N > 0 && K > 0 && batches > 0, WFAE_ERR_BAD_SHAPE, "split_gemm: bad shape");
   WFAE_REQUIRE(((reinterpret_cast<uintptr_t>(A3) | reinterpret_cast<uintptr_t>(B3)) & 15) == 0, WFAE_ERR_BAD_SHAPE,
                "split_gemm: operands must be 16-byte aligned");
   const long na = (long)batches * M * K, nb = (long)batches * K * N;
-  return split_gemm(b_kind, A3, B3, C, M, N, K, na, nb, (long)M * K, (long)K * N, (long)M * N, batches, K, 1, 0,
+  return split_gemm(b_kind, planes, A3, B3, C, M, N, K, na, nb, (long)M * K, (long)K * N, (long)M * N, batches, K, 1, 0,
                     (hipStream_t)stream, "split_gemm");
 }
 

@@ -74,8 +74,10 @@ __device__ __forceinline__ void put_operand(void* __restrict__ base, long idx, l
     split3(v, h, m, l);
     unsigned short* __restrict__ o = static_cast<unsigned short*>(base) + idx;
     o[0] = h;
-    o[plane] = m;
-    o[2 * plane] = l;
+    if (plane) {   // plane == 0: the h plane alone (bf16-rounded operands, 'medium' precision)
+      o[plane] = m;
+      o[2 * plane] = l;
+    }
   }
 }
 
@@ -104,7 +106,7 @@ __device__ __forceinline__ bool tile_of_thread(int C, int Timg, long T, int& c, 
 // hi (N,Chi,2Hlo,2Wlo) -> V[N*N][4Chi][T]
 template <typename WV, bool SPLIT = false>
 __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ hi, void* __restrict__ V, int Chi,
-                                                      int Hlo, int Wlo, long T) {
+                                                      int Hlo, int Wlo, long T, int planes = 3) {
   constexpr int N = WV::N, M = WV::M, PSZ = 2 * N;
   const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
   int h, n, tl;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 #pragma unroll
       for (int u = 0; u < N; ++u)
 #pragma unroll
-        for (int w = 0; w < N; ++w) put_operand<SPLIT>(V, dst + (long)(u * N + w) * xi_stride, (long)(N * N) * xi_stride, v[u][w]);
+        for (int w = 0; w < N; ++w) put_operand<SPLIT>(V, dst + (long)(u * N + w) * xi_stride, planes == 3 ? (long)(N * N) * xi_stride : 0, v[u][w]);
     }
   }
 }
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 // adjoint of wino_out: lo (N,Clo,Hlo,Wlo) -> Mt[N*N][Clo][T]:  Mt = A Y A^T
 template <typename WV, bool SPLIT = false>
 __global__ __launch_bounds__(256) void wino_out_t_kernel(const float* __restrict__ lo, void* __restrict__ Mt, int Clo,
-                                                         int Hlo, int Wlo, long T) {
+                                                         int Hlo, int Wlo, long T, int planes = 3) {
   constexpr int N = WV::N, M = WV::M;
   const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
   int l, n, tl;
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256) void wino_out_t_kernel(const float* __restrict
 #pragma unroll
   for (int u = 0; u < N; ++u)
 #pragma unroll
-    for (int v = 0; v < N; ++v) put_operand<SPLIT>(Mt, dst + (long)(u * N + v) * xi_stride, (long)(N * N) * xi_stride, m[u][v]);
+    for (int v = 0; v < N; ++v) put_operand<SPLIT>(Mt, dst + (long)(u * N + v) * xi_stride, planes == 3 ? (long)(N * N) * xi_stride : 0, m[u][v]);
 }
 
 // w (Clo,Chi,4,4) -> U[N*N][Clo][4Chi]:  U = G g G^T per phase, g[a][b] = w[2a+p][2b+q]
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256) void wino_out_t_kernel(const float* __restrict
 // threads own consecutive lo channels
 template <typename WV, bool SPLIT = false, bool TRANSPOSED = false>
 __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, void* __restrict__ U, int Clo,
-                                                           int Chi) {
+                                                           int Chi, int planes = 3) {
   constexpr int N = WV::N;
   const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i0 >= (long)Clo * Chi) return;
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
 #pragma unroll
       for (int a = 0; a < N; ++a)
 #pragma unroll
-        for (int b = 0; b < N; ++b) put_operand<SPLIT>(U, dst + (long)(a * N + b) * xi_stride, (long)(N * N) * xi_stride, u[a][b]);
+        for (int b = 0; b < N; ++b) put_operand<SPLIT>(U, dst + (long)(a * N + b) * xi_stride, planes == 3 ? (long)(N * N) * xi_stride : 0, u[a][b]);
     }
 }
 
@@ -523,31 +525,32 @@ int wino_in(int variant, const float* hi, float* V, int NB, int Chi, int Hlo, in
   return check_launch("wino_in");
 }
 // the *_split forms write the three bf16 planes of splitgemm.hip (plane stride = the operand's element count)
-int wino_in_split(int variant, const float* hi, unsigned short* V3, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
+int wino_in_split(int variant, const float* hi, unsigned short* V3, int planes, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
   const int M = variant ? 4 : 2;
   const long T = (long)NB * (Hlo / M) * (Wlo / M);
   const dim3 grid = flat_grid(NB, Chi, Hlo, Wlo, M);
-  if (variant == 0) hipLaunchKernelGGL((wino_in_kernel<W22, true>), grid, dim3(256), 0, st, hi, (void*)V3, Chi, Hlo, Wlo, T);
-  else hipLaunchKernelGGL((wino_in_kernel<W42, true>), grid, dim3(256), 0, st, hi, (void*)V3, Chi, Hlo, Wlo, T);
+  if (variant == 0) hipLaunchKernelGGL((wino_in_kernel<W22, true>), grid, dim3(256), 0, st, hi, (void*)V3, Chi, Hlo, Wlo, T, planes);
+  else hipLaunchKernelGGL((wino_in_kernel<W42, true>), grid, dim3(256), 0, st, hi, (void*)V3, Chi, Hlo, Wlo, T, planes);
   return check_launch("wino_in_split");
 }
-int wino_out_t_split(int variant, const float* lo, unsigned short* Mt3, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
+int wino_out_t_split(int variant, const float* lo, unsigned short* Mt3, int planes, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
   const int M = variant ? 4 : 2;
   const long T = (long)NB * (Hlo / M) * (Wlo / M);
   const dim3 grid = flat_grid(NB, Clo, Hlo, Wlo, M);
-  if (variant == 0) hipLaunchKernelGGL((wino_out_t_kernel<W22, true>), grid, dim3(256), 0, st, lo, (void*)Mt3, Clo, Hlo, Wlo, T);
-  else hipLaunchKernelGGL((wino_out_t_kernel<W42, true>), grid, dim3(256), 0, st, lo, (void*)Mt3, Clo, Hlo, Wlo, T);
+  if (variant == 0) hipLaunchKernelGGL((wino_out_t_kernel<W22, true>), grid, dim3(256), 0, st, lo, (void*)Mt3, Clo, Hlo, Wlo, T, planes);
+  else hipLaunchKernelGGL((wino_out_t_kernel<W42, true>), grid, dim3(256), 0, st, lo, (void*)Mt3, Clo, Hlo, Wlo, T, planes);
   return check_launch("wino_out_t_split");
 }
 // U3 [3][N*N][Clo][4Chi] and its transpose Ut3 [3][N*N][4Chi][Clo]
-int wino_weights_split(int variant, const float* w, unsigned short* U3, unsigned short* Ut3, int Clo, int Chi, hipStream_t st) {
+int wino_weights_split(int variant, const float* w, unsigned short* U3, unsigned short* Ut3, int planes, int Clo, int Chi,
+                       hipStream_t st) {
   const dim3 grid(cdiv((long)Clo * Chi, 256));
   if (variant == 0) {
-    hipLaunchKernelGGL((wino_weights_kernel<W22, true, false>), grid, dim3(256), 0, st, w, (void*)U3, Clo, Chi);
-    hipLaunchKernelGGL((wino_weights_kernel<W22, true, true>), grid, dim3(256), 0, st, w, (void*)Ut3, Clo, Chi);
+    hipLaunchKernelGGL((wino_weights_kernel<W22, true, false>), grid, dim3(256), 0, st, w, (void*)U3, Clo, Chi, planes);
+    hipLaunchKernelGGL((wino_weights_kernel<W22, true, true>), grid, dim3(256), 0, st, w, (void*)Ut3, Clo, Chi, planes);
   } else {
-    hipLaunchKernelGGL((wino_weights_kernel<W42, true, false>), grid, dim3(256), 0, st, w, (void*)U3, Clo, Chi);
-    hipLaunchKernelGGL((wino_weights_kernel<W42, true, true>), grid, dim3(256), 0, st, w, (void*)Ut3, Clo, Chi);
+    hipLaunchKernelGGL((wino_weights_kernel<W42, true, false>), grid, dim3(256), 0, st, w, (void*)U3, Clo, Chi, planes);
+    hipLaunchKernelGGL((wino_weights_kernel<W42, true, true>), grid, dim3(256), 0, st, w, (void*)Ut3, Clo, Chi, planes);
   }
   return check_launch("wino_weights_split");
 }

@@ -265,7 +265,7 @@ def get_float32_matmul_precision():
 
 
 class WinoPlan:
-    __slots__ = ("variant", "nb", "chi", "clo", "hlo", "wlo", "T", "nU", "nV", "nM", "split")
+    __slots__ = ("variant", "nb", "chi", "clo", "hlo", "wlo", "T", "nU", "nV", "nM", "split", "planes")
 
     @property
     def dims(self):
@@ -288,6 +288,7 @@ def _query_plan(variant, key):
     pl.nb, pl.chi, pl.clo, pl.hlo, pl.wlo = key
     pl.T, pl.nU, pl.nV, pl.nM = (int(v) for v in out)
     pl.split = False
+    pl.planes = 3
     return pl
 
 
@@ -320,8 +321,10 @@ def wino_plan(nb, chi, clo, hlo, wlo):
         if mode == "0":
             return None
     key = (nb, chi, clo, hlo, wlo)
-    split = _SPLIT_GEMM and _lib.load().wfae_get_matmul_precision() == 0
-    ck = (mode if mode in ("f22", "f42") else "a", split, key)
+    # split operands: three exact planes at fp32 precision, the bf16 h plane alone at 'medium' precision
+    prec = _lib.load().wfae_get_matmul_precision()
+    split = _SPLIT_GEMM
+    ck = (mode if mode in ("f22", "f42") else "a", split, prec, key)
     pl = _plans.get(ck, False)
     if pl is False:
         if mode == "f22":
@@ -332,6 +335,7 @@ def wino_plan(nb, chi, clo, hlo, wlo):
             pl = _query_plan(1, key) or _query_plan(0, key)
         if pl is not None and split:
             pl.split = bool(_lib.load().wfae_wino_split_supported(pl.variant, *key))
+            pl.planes = 3 if prec == 0 else 1
         _plans[ck] = pl
     return pl
 
@@ -340,37 +344,41 @@ def _buf(n, like):
     return torch.empty(n, dtype=torch.float32, device=like.device)
 
 
-def _buf3(n, like):
-    """a split operand: three planes of bf16 bit patterns, n elements each"""
-    return torch.empty(3 * n, dtype=torch.int16, device=like.device)
+def _buf3(n, like, planes=3):
+    """a split operand: `planes` planes of bf16 bit patterns, n elements each"""
+    return torch.empty(planes * n, dtype=torch.int16, device=like.device)
 
 
-def split_bf16x3(x):
-    """fp32 tensor -> its three bf16 planes (int16 bit patterns, shape (3,) + x.shape): x == h + m + l exactly"""
+def split_bf16x3(x, planes=3):
+    """fp32 tensor -> its three bf16 planes (int16 bit patterns, shape (3,) + x.shape): x == h + m + l exactly;
+    planes=1: the h plane alone (x rounded to bf16)"""
     _chk(x)
-    out = torch.empty((3,) + tuple(x.shape), dtype=torch.int16, device=x.device)
-    _call("wfae_split_bf16x3", 0, 10 * x.numel(), _p(x), out.data_ptr(), x.numel(), _stream())
+    out = torch.empty((planes,) + tuple(x.shape), dtype=torch.int16, device=x.device)
+    _call("wfae_split_bf16x3", 0, (4 + 2 * planes) * x.numel(), _p(x), out.data_ptr(), x.numel(), planes, _stream())
     return out
 
 
 def split_gemm(a3, b3, b_kind=0):
-    """C[y] = A[y] B[y] from split operands: a3 (3, Y, M, K); b3 (3, Y, K, N) for b_kind 0, (3, Y, N, K) for b_kind 1"""
-    _, y, m, k = a3.shape
+    """C[y] = A[y] B[y] from split operands: a3 (P, Y, M, K); b3 (P, Y, K, N) for b_kind 0, (P, Y, N, K) for b_kind 1;
+    P = 3 planes (exact fp32 product) or 1 (bf16-rounded operands)"""
+    planes, y, m, k = a3.shape
     n = b3.shape[3] if b_kind == 0 else b3.shape[2]
     if a3.dtype != torch.int16 or b3.dtype != torch.int16 or not (a3.is_contiguous() and b3.is_contiguous()):
         raise _lib.WfaeError("split_gemm: contiguous int16 plane tensors from split_bf16x3")
     c = torch.empty((y, m, n), dtype=torch.float32, device=a3.device)
-    _call("wfae_split_gemm", 2 * y * m * n * k, 6 * y * k * (m + n) + 4 * y * m * n, b_kind, a3.data_ptr(), b3.data_ptr(), _p(c),
-          m, n, k, y, _stream())
+    if b3.shape[0] != planes:
+        raise _lib.WfaeError("split_gemm: operands with different plane counts")
+    _call("wfae_split_gemm", 2 * y * m * n * k, 2 * planes * y * k * (m + n) + 4 * y * m * n, b_kind, planes, a3.data_ptr(),
+          b3.data_ptr(), _p(c), m, n, k, y, _stream())
     return c
 
 
 def wino_weights(w, pl):
     _chk(w)
     if pl.split:
-        U = _buf3(2 * pl.nU, w)   # U3 then Ut3
-        _call("wfae_wino_weights_split", 0, 4 * w.numel() + 12 * pl.nU, pl.variant, _p(w), U.data_ptr(),
-              U.data_ptr() + 6 * pl.nU, pl.chi, pl.clo, _stream(), label="wfae_wino_weights")
+        U = _buf3(2 * pl.nU, w, pl.planes)   # U3 then Ut3
+        _call("wfae_wino_weights_split", 0, 4 * w.numel() + 4 * pl.planes * pl.nU, pl.variant, _p(w), U.data_ptr(),
+              U.data_ptr() + 2 * pl.planes * pl.nU, pl.planes, pl.chi, pl.clo, _stream(), label="wfae_wino_weights")
         return U
     U = _buf(pl.nU, w)
     _call("wfae_wino_weights", 0, 4 * (w.numel() + pl.nU), pl.variant, _p(w), _p(U), pl.chi, pl.clo, _stream())
@@ -381,9 +389,9 @@ def wino_in(hi, pl):
     """hi-side tensor (N,Chi,2Hlo,2Wlo) -> V[xi][4Chi][T]"""
     _chk(hi)
     if pl.split:
-        V = _buf3(pl.nV, hi)
-        _call("wfae_wino_in_split", 0, 4 * hi.numel() + 6 * pl.nV, pl.variant, _p(hi), V.data_ptr(), pl.nb, pl.chi, pl.hlo,
-              pl.wlo, _stream(), label="wfae_wino_in")
+        V = _buf3(pl.nV, hi, pl.planes)
+        _call("wfae_wino_in_split", 0, 4 * hi.numel() + 2 * pl.planes * pl.nV, pl.variant, _p(hi), V.data_ptr(), pl.planes, pl.nb,
+              pl.chi, pl.hlo, pl.wlo, _stream(), label="wfae_wino_in")
         return V
     V = _buf(pl.nV, hi)
     _call("wfae_wino_in", 0, 4 * (hi.numel() + pl.nV), pl.variant, _p(hi), _p(V), pl.nb, pl.chi, pl.hlo, pl.wlo, _stream())
@@ -394,9 +402,9 @@ def wino_out_t(lo, pl):
     """lo-side tensor (N,Clo,Hlo,Wlo) -> Mt[xi][Clo][T]"""
     _chk(lo)
     if pl.split:
-        Mt = _buf3(pl.nM, lo)
-        _call("wfae_wino_out_t_split", 0, 4 * lo.numel() + 6 * pl.nM, pl.variant, _p(lo), Mt.data_ptr(), pl.nb, pl.clo, pl.hlo,
-              pl.wlo, _stream(), label="wfae_wino_out_t")
+        Mt = _buf3(pl.nM, lo, pl.planes)
+        _call("wfae_wino_out_t_split", 0, 4 * lo.numel() + 2 * pl.planes * pl.nM, pl.variant, _p(lo), Mt.data_ptr(), pl.planes,
+              pl.nb, pl.clo, pl.hlo, pl.wlo, _stream(), label="wfae_wino_out_t")
         return Mt
     Mt = _buf(pl.nM, lo)
     _call("wfae_wino_out_t", 0, 4 * (lo.numel() + pl.nM), pl.variant, _p(lo), _p(Mt), pl.nb, pl.clo, pl.hlo, pl.wlo, _stream())
@@ -414,8 +422,8 @@ def wino_down(U, V, pl, stats=False):
     M = _buf(pl.nM, V)
     lo = torch.empty((pl.nb, pl.clo, pl.hlo, pl.wlo), dtype=torch.float32, device=V.device)
     if pl.split:
-        _call("wfae_wino_gemm_down_split", pl.gemm_flops, 6 * (pl.nU + pl.nV) + 4 * pl.nM, pl.variant, U.data_ptr(), V.data_ptr(),
-              _p(M), *pl.dims, _stream(), label="wfae_wino_gemm_down")
+        _call("wfae_wino_gemm_down_split", pl.gemm_flops, 2 * pl.planes * (pl.nU + pl.nV) + 4 * pl.nM, pl.variant, U.data_ptr(),
+              V.data_ptr(), _p(M), pl.planes, *pl.dims, _stream(), label="wfae_wino_gemm_down")
     else:
         _call("wfae_wino_gemm_down", pl.gemm_flops, 4 * (pl.nU + pl.nV + pl.nM), pl.variant, _p(U), _p(V), _p(M), *pl.dims, _stream())
     m = 4 if pl.variant else 2
@@ -439,8 +447,8 @@ def wino_up(U, Mt, pl, stats=False):
     dV = _buf(pl.nV, Mt)
     hi = torch.empty((pl.nb, pl.chi, 2 * pl.hlo, 2 * pl.wlo), dtype=torch.float32, device=Mt.device)
     if pl.split:
-        _call("wfae_wino_gemm_up_split", pl.gemm_flops, 6 * (pl.nU + pl.nM) + 4 * pl.nV, pl.variant, U.data_ptr() + 6 * pl.nU,
-              Mt.data_ptr(), _p(dV), *pl.dims, _stream(), label="wfae_wino_gemm_up")
+        _call("wfae_wino_gemm_up_split", pl.gemm_flops, 2 * pl.planes * (pl.nU + pl.nM) + 4 * pl.nV, pl.variant,
+              U.data_ptr() + 2 * pl.planes * pl.nU, Mt.data_ptr(), _p(dV), pl.planes, *pl.dims, _stream(), label="wfae_wino_gemm_up")
     else:
         _call("wfae_wino_gemm_up", pl.gemm_flops, 4 * (pl.nU + pl.nV + pl.nM), pl.variant, _p(U), _p(Mt), _p(dV), *pl.dims, _stream())
     m = 4 if pl.variant else 2
@@ -461,8 +469,9 @@ def wino_wgrad(Mt, V, dw, pl, accumulate=False):
     _chk(dw)
     if pl.split:
         ws = workspace(min(pl.nU * 4 * 13, max(pl.nU * 4 * 6, 1 << 30)))
-        _call("wfae_wino_gemm_wgrad_split", pl.gemm_flops, 6 * (pl.nV + pl.nM) + 4 * pl.nU, pl.variant, Mt.data_ptr(), V.data_ptr(),
-              _p(dw), *pl.dims, int(accumulate), ws.data_ptr(), ws.numel(), _stream(), label="wfae_wino_gemm_wgrad")
+        _call("wfae_wino_gemm_wgrad_split", pl.gemm_flops, 2 * pl.planes * (pl.nV + pl.nM) + 4 * pl.nU, pl.variant, Mt.data_ptr(),
+              V.data_ptr(), _p(dw), pl.planes, *pl.dims, int(accumulate), ws.data_ptr(), ws.numel(), _stream(),
+              label="wfae_wino_gemm_wgrad")
         return dw
     ws = workspace(pl.nU * 4 * 6)
     _call("wfae_wino_gemm_wgrad", pl.gemm_flops, 4 * (pl.nU + pl.nV + pl.nM), pl.variant, _p(Mt), _p(V), _p(dw), *pl.dims,

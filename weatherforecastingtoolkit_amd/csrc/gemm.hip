@@ -1359,7 +1359,7 @@ int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what,
       }
       return check_launch(what);
     }
-    if constexpr (BKD == B_NCONTIG || BKD == B_KCONTIG) {
+    if constexpr (BKD == B_NCONTIG || BKD == B_KCONTIG || BKD == B_TAPN || BKD == B_TAPK) {
       // fp32 products on the bf16 matrix pipe, operands split in registers (PREC 2): for the MFMA-bound shapes
       static const int split_min_k = env_int("WFAE_SPLIT_MIN_K", 128);
       static const int split_min_m = env_int("WFAE_SPLIT_MIN_M", 64);

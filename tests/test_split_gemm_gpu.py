@@ -135,3 +135,31 @@ def test_winograd_medium_precision_on_one_plane_operands(ops, dev):
         ops.set_split_gemm(True)
     for a, b in zip(res[False], res[True]):
         assert float((a - b).abs().max() / a.abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("nb,cin,cout,h", [(16, 512, 128, 48), (16, 128, 512, 48), (32, 1024, 256, 24), (32, 256, 1024, 24)])
+def test_conv1x1_in_register_split_matches_fp32_accuracy(ops, dev, nb, cin, cout, h):
+    """the generic GEMM kernel with the operands split in registers (gemm_kernel PREC 2: K >= 128, M >= 64): forward, data
+    gradient and weight gradient of the 1x1 convolution against fp64 — within 1.5x of the fp32-MFMA kernel's error"""
+    g = torch.Generator().manual_seed(cin + cout)
+    x = (torch.rand(nb, cin, h, h, generator=g) - 0.5).to(dev)
+    w = ((torch.rand(cout, cin, 1, 1, generator=g) - 0.5) * 0.1).to(dev)
+    dy = (torch.rand(nb, cout, h, h, generator=g) - 0.5).to(dev)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr)
+    ref.backward(dy.double())
+    res = {}
+    try:
+        for split in (False, True):
+            ops.set_split_gemm(split)
+            dw = torch.empty_like(w)
+            ops.conv1x1_bwd_weight(dy, x, dw)
+            res[split] = (ops.conv1x1_fwd(x, w), ops.conv1x1_bwd_data(dy, w), dw)
+    finally:
+        ops.set_split_gemm(True)
+    for i, r64 in enumerate((ref.detach(), xr.grad, wr.grad)):
+        rms = float(r64.pow(2).mean().sqrt())
+        e_f32 = float((res[False][i].double() - r64).abs().max()) / rms
+        e_split = float((res[True][i].double() - r64).abs().max()) / rms
+        assert e_split <= 1.5 * e_f32 + 1e-7, (i, e_split, e_f32)
+        assert not torch.equal(res[False][i], res[True][i]), "the split path did not run"

@@ -275,6 +275,8 @@ int wfae_wino_gemm_wgrad(int variant, const float* Mt, const float* V, float* dw
  * the GEMM outputs stay fp32 and go through wino_out / wino_in_t / the G^T dU G reduction unchanged.
  *   wino_weights_split: U3 [3][xi][Clo][4Chi] and Ut3 [3][xi][4Chi][Clo] (the up product contracts over Clo)
  *   wino_in_split / wino_out_t_split: V3 [3][xi][4Chi][T], Mt3 [3][xi][Clo][T]
+ * Range: the split is exact for |x| in [2^-110, 3.3e38) (below, the l plane loses bits to bf16's underflow — the absolute
+ * error stays under 2^-133; above, bf16(x) rounds to infinity); NaN and infinities propagate as NaN.
  * `planes` = 3: the exact split above.  `planes` = 1: only the h plane is written / read — bf16-rounded operands with
  * fp32 accumulation, i.e. WFAE_PRECISION_BF16's arithmetic with 2-byte operand storage for the matrix work (one MFMA
  * product per tile; the GEMMs turn HBM-bound).  Buffers hold `planes` planes.

@@ -177,3 +177,41 @@ def test_ae_step_bf16_tracks_fp32(medium, dev):
     d = (r_bf - r_fp).abs()
     assert float(d.mean()) < 2e-2 and float(d.max()) < 0.15, (float(d.mean()), float(d.max()))
     assert l_bf[-1] < 0.9 * l_bf[0] and abs(l_bf[-1] - l_fp[-1]) / l_fp[-1] < 0.1, (l_bf, l_fp)
+
+
+def test_gan_step_384_medium_tracks_fp32(dev):
+    """BASELINE config 5's shape on one card: the AE+GAN step of experiments/ae_v2_2 at 384x384 (B = 4, discriminator
+    active) at 'medium' precision — bf16 MFMA operands, the Winograd products on 2-byte operand planes — against the same
+    step in fp32 from the same weights: reconstruction and discriminator losses, logits and both gradient norms of the
+    first step agree to bf16-operand noise, and three steps move the losses the same way"""
+    import os
+    import weatherforecastingtoolkit_amd as pkg
+    import weatherforecastingtoolkit_amd.experiments.ae_v2_2 as exp
+    from weatherforecastingtoolkit_amd import config as C, synth
+    from weatherforecastingtoolkit_amd.experiments.ae_v2_2.train import CARRIED_KEYS, Model
+    x = torch.from_numpy(synth.uniform_frames(4, 384, seed=77)).to(dev)
+    out = {}
+    try:
+        for prec in ("highest", "medium"):
+            pkg.set_float32_matmul_precision(prec)
+            cfg = C.load(os.path.join(os.path.dirname(exp.__file__), "config.yaml"), CARRIED_KEYS)
+            cfg.trainer.total_train_steps = 1000
+            cfg.lpips.disc_start = 0
+            torch.manual_seed(0)
+            model = Model(cfg, img_size=384).to(dev).train()
+            model.configure_optimizers()
+            logs = []
+            for i in range(3):
+                _, lg = model.training_step({"vil": x}, i)
+                logs.append({k: float(v) for k, v in lg.items()})
+            out[prec] = logs
+    finally:
+        pkg.set_float32_matmul_precision("highest")
+    f0, m0 = out["highest"][0], out["medium"][0]
+    for k in ("train/rec_loss", "train/disc_loss", "train/g_grad_norm", "train/d_grad_norm"):
+        assert k in f0 and k in m0, (k, sorted(f0))
+        assert abs(m0[k] - f0[k]) <= 3e-2 * abs(f0[k]) + 1e-4, (k, m0[k], f0[k])
+    for k in ("train/logits_real", "train/logits_fake"):
+        assert abs(m0[k] - f0[k]) <= 3e-2 * max(abs(f0[k]), 0.1), (k, m0[k], f0[k])
+    f2, m2 = out["highest"][2], out["medium"][2]
+    assert abs(m2["train/rec_loss"] - f2["train/rec_loss"]) <= 3e-2 * f2["train/rec_loss"]

@@ -306,17 +306,30 @@ __global__ __launch_bounds__(RT) void bn_act_bwd_reduce_kernel(const float* __re
     long i = beg + (long)threadIdx.x * 4;
     long o = i / g.inner;
     long in = i - o * g.inner;
-    for (; i < end; i += RT * 4) {
-      const long off = (o * g.C + c) * g.inner + in;
-      const float4 xv = *reinterpret_cast<const float4*>(x + off);
-      const float4 dv = *reinterpret_cast<const float4*>(dy + off);
-      const float d0 = dv.x * act_grad_f<ACT>(fmaf(xv.x, a, b)), d1 = dv.y * act_grad_f<ACT>(fmaf(xv.y, a, b));
-      const float d2 = dv.z * act_grad_f<ACT>(fmaf(xv.z, a, b)), d3 = dv.w * act_grad_f<ACT>(fmaf(xv.w, a, b));
+    // two chunks per iteration, all four loads issued before the arithmetic (the fp64 accumulation chain kept the compiler
+    // from overlapping iterations: 5.2 TB/s against 6.1 of the dx pass); sums are added in the same order as one chunk
+    // per iteration would, a missing second chunk re-reads the first and is multiplied by zero
+    auto quad = [&](const float4& xv, const float4& dv, float m) {
+      const float d0 = m * dv.x * act_grad_f<ACT>(fmaf(xv.x, a, b)), d1 = m * dv.y * act_grad_f<ACT>(fmaf(xv.y, a, b));
+      const float d2 = m * dv.z * act_grad_f<ACT>(fmaf(xv.z, a, b)), d3 = m * dv.w * act_grad_f<ACT>(fmaf(xv.w, a, b));
       s1 += (double)((d0 + d1) + (d2 + d3));
       const float h0 = (xv.x - mu) * is, h1 = (xv.y - mu) * is, h2 = (xv.z - mu) * is, h3 = (xv.w - mu) * is;
       s2 += (double)(fmaf(d0, h0, d1 * h1) + fmaf(d2, h2, d3 * h3));
+    };
+    for (; i < end; i += 2 * RT * 4) {
+      const long off0 = (o * g.C + c) * g.inner + in;
       in += RT * 4;
       while (in >= g.inner) { in -= g.inner; ++o; }
+      const bool two = i + RT * 4 < end;
+      const long off1 = two ? (o * g.C + c) * g.inner + in : off0;
+      in += RT * 4;
+      while (in >= g.inner) { in -= g.inner; ++o; }
+      const float4 xv0 = *reinterpret_cast<const float4*>(x + off0);
+      const float4 dv0 = *reinterpret_cast<const float4*>(dy + off0);
+      const float4 xv1 = *reinterpret_cast<const float4*>(x + off1);
+      const float4 dv1 = *reinterpret_cast<const float4*>(dy + off1);
+      quad(xv0, dv0, 1.f);
+      if (two) quad(xv1, dv1, 1.f);
     }
   } else {
     for (long i = beg + threadIdx.x; i < end; i += RT) {

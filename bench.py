@@ -271,10 +271,11 @@ def main():
                                    "fwd + L1 + bwd + AdamW + cosine-warmup LR",
                        "batch_per_gpu": B, "global_batch": B * world, "img_size": S,
                        "parallelism": f"dp{world}", "params": sum(p.numel() for p in net.parameters()),
-                       "matmul": ("fp32 tensors, fp32 accumulation; the Winograd-domain GEMMs of the 4x4 stride-2 layers "
-                                  "multiply on the bf16 matrix pipe with every fp32 operand carried EXACTLY as three bf16 "
-                                  "planes (six products per fp32 product: error vs fp64 that of the fp32 MFMA kernels, "
-                                  "tests/test_split_gemm_gpu.py); every other GEMM on v_mfma_f32_32x32x2_f32"
+                       "matmul": ("fp32 tensors, fp32 accumulation; the MFMA-bound GEMMs (Winograd-domain products of the 4x4 "
+                                  "stride-2 layers, 1x1 convolutions with K >= 128) multiply on the bf16 matrix pipe with "
+                                  "every fp32 operand carried EXACTLY as three bf16 values (six products per fp32 product: "
+                                  "error vs fp64 that of the fp32 MFMA kernels, tests/test_split_gemm_gpu.py); the other "
+                                  "GEMMs on v_mfma_f32_32x32x2_f32; see fp32_mfma_only for the step without the split"
                                   if args.precision == "highest" and ops.split_gemm_enabled() else
                                   "v_mfma_f32_32x32x2_f32 everywhere" if args.precision == "highest" else
                                   "bf16-rounded MFMA operands")},

@@ -237,6 +237,15 @@ def main(argv=None):
                 dp.sync.broadcast_(a.flat_p, 0)
     stop_at = total if args.stop_after < 0 else min(total, args.stop_after)
     t0, done = time.time(), 0
+    pending = []   # per-step scalars are read one step late, when they are long finished (no stall of the launch queue)
+
+    def flush_logs():
+        while pending:
+            step_, logs_, lr_, n_ = pending.pop(0)
+            rec = {k: float(v) for k, v in logs_.items()}
+            rec.update(step=step_, lr=lr_, frames_per_s=n_ * cfg.dataset.batch_size * world / (time.time() - t0))
+            print(json.dumps(rec), flush=True)
+
     while model.global_step < stop_at:
         first = (model.global_step * accum) % max(1, len(loader))
         for i in range(first, len(loader)):
@@ -245,10 +254,9 @@ def main(argv=None):
             _, logs = model.training_step(loader[i], i)
             done += 1
             if rank == 0 and done % max(1, cfg.trainer.log_every_n_steps) == 0:
-                rec = {k: float(v) for k, v in logs.items()}
-                rec.update(step=model.global_step, lr=model.g_opt.param_groups[0]["lr"],
-                           frames_per_s=done * cfg.dataset.batch_size * world / (time.time() - t0))
-                print(json.dumps(rec), flush=True)
+                flush_logs()
+                pending.append((model.global_step, logs, model.g_opt.param_groups[0]["lr"], done))
+    flush_logs()
     for dp in model._dp:
         dp.sync_buffers()                # collectives (one broadcast per BatchNorm buffer): every rank takes part
     if rank == 0:

@@ -21,6 +21,14 @@ Extra objects in the line:
                 this same command (profiles/pmc_traffic.json) and carries its source
                 tag; it is reported as null + "stale" when the kernel sources have
                 changed since that pass.
+                Entry points that launch the same kernel are added up first (the split-operand
+                Winograd GEMMs: wfae_wino_gemm_down + _up = sgemm3_kernel<B = K x N>), as rocprofv3's
+                per-kernel statistics do; for that kernel `achieved` counts the executed bf16 MFMA
+                work (six products per fp32 product) against the dense bf16 peak and
+                `fp32_equivalent_tflops` the same work counted once.
+  fp32_mfma_only  the same step timed in the same run with WFAE_SPLIT_GEMM=0 (every GEMM on
+                v_mfma_f32_32x32x2_f32): a side figure, never `value`; config.matmul says which
+                GEMMs the headline runs on the bf16 pipe with exact three-plane operands.
   step_roofline whole-step fractions per SURVEY.md §8(d):
                 fp32_fraction = 938.8 GFLOP/frame * fps / 157.3 TFLOP/s (direct-form FLOPs),
                 executed_flops_fraction = FLOPs the kernels actually execute (Winograd

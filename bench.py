@@ -4,6 +4,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no launcher starts its own N ranks (child processes, before this process
+touches the GPU) and relays rank 0's line; under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
+
 One "step" = forward + L1 loss + backward + (gradient all-reduce) + AdamW + LR
 schedule of ae_64x8x8_lin.PosAwareAE_TF(img_size=384) on a batch of 32
 synthetic SEVIR-shaped frames per GPU (BASELINE.json configs[1]; weak scaling:
@@ -144,6 +147,64 @@ def kernel_source_tag():
     return h.hexdigest()[:16]
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` (N > 1) with no launcher around it: start the N ranks as CHILD processes, one per GPU
+    (RANK = LOCAL_RANK = 0..N-1, rendezvous on 127.0.0.1), relay rank 0's JSON line, return the worst exit status.
+    Runs before anything in this process has imported torch or touched HIP: a process that has initialised the GPU must
+    neither fork ranks nor exec (the reference leaves this to Lightning's launcher, experiments/ae_v2/train.py:332-343)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between processes on this driver
+    base.setdefault("OMP_NUM_THREADS", "4")
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0 owns stdout (the ONE JSON line); the other ranks' stdout goes to stderr so nothing else lands on it
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:       # a rank died: the others would wait in a collective for ever
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def check_launch(args):
+    """--check-launch: the rendezvous of a multi-rank run without the model (CPU test of the self-launcher)"""
+    import torch
+    import torch.distributed as dist
+    from weatherforecastingtoolkit_amd import parallel
+    backend = os.environ.get("WFAE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    rank, world, local = parallel.init_from_env(backend)
+    ones = torch.ones(1, device=torch.device("cuda", local) if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(ones)
+    if rank == 0:
+        print(json.dumps({"check_launch": True, "n_gpus": world, "requested": args.gpus,
+                          "dp": {"ranks_seen": int(ones.item()), "backend": backend if world > 1 else None}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,13 +218,22 @@ def main():
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra fp32-MFMA-only timing (profiling runs)")
     ap.add_argument("--fp32-mfma-only", action="store_true",
                     help="keep the Winograd-domain GEMMs on v_mfma_f32_32x32x2_f32 (no split bf16 operands)")
+    ap.add_argument("--check-launch", action="store_true",
+                    help="rendezvous only: every rank joins the process group, an all-reduce of ones counts them, rank 0 "
+                         "prints {n_gpus, dp.ranks_seen} and exits (no model, no kernels; gloo when there is no GPU)")
     ap.add_argument("--precision", choices=["highest", "medium"], default="highest",
                     help="'medium' = bf16 MFMA operands (BASELINE config 5's arithmetic; NOT the headline "
                          "configuration — the line is then labelled dtype bf16)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process only starts the ranks (it never touches the GPU)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
+    if args.check_launch:
+        return check_launch(args)
     from weatherforecastingtoolkit_amd import functional as Fn, ops, parallel
     from weatherforecastingtoolkit_amd.optim import CosineWarmupLR, FusedAdamW
     from weatherforecastingtoolkit_amd.pipeline.models.ae_64x8x8_lin import PosAwareAE_TF

@@ -45,6 +45,14 @@ typedef enum {
   WFAE_ERR_UNSUPPORTED = -5
 } wfae_status;
 
+/* ABI history (wfae_version() = 100 * major + minor; a caller built against another minor must re-check the entry
+ * points named here):
+ *   100  round 1.
+ *   101  wfae_conv1x1_fwd_stats / wfae_conv1x1_fwd_bnact / wfae_bn_stats_from_rows: `stat_part` changed from float* to
+ *        double* and `stat_capacity` counts DOUBLES (the epilogue sums are reduced in fp64).  A caller built against 100
+ *        would hand over a buffer of half the byte size: check wfae_version() >= 101 before using them.
+ *   102  round 3: wfae_c1gemm_* (1x1 convolutions on the bf16 matrix pipe with exact split operands, fused BatchNorm
+ *        backward epilogues) added; nothing removed. */
 int wfae_version(void);
 const char* wfae_last_error_string(void);
 /* upper bound of scratch bytes any single call needs for a problem whose

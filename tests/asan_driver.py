@@ -106,5 +106,5 @@ expect(lib.wfae_conv4x4s2_down(P, Q, R, 32, 256, 512, 96, 96, None), ANY_FAIL, "
 expect(lib.wfae_conv4x4s2_wgrad(P, Q, R, 32, 256, 512, 96, 96, 0, WS, big, None), ANY_FAIL, "conv4x4s2_wgrad")
 expect(lib.wfae_linear_fwd(P, Q, S, R, 32, 36864, 2048, WS, big, None), ANY_FAIL, "linear_fwd 36864->2048")
 expect(lib.wfae_linear_bwd_weight_splitk(P, Q, R, 2048, 512, 512, 0, WS, big, None), ANY_FAIL, "linear_bwd_weight_splitk")
-assert lib.wfae_version() == 100 and lib.wfae_workspace_bytes(1 << 24) >= (1 << 26)
+assert lib.wfae_version() == 102 and lib.wfae_workspace_bytes(1 << 24) >= (1 << 26)
 print(f"asan driver: {checked} calls, no sanitizer report")

@@ -43,3 +43,24 @@ def test_bench_json_contract(dev):
     assert 0 < sr["executed_flops_fraction"] < sr["fp32_fraction"] * 1.0001
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "warm" in cb["sample"]
+
+
+def test_bench_two_ranks_one_card(dev):
+    """`python bench.py --gpus 2` exactly as the driver calls it — no torch.distributed.run, WORLD_SIZE unset: the parent
+    starts the two ranks itself (before touching the GPU), both run the full step and exchange gradients, rank 0 prints ONE
+    JSON line with the whole-job rate.  Two ranks share this box's single card, so the exchange runs over gloo
+    (WFAE_DIST_BACKEND; RCCL needs a device per rank) — the launch path, the rank bookkeeping and the timing protocol are
+    the ones an 8-GPU node runs."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["WFAE_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--img-size", "128", "--no-fp32-leg"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 4
+    assert d["dp"]["ranks_seen"] == 2 and d["dp"]["backend"] == "gloo" and d["dp"]["grad_exchange_ms_per_step"] > 0
+    assert abs(d["value"] - 2 * 2 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert "cpu_baseline" not in d          # rank 0 at N = 1 only

@@ -55,3 +55,35 @@ def test_single_process_is_identity():
     s = parallel.GradSync()
     t = torch.ones(10)
     assert s.world == 1 and s.allreduce_(t) is t and s.broadcast_(t) is t
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` exactly as the driver calls it (no torch.distributed.run around it, WORLD_SIZE unset):
+    the parent starts two ranks before touching any GPU, they rendezvous (gloo here: no GPU), rank 0 prints ONE JSON
+    line and the parent exits with the ranks' status.  --check-launch stops after the rendezvous (the step itself needs
+    a GPU: tests/test_bench_gpu.py::test_bench_two_ranks_one_card)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["WFAE_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--check-launch"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dp"]["ranks_seen"] == 2 and d["dp"]["backend"] == "gloo"
+
+
+def test_bench_launcher_propagates_a_rank_failure():
+    """a rank that dies must not leave the others waiting in a collective: the parent ends them and returns non-zero"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["WFAE_DIST_BACKEND"] = "no-such-backend"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--check-launch"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -66,3 +66,34 @@ def test_forecaster_on_vit_tokens(dev, tmp_path):
     assert rc == 0
     ck = torch.load(tmp_path / "outputs" / "pretrained_ae_linear_sevir" / "checkpoints" / "last.ckpt", map_location="cpu")
     assert tuple(ck["state_dict"]["predictor.weight"].shape) == (12 * 512, 13 * 512)
+
+
+def test_forecaster_12_in_12_out_on_64x512_latent(dev):
+    """BASELINE configs[3] as stated: 12-in / 12-out frame sequences on the structured [64, 512] latent (64 tokens of
+    512 channels = C 512 on an 8 x 8 latent grid).  The reference script hard-codes 13 / 12
+    (v1_experiments/pretrained_ae_linear_sevir/train.py:67,73-83); the oracle's restatement follows input_frames, so the
+    comparison runs against it directly on seeded latents ("parity unpinned": no reference fixture exists for it)."""
+    from oracle import ae_oracle as orc
+    from weatherforecastingtoolkit_amd import synth
+    from weatherforecastingtoolkit_amd.experiments.v1_experiments.pretrained_ae_linear_sevir.train import Model
+    tin = tout = 12
+    b, c, h, w = 2, 512, 8, 8
+    model = Model(_cfg(tin, tout, c)).to(dev)
+    assert tuple(model.predictor.weight.shape) == (tout * c, tin * c)
+    wt = torch.from_numpy(synth.uniform(11, "lf12/w", (tout * c, tin * c), -0.02, 0.02))
+    bs = torch.from_numpy(synth.uniform(11, "lf12/b", (tout * c,), -0.1, 0.1))
+    with torch.no_grad():
+        model.predictor.weight.copy_(wt)
+        model.predictor.bias.copy_(bs)
+    model.configure_optimizers()
+    v = torch.from_numpy(synth.uniform(11, "lf12/v", (b, tin + tout, c, h, w), -1, 1))
+    wo, bo = wt.clone().requires_grad_(True), bs.clone().requires_grad_(True)
+    oloss, opred = orc.linear_forecast_loss(v, wo, bo, tin)
+    oloss.backward()
+    vd = v.to(dev)
+    assert relerr(model.predict_latents(vd), opred.detach()) < 2e-5
+    loss, _ = model.latent_loss(vd)
+    loss.backward()
+    assert abs(loss.item() - float(oloss)) < 1e-5 * float(oloss)
+    assert relerr(model.predictor.weight.grad, wo.grad) < 2e-5
+    assert relerr(model.predictor.bias.grad, bo.grad) < 2e-5

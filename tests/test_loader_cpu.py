@@ -95,3 +95,26 @@ def test_h5_source_fails_loudly_without_h5py(tmp_path):
         pass
     with pytest.raises(RuntimeError, match="h5py"):
         H5EventSource(str(tmp_path))
+
+
+def test_change_layout_matches_reference_semantics():
+    """every (in_layout, out_layout) pair of the reference's change_layout_torch (sevire/sevir.py:98-139): the result
+    must have the shape / values the reference's permute + unsqueeze chain gives (restated here case by case on a tensor
+    whose elements encode their own NHWT index, so any axis mix-up shows)"""
+    import torch
+    from weatherforecastingtoolkit_amd.pipeline.datasets.sevire.sevir import LAYOUTS, change_layout_torch
+    n, h, w, t = 2, 3, 4, 5
+    base = torch.arange(n * h * w * t, dtype=torch.float32).view(n, h, w, t)      # 'NHWT'
+    want = {"NHWT": base, "NTHW": base.permute(0, 3, 1, 2), "NTCHW": base.permute(0, 3, 1, 2).unsqueeze(2),
+            "NTHWC": base.permute(0, 3, 1, 2).unsqueeze(-1), "TNHW": base.permute(3, 0, 1, 2),
+            "TNCHW": base.permute(3, 0, 1, 2).unsqueeze(2)}
+    assert set(want) == set(LAYOUTS)
+    for i, src in want.items():
+        for o, dst in want.items():
+            got = change_layout_torch(src, i, o)
+            assert got.shape == dst.shape and torch.equal(got, dst), (i, o)
+            assert change_layout_torch(src, i, o, ret_contiguous=True).is_contiguous()
+    with pytest.raises(NotImplementedError):
+        change_layout_torch(base, "NHWT", "NCHW")
+    with pytest.raises(NotImplementedError):
+        SEVIRFrameLoader(np.zeros((1, 4, 4, 3), np.uint8), 1, layout="NCHW")

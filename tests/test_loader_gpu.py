@@ -46,3 +46,19 @@ def test_train_script_on_file_backed_events(dev, tmp_path):
     rc = train.main(["--model", "lin", "--max-steps", "3", "--data-dir", str(root), f"experiment_path={tmp_path}",
                      "dataset.batch_size=4"])
     assert rc == 0
+
+
+@pytest.mark.parametrize("layout", ["NHWT", "NTHW", "NTCHW", "NTHWC", "TNHW", "TNCHW"])
+def test_loader_layouts(dev, layout):
+    """sequence batches (seq_len > 1) in every out_layout of the reference's change_layout_torch
+    (sevire/sevir.py:98-139; Path-B reads 'NTCHW' sequences): bit-exact against (1/255) * u8 re-laid out on the host"""
+    from weatherforecastingtoolkit_amd import synth
+    from weatherforecastingtoolkit_amd.pipeline.datasets.sevire.sevir import SEVIRFrameLoader, change_layout_torch
+    ev = synth.blob_events(2, 32, 25, seed=3)
+    ld = SEVIRFrameLoader(ev, 3, seq_len=24, stride=1, layout=layout, device=dev)
+    u8 = torch.from_numpy(ld.batch_u8(0).astype(np.float32) * np.float32(1 / 255))      # (B, H, W, T)
+    want = change_layout_torch(u8, "NHWT", layout)
+    got = ld[0]["vil"]
+    assert got.shape == want.shape and torch.equal(got.cpu(), want)
+    pre = next(iter(ld.prefetch(1)))["vil"]
+    assert torch.equal(pre, got)

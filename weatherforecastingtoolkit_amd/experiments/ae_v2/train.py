@@ -159,17 +159,26 @@ class Model(tnn.Module):
 
 def _mean_logs(rows, world):
     """epoch mean of per-step scalar logs (Lightning on_epoch=True), averaged over ranks (sync_dist=True)"""
+    if world > 1:
+        # every rank enters the same collectives even when its shard of the loader was empty (ranks would otherwise wait
+        # for ever): the key set is agreed first, then sums and counts travel together
+        import torch.distributed as dist
+        gathered = [None] * world
+        dist.all_gather_object(gathered, sorted({k for r in rows for k in r}))
+        keys = sorted({k for ks in gathered for k in ks})
+        if not keys:
+            return {}
+        t = torch.tensor([[sum(float(r[k]) for r in rows if k in r) for k in keys],
+                          [float(sum(1 for r in rows if k in r)) for k in keys]], dtype=torch.float64).cuda()
+        dist.all_reduce(t)
+        t = t.cpu()
+        # mean over the rows of all ranks (= the mean of the rank means of sync_dist=True when the shards are equal; a rank
+        # without rows contributes nothing)
+        return {k: float(t[0, i] / max(1.0, float(t[1, i]))) for i, k in enumerate(keys)}
     if not rows:
         return {}
     keys = sorted({k for r in rows for k in r})
-    vals = torch.tensor([sum(float(r[k]) for r in rows if k in r) / max(1, sum(1 for r in rows if k in r)) for k in keys],
-                        dtype=torch.float64)
-    if world > 1:
-        import torch.distributed as dist
-        t = vals.cuda()
-        dist.all_reduce(t)
-        vals = (t / world).cpu()
-    return {k: float(v) for k, v in zip(keys, vals)}
+    return {k: sum(float(r[k]) for r in rows if k in r) / max(1, sum(1 for r in rows if k in r)) for k in keys}
 
 
 def evaluate(model, loader, split, limit, world):
@@ -197,7 +206,8 @@ def save_checkpoint(path, model, epoch):
     tmp = path + ".tmp"
     torch.save({"state_dict": sd, "global_step": model.global_step, "epoch": epoch,
                 "optimizer_states": [model.opt.state_dict()], "lr_schedulers": [model.sched.state_dict()],
-                "rng": {"torch_seed": torch.initial_seed(), "dropout_counter": Fn._seed_counter[0]}}, tmp)
+                "rng": {"torch_seed": torch.initial_seed(), "dropout_counter": Fn._seed_counter[0],
+                        "torch_state": torch.get_rng_state(), "cuda_state": torch.cuda.get_rng_state()}}, tmp)
     os.replace(tmp, path)
 
 
@@ -217,6 +227,9 @@ def load_checkpoint(path, model):
     rng = ck.get("rng")
     if rng:
         torch.manual_seed(rng["torch_seed"])
+        if rng.get("torch_state") is not None:      # the generators continue where the interrupted run stopped
+            torch.set_rng_state(rng["torch_state"])
+            torch.cuda.set_rng_state(rng["cuda_state"])
         Fn._seed_counter[0] = rng["dropout_counter"]
     return int(ck.get("epoch", 0))
 
@@ -340,19 +353,19 @@ def main(argv=None):
                 flush_logs()
                 pending.append((step, logs, opt.param_groups[0]["lr"], t_steps))
             if step % save_every == 0 and step < stop_at:
-                dp.sync_buffers()                                             # collective: every rank
+                dp.sync_buffers(model)                                             # collective: every rank
                 if rank == 0:
                     save_checkpoint(last, model, epoch)
         flush_logs()
         if model.global_step % max(1, nb) == 0 or model.global_step >= total_steps:
             # Lightning runs the validation loop at the end of every training epoch
-            dp.sync_buffers()
+            dp.sync_buffers(model)
             vlog = evaluate(model, val_loader, "val", cfg.trainer.limit_val_batches, world)
             if rank == 0 and vlog.get("batches"):
                 vlog.update(step=model.global_step, epoch=epoch)
                 print(json.dumps(vlog), flush=True)
     flush_logs()
-    dp.sync_buffers()                    # a collective (one broadcast per BatchNorm buffer): every rank takes part
+    dp.sync_buffers(model)                    # a collective (one broadcast per BatchNorm buffer): every rank takes part
     if args.test:
         tlog = evaluate(model, test_loader, "test", cfg.trainer.limit_test_batches, world)
         if rank == 0:

@@ -658,7 +658,9 @@ def bn_act_fwd_stats(x, st, act=1):
     _chk(x)
     nb, c, h, wd = x.shape
     y = torch.empty_like(x)
-    cap = 2 * c * nb * max(1, min(1024, (h * wd + 4095) // 4096 + 1))
+    # the library's split count per (image, channel): cdiv(HW / 4 if HW % 4 == 0 else HW, 1024) clamped to 1..1024
+    hw = h * wd
+    cap = 2 * c * nb * max(1, min(1024, ((hw // 4 if hw % 4 == 0 else hw) + 1023) // 1024))
     part = torch.empty(cap, dtype=torch.float64, device=x.device)
     splits = ctypes.c_int(0)
     _call("wfae_bn_act_fwd_stats", 0, 8 * x.numel(), _p(x), _p(st.scale), _p(st.shift), _p(y), nb, c, h * wd, act,

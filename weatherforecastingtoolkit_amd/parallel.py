@@ -28,6 +28,10 @@ def init_from_env(backend=None):
         return 0, 1, 0
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
     if not dist.is_initialized():
+        # SURVEY.md 8(e) "Determinism": the sum order of an all-reduce is fixed by the algorithm (ring order and chunking)
+        # and by the bucket sequence.  Buckets are fixed-size slices of ONE flat arena walked in address order (GradSync),
+        # and the RCCL algorithm is pinned here unless the caller chose one, so the same ranks give the same sums run to run.
+        os.environ.setdefault("NCCL_ALGO", "Ring")
         if backend is None:
             # WFAE_DIST_BACKEND=gloo: several ranks sharing one card (rehearsals on a 1-GPU box; RCCL needs a device per rank)
             backend = os.environ.get("WFAE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -148,12 +152,14 @@ class DataParallelTrainer:
             self.hook_launches += 1
         self._done_from = start
 
-    def sync_buffers(self):
+    def sync_buffers(self, module=None):
         """rank 0's BatchNorm running statistics to every rank (DDP broadcast_buffers parity);
-        call before evaluation / checkpointing."""
+        call before evaluation / checkpointing.  `module`: the module whose buffers travel (default: the wrapped
+        model; the train scripts pass the whole LightningModule counterpart so that loss.discriminator's BatchNorm
+        buffers, which are saved from rank 0, are rank 0's everywhere)."""
         if self.world == 1:
             return
-        for b in self.model.buffers():
+        for b in (self.model if module is None else module).buffers():
             if b.dtype.is_floating_point:
                 dist.broadcast(b, src=0)
 

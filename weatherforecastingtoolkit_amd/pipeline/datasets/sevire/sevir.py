@@ -30,11 +30,37 @@ PREPROCESS_SCALE_01 = {"vil": 1 / 255}
 PREPROCESS_OFFSET_01 = {"vil": 0}
 
 
+# out_layout values of the reference's change_layout_torch (sevire/sevir.py:98-139).  The device kernel writes the frames
+# as contiguous 'NTHW' (the ae_v2 setting, train.py:290-304; T plays the role of the channel dimension); the other
+# layouts are the reference's own permute / unsqueeze VIEWS of that tensor (the reference returns views too unless
+# ret_contiguous is set), so values, shapes and dtypes agree with change_layout_torch(x_nhwt, 'NHWT', layout).
+LAYOUTS = {
+    "NTHW": lambda t: t,
+    "NHWT": lambda t: t.permute(0, 2, 3, 1),
+    "NTCHW": lambda t: t.unsqueeze(2),
+    "NTHWC": lambda t: t.unsqueeze(-1),
+    "TNHW": lambda t: t.permute(1, 0, 2, 3),
+    "TNCHW": lambda t: t.permute(1, 0, 2, 3).unsqueeze(2),
+}
+
+
+def change_layout_torch(data, in_layout="NHWT", out_layout="NHWT", ret_contiguous=False):
+    """the reference's layout switch (sevire/sevir.py:98-139) for tensors that already live on the device"""
+    to_nhwt = {"NHWT": lambda d: d, "NTHW": lambda d: d.permute(0, 2, 3, 1),
+               "NTCHW": lambda d: d[:, :, 0].permute(0, 2, 3, 1), "NTHWC": lambda d: d[..., 0].permute(0, 2, 3, 1),
+               "TNHW": lambda d: d.permute(1, 2, 3, 0), "TNCHW": lambda d: d[:, :, 0].permute(1, 2, 3, 0)}
+    if in_layout not in to_nhwt or out_layout not in LAYOUTS:
+        raise NotImplementedError
+    data = LAYOUTS[out_layout](to_nhwt[in_layout](data).permute(0, 3, 1, 2))
+    return data.contiguous() if ret_contiguous else data
+
+
 class SEVIRFrameLoader:
     def __init__(self, events_u8, batch_size, seq_len=1, stride=1, layout="NTHW", shuffle=False,
                  shuffle_seed=1, device=None, num_shard=1, rank=0):
-        if layout != "NTHW":
-            raise ValueError("only layout='NTHW' (the ae_v2 setting, train.py:290-304) is built")
+        if layout not in LAYOUTS:
+            raise NotImplementedError(f"layout {layout!r}: the reference's change_layout_torch knows {sorted(LAYOUTS)}")
+        self.layout = layout
         if hasattr(events_u8, "read") and hasattr(events_u8, "event_shape"):
             # an event store (catalog + files): events are read on demand; shuffling is the catalog's job
             self.store, self.events = events_u8, None
@@ -106,7 +132,7 @@ class SEVIRFrameLoader:
         if self.device is None or self.device.type != "cuda":
             raise RuntimeError("SEVIRFrameLoader preprocesses on the GPU: pass device='cuda:N'")
         u8 = u8.to(self.device, non_blocking=True)
-        return {"vil": ops.vil_u8_to_f32(u8, PREPROCESS_SCALE_01["vil"])}
+        return {"vil": LAYOUTS[self.layout](ops.vil_u8_to_f32(u8, PREPROCESS_SCALE_01["vil"]))}
 
     def __iter__(self):
         for i in range(len(self)):
@@ -166,7 +192,7 @@ class _Prefetcher:
                 if slot is None:
                     break
                 torch.cuda.current_stream(dev).wait_event(ev)
-                out = {"vil": ops.vil_u8_to_f32(dbuf[slot], PREPROCESS_SCALE_01["vil"])}
+                out = {"vil": LAYOUTS[self.loader.layout](ops.vil_u8_to_f32(dbuf[slot], PREPROCESS_SCALE_01["vil"]))}
                 done = torch.cuda.Event()
                 done.record(torch.cuda.current_stream(dev))
                 yield out

@@ -120,6 +120,45 @@ int wfae_conv1x1_bwd_data(const float* dy, const float* w, float* dx, int NB, in
 int wfae_conv1x1_bwd_weight(const float* dy, const float* x, float* dw, int NB, int Cin, int Cout,
                             int HW, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
 
+/* ---- The Bottleneck's 1x1 convolutions on the bf16 matrix pipe at fp32 accuracy (csrc/c1gemm.hip, ABI 102).
+ * Same products as wfae_conv1x1_fwd / wfae_conv1x1_bwd_data (pipeline/models/ae_64x8x8_lin.py:15,19) with the weight as
+ * three exact bf16 planes (the "split" operands of the Winograd section below) and the fp32 activation split once per
+ * loaded value on its way into LDS: y[n,m,p] = sum_k W[m,k] f(x[n,k,p]).
+ *   c1gemm_supported:     1 when M % 64 == 0, K % 32 == 0, HW % 4 == 0 (other shapes: wfae_conv1x1_*).
+ *   c1gemm_split_weights: w (Cout,Cin) -> W3 [3][Cout][Cin] and Wt3 [3][Cin][Cout] (3 * Cout * Cin uint16 each); the
+ *                         forward passes W3 with (M, K) = (Cout, Cin), the data gradient Wt3 with (M, K) = (Cin, Cout).
+ *   c1gemm_fwd:           y = W f(x) (+ res); pro_scale / pro_shift [K] non-null: f = GELU(x * scale[k] + shift[k]) (the
+ *                         fused BatchNorm + GELU prologue of wfae_conv1x1_fwd_bnact, same arithmetic), else f = identity.
+ *                         stat_part non-null: BatchNorm sums of y as *stat_rows partial rows, sum[rows][M] then
+ *                         sumsq[rows][M] (fp64; finish with wfae_bn_stats_from_rows); capacity 2 * rows * M doubles,
+ *                         rows = wfae_c1gemm_stat_rows(M, K, NB, HW).
+ *   c1gemm_bnred:         da = W dt (the data gradient of a C/4 -> C ... or any 1x1 convolution) and, while da is on
+ *                         chip, the reductions of the BatchNorm + GELU backward of the layer in front of it
+ *                         (wfae_bn_act_bwd phase 1): part = sum dU [rows][M] then sum dU * xhat [rows][M], dU = da *
+ *                         gelu'(x * bn_scale + bn_shift), xhat = (x - mean) * invstd, x (NB,M,HW) the BatchNorm input.
+ *                         da may be null: nothing is stored (the recompute form, followed by c1gemm_bndx).  Finish with
+ *                         wfae_bn_act_bwd_from_rows, which leaves what wfae_bn_act_bwd(phases = 2) reads.
+ *   c1gemm_bndx:          dx = gamma * invstd * (dU - mean dU - xhat * mean(dU xhat)) (+ res) with da = W dt recomputed
+ *                         on chip (wfae_bn_act_bwd phase 2 without ever storing da); coef = the 2 M floats at the head
+ *                         of the workspace wfae_bn_act_bwd_from_rows wrote. */
+int wfae_c1gemm_supported(int M, int K, int HW);
+int wfae_c1gemm_stat_rows(int M, int K, int NB, int HW);
+int wfae_c1gemm_split_weights(const float* w, uint16_t* W3, uint16_t* Wt3, int Cout, int Cin, wfae_stream_t stream);
+int wfae_c1gemm_fwd(const uint16_t* W3, const float* x, const float* pro_scale, const float* pro_shift, const float* res,
+                    float* y, int NB, int K, int M, int HW, double* stat_part, int64_t stat_capacity, int* stat_rows,
+                    wfae_stream_t stream);
+int wfae_c1gemm_bnred(const uint16_t* W3, const float* dt, const float* x, const float* bn_scale, const float* bn_shift,
+                      const float* save_mean, const float* save_invstd, float* da, int NB, int K, int M, int HW,
+                      double* part, int64_t part_capacity, int* part_rows, wfae_stream_t stream);
+int wfae_c1gemm_bndx(const uint16_t* W3, const float* dt, const float* x, const float* gamma, const float* bn_scale,
+                     const float* bn_shift, const float* save_mean, const float* save_invstd, const float* coef,
+                     const float* res, float* dx, int NB, int K, int M, int HW, int training, wfae_stream_t stream);
+/* wfae_bn_act_bwd phase 1 from partial rows a producer left (wfae_c1gemm_bnred): dgamma / dbeta and the coefficients at
+ * the head of ws, exactly as phase 1 leaves them — follow with wfae_bn_act_bwd(phases = 2, same ws) or wfae_c1gemm_bndx
+ * (coef = (const float*)ws). */
+int wfae_bn_act_bwd_from_rows(const double* part, int rows, int C, float* dgamma, float* dbeta, int accumulate, void* ws,
+                              size_t ws_bytes, wfae_stream_t stream);
+
 /* ---- nn.Linear (to_latent / from_latent, ae_64x8x8_lin.py:74-75,92,98) ---
  * y[b,o] = sum_i x[b,i] w[o,i] + bias[o] */
 int wfae_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In,

@@ -119,6 +119,59 @@ def main():
                     report(f"conv1x1 {nm:5s} {cin}->{cout} @{h}{' +res' if res and nm == 'fwd' else ''}", ms, fl, by + extra)
                     acc("conv1_" + nm, ms, 4)
                 del x, w, dy, r, dw
+    if "c1" in only:
+        # csrc/c1gemm.hip against the kernels it replaces, per Bottleneck stage: forward / data gradient of both 1x1
+        # convolutions, and the BatchNorm-backward sequences of the first BatchNorm (C channels):
+        #   old   : conv1x1_bwd_data + bn_act_bwd (reduce pass + dx pass)
+        #   bnred : c1gemm_bnred (reduce in the GEMM epilogue) + finalize + dx pass
+        #   recomp: c1gemm_bnred(store=False) + finalize + c1gemm_bndx (da never in HBM)
+        for c, h in stages[:4] + stages[7:]:
+            mult = 4 if c == 128 or h == S // 16 else 8
+            mid = c // 4
+            n = B * h * h
+            x, t2 = rnd(B, c, h, h), rnd(B, mid, h, h)
+            w1, w3 = rnd(mid, c, 1, 1) * c ** -0.5, rnd(c, mid, 1, 1) * mid ** -0.5
+            g, b_, rm, rv = torch.ones(c, device=dev), torch.zeros(c, device=dev), torch.zeros(c, device=dev), torch.ones(c, device=dev)
+            st = ops.bn_stats_train(x, g, b_, rm, rv)
+            dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
+            W1, W1t = ops.c1_split_weights(w1)
+            W3, W3t = ops.c1_split_weights(w3)
+            fl = 2 * n * c * mid
+            by1, by3 = 4 * n * (c + mid), 4 * n * (c + mid) + 4 * n * c
+            rows = []
+            if ops.c1gemm_supported(mid, c, h * h):
+                rows += [(f"fwd  {c}->{mid} bnact old", lambda: ops.conv1x1_fwd_bnact(x, st, w1), fl, by1, "fwd1_old"),
+                         (f"fwd  {c}->{mid} bnact c1gemm", lambda: ops.c1gemm_fwd(W1, x, st), fl, by1, "fwd1_c1"),
+                         (f"dgrad {c}->{mid} (da3) old", lambda: ops.conv1x1_bwd_data(x, w3), fl, by1, "dgrad3_old"),
+                         (f"dgrad {c}->{mid} (da3) c1gemm", lambda: ops.c1gemm_fwd(W3t, x), fl, by1, "dgrad3_c1")]
+            if ops.c1gemm_supported(c, mid, h * h):
+                rows += [(f"fwd  {mid}->{c} +res old", lambda: ops.conv1x1_fwd(t2, w3, None, x), fl, by3, "fwd3_old"),
+                         (f"fwd  {mid}->{c} +res c1gemm", lambda: ops.c1gemm_fwd(W3, t2, None, x), fl, by3, "fwd3_c1"),
+                         (f"dgrad {mid}->{c} (da1) old", lambda: ops.conv1x1_bwd_data(t2, w1), fl, by1, "dgrad1_old"),
+                         (f"dgrad {mid}->{c} (da1) c1gemm", lambda: ops.c1gemm_fwd(W1t, t2), fl, by1, "dgrad1_c1")]
+
+                def seq_old():
+                    da = ops.conv1x1_bwd_data(t2, w1)
+                    ops.bn_act_bwd(da, x, g, st, dg, db, x, 1, True)
+
+                def seq_red():
+                    da, sr = ops.c1gemm_bnred(W1t, t2, x, st)
+                    ops.bn_act_bwd_from_rows(sr, c, dg, db)
+                    ops.bn_act_bwd_dx(da, x, g, st, x, 1, True)
+
+                def seq_rec():
+                    _, sr = ops.c1gemm_bnred(W1t, t2, x, st, store=False)
+                    ops.bn_act_bwd_from_rows(sr, c, dg, db)
+                    ops.c1gemm_bndx(W1t, t2, x, g, st, x, True)
+                byo = 4 * n * (mid + c) + 4 * n * 2 * c + 4 * n * 4 * c
+                rows += [(f"bn1 bwd C={c}: dgrad + reduce + dx (old)", seq_old, fl, byo, "bn1seq_old"),
+                         (f"bn1 bwd C={c}: bnred + dx", seq_red, fl, byo - 4 * n * c, "bn1seq_bnred"),
+                         (f"bn1 bwd C={c}: bnred(no store) + bndx", seq_rec, 2 * fl, 4 * n * (2 * mid + 5 * c), "bn1seq_recompute")]
+            for tag, fn, f_, b2, key in rows:
+                ms = timeit(fn, R)
+                report(f"c1 @{h} {tag}", ms, f_, b2)
+                acc(key, ms, mult)
+            del x, t2, w1, w3, W1, W1t, W3, W3t
     if "fuse" in only:
         # BatchNorm-apply + GELU in the GEMM loaders vs the materialised form, first BatchNorm of a Bottleneck (C -> C/4)
         for c, h in stages:

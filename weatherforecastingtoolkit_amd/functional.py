@@ -73,6 +73,15 @@ FUSE_A3_MAXC = int(os.environ.get("WFAE_FUSE_A3_MAXC", "128"))
 PRODUCER_STATS = os.environ.get("WFAE_PRODUCER_STATS", "1") == "1"
 
 
+# Bottleneck 1x1 convolutions on csrc/c1gemm.hip (ops.c1gemm_supported decides per shape).  C1_BNRED: the reductions of the
+# BatchNorm + GELU backward in front of a 1x1 convolution (sum dU, sum dU * xhat) ride in the epilogue of the data-gradient
+# GEMM that produces dA instead of costing a pass over (dA, x) (WFAE_C1_BNRED=0: separate reduce pass).
+# C1_RECOMPUTE_MAXC: for Bottlenecks of at most this many channels the C-wide dA of the first BatchNorm is never written:
+# the reduce GEMM drops it and a second GEMM recomputes it inside the dx epilogue (K = C / 4 is short, the stage is HBM-bound).
+C1_BNRED = os.environ.get("WFAE_C1_BNRED", "1") == "1"
+C1_RECOMPUTE_MAXC = int(os.environ.get("WFAE_C1_RECOMPUTE_MAXC", "0"))
+
+
 def set_wgrad_overlap(flag: bool):
     global _overlap
     _overlap = bool(flag)
@@ -565,12 +574,21 @@ class BottleneckFn(Function):
         training = _use_batch_stats(bn1)
         fuse = training and STAT_FUSION
         emit = fuse and getattr(mod, "emit_stats", False)
+        C, mid, hw = x.shape[1], w1.shape[0], x.shape[2] * x.shape[3]
+        # csrc/c1gemm.hip serves (M = mid, K = C): the C -> C/4 forward and the C/4 -> C data gradient; (M = C, K = mid): the
+        # C/4 -> C forward and the C -> C/4 data gradient.  The weight planes are written once here and reused in backward.
+        use1, use3 = ops.c1gemm_supported(mid, C, hw), ops.c1gemm_supported(C, mid, hw)
+        W1p = ops.c1_split_weights(w1) if (use1 or use3) else (None, None)
+        W3p = ops.c1_split_weights(w3) if (use1 or use3) else (None, None)
         st1 = _bn_stats_rows(x_stats if (fuse or isinstance(x_stats, ops.StatParts)) else None, x, bn1, training)
-        if FUSE_A1 and x.shape[1] <= FUSE_A1_MAXC and ops.conv1x1_bnact_supported(x, w1.shape[0]):
-            a1 = None
+        fused1 = FUSE_A1 and x.shape[1] <= FUSE_A1_MAXC and ops.conv1x1_bnact_supported(x, w1.shape[0])
+        a1 = None if fused1 else ops.bn_act_fwd(x, st1, 1)
+        if use1:
+            src, pro = (x, st1) if fused1 else (a1, None)
+            t1, sr2 = ops.c1gemm_fwd(W1p[0], src, pro, None, True) if fuse else (ops.c1gemm_fwd(W1p[0], src, pro), None)
+        elif fused1:
             t1, sr2 = ops.conv1x1_fwd_bnact(x, st1, w1, stats=True) if fuse else (ops.conv1x1_fwd_bnact(x, st1, w1), None)
         else:
-            a1 = ops.bn_act_fwd(x, st1, 1)
             t1, sr2 = ops.conv1x1_fwd_stats(a1, w1) if fuse else (ops.conv1x1_fwd(a1, w1), None)
         st2 = _bn_stats_rows(sr2, t1, bn2, training)
         a2 = ops.bn_act_fwd(t1, st2, 1)
@@ -582,11 +600,15 @@ class BottleneckFn(Function):
                 (ops.conv1x1_fwd_bnact(t2, st3, w3, None, x), None)
         else:
             a3 = ops.bn_act_fwd(t2, st3, 1)
-            y, mod._out_stats = ops.conv1x1_fwd_stats(a3, w3, None, x) if emit else (ops.conv1x1_fwd(a3, w3, None, x), None)
+            if use3:
+                y, mod._out_stats = ops.c1gemm_fwd(W3p[0], a3, None, x, True) if emit else (ops.c1gemm_fwd(W3p[0], a3, None, x), None)
+            else:
+                y, mod._out_stats = ops.conv1x1_fwd_stats(a3, w3, None, x) if emit else (ops.conv1x1_fwd(a3, w3, None, x), None)
         ctx.save_for_backward(x, _opt(a1), t1, a2, t2, _opt(a3), g1, w1, g2, wg, g3, w3,
                               st1.mean, st1.invstd, st1.scale, st1.shift,
                               st2.mean, st2.invstd, st2.scale, st2.shift,
-                              st3.mean, st3.invstd, st3.scale, st3.shift)
+                              st3.mean, st3.invstd, st3.scale, st3.shift,
+                              _opt(W1p[1] if use3 else None), _opt(W3p[1] if use1 else None))
         ctx.training = training
         ctx.groups = groups
         ctx.betas = (b1, b2, b3)
@@ -596,6 +618,7 @@ class BottleneckFn(Function):
     def backward(ctx, dy):
         (x, a1, t1, a2, t2, a3, g1, w1, g2, wg, g3, w3, *s) = ctx.saved_tensors
         st1, st2, st3 = _mk_stats(*s[0:4]), _mk_stats(*s[4:8]), _mk_stats(*s[8:12])
+        W1t, W3t = s[12], s[13]     # bf16 planes of w1^T (M = C, K = mid) and w3^T (M = mid, K = C); empty: not on c1gemm
         tr = ctx.training
         dy = _c(dy)
         mid = w1.shape[0]
@@ -604,9 +627,15 @@ class BottleneckFn(Function):
             _wgrad(lambda: ops.conv1x1_bwd_weight_bnact(dy, t2, st3, dw3), dy, t2, st3.scale, st3.shift)
         else:
             _wgrad(lambda: ops.conv1x1_bwd_weight(dy, a3, dw3), dy, a3)
-        da3 = ops.conv1x1_bwd_data(dy, w3)
         dg3, db3 = grad_buffer(g3), grad_buffer(ctx.betas[2])
-        dt2 = ops.bn_act_bwd(da3, t2, g3, st3, dg3, db3, None, 1, tr)
+        if W3t.numel() and C1_BNRED:
+            # the data gradient's epilogue reduces sum dU, sum dU * xhat of the third BatchNorm while da3 is on chip
+            da3, sr = ops.c1gemm_bnred(W3t, dy, t2, st3)
+            ops.bn_act_bwd_from_rows(sr, mid, dg3, db3)
+            dt2 = ops.bn_act_bwd_dx(da3, t2, g3, st3, None, 1, tr)
+        else:
+            da3 = ops.c1gemm_fwd(W3t, dy, label="wfae_c1gemm_dgrad") if W3t.numel() else ops.conv1x1_bwd_data(dy, w3)
+            dt2 = ops.bn_act_bwd(da3, t2, g3, st3, dg3, db3, None, 1, tr)
         del da3
         dwg = grad_buffer(wg)
         _wgrad(lambda: _g3_wgrad(dt2, a2, dwg, ctx.groups), dt2, a2)
@@ -620,10 +649,19 @@ class BottleneckFn(Function):
             _wgrad(lambda: ops.conv1x1_bwd_weight_bnact(dt1, x, st1, dw1), dt1, x, st1.scale, st1.shift)
         else:
             _wgrad(lambda: ops.conv1x1_bwd_weight(dt1, a1, dw1), dt1, a1)
-        da1 = ops.conv1x1_bwd_data(dt1, w1)
-        del dt1
         dg1, db1 = grad_buffer(g1), grad_buffer(ctx.betas[0])
-        dx = ops.bn_act_bwd(da1, x, g1, st1, dg1, db1, dy, 1, tr)
+        if W1t.numel() and C1_BNRED and x.shape[1] <= C1_RECOMPUTE_MAXC:
+            # the C-wide da1 = W1^T dt1 never exists in HBM: one GEMM reduces, a second recomputes it inside the dx epilogue
+            _, sr = ops.c1gemm_bnred(W1t, dt1, x, st1, store=False)
+            ops.bn_act_bwd_from_rows(sr, x.shape[1], dg1, db1)
+            dx = ops.c1gemm_bndx(W1t, dt1, x, g1, st1, dy, tr)
+        elif W1t.numel() and C1_BNRED:
+            da1, sr = ops.c1gemm_bnred(W1t, dt1, x, st1)
+            ops.bn_act_bwd_from_rows(sr, x.shape[1], dg1, db1)
+            dx = ops.bn_act_bwd_dx(da1, x, g1, st1, dy, 1, tr)
+        else:
+            da1 = ops.c1gemm_fwd(W1t, dt1, label="wfae_c1gemm_dgrad") if W1t.numel() else ops.conv1x1_bwd_data(dt1, w1)
+            dx = ops.bn_act_bwd(da1, x, g1, st1, dg1, db1, dy, 1, tr)
         return dx, dg1, db1, dw1, dg2, db2, dwg, dg3, db3, dw3, None, None
 
 

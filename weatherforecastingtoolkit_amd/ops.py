@@ -189,6 +189,114 @@ def conv1x1_bwd_weight(dy, x, dw, accumulate=False):
     return dw
 
 
+# ------------------------------------------- 1x1 conv on the bf16 pipe (c1gemm)
+# csrc/c1gemm.hip: the Bottleneck's 1x1 convolutions with the weight as three exact bf16 planes and the activation split
+# once per loaded value on its way into LDS; epilogues: residual, BatchNorm sums, BatchNorm-backward reduce / dx.
+_C1GEMM = os.environ.get("WFAE_C1GEMM", "1") != "0"
+
+
+def set_c1gemm(on):
+    global _C1GEMM
+    _C1GEMM = bool(on)
+
+
+def c1gemm_supported(m, k, hw):
+    """True when csrc/c1gemm.hip serves y (m channels) = W (m x k) x at this size in the current arithmetic mode (fp32
+    precision with the split GEMMs on); everything else stays on wfae_conv1x1_*"""
+    return (_C1GEMM and _SPLIT_GEMM and _lib.load().wfae_get_matmul_precision() == 0
+            and bool(_lib.load().wfae_c1gemm_supported(int(m), int(k), int(hw))))
+
+
+def c1_split_weights(w):
+    """w (Cout, Cin[,1,1]) -> (W3, Wt3): bf16 planes (int16) [3, Cout, Cin] of w and [3, Cin, Cout] of its transpose"""
+    _chk(w)
+    cout, cin = w.shape[0], w.shape[1]
+    W3 = torch.empty((3, cout, cin), dtype=torch.int16, device=w.device)
+    Wt3 = torch.empty((3, cin, cout), dtype=torch.int16, device=w.device)
+    _call("wfae_c1gemm_split_weights", 0, 16 * w.numel(), _p(w), W3.data_ptr(), Wt3.data_ptr(), cout, cin, _stream())
+    return W3, Wt3
+
+
+def c1gemm_fwd(W3, x, st=None, res=None, stats=False, label="wfae_c1gemm_fwd"):
+    """y = W f(x) (+ res), W3 (3, M, K) from c1_split_weights; st: BnStats whose scale / shift fold a BatchNorm + GELU in
+    front of the convolution into the operand loader; stats=True: -> (y, StatRows of y)"""
+    import ctypes
+    _chk(x, res)
+    nb, k, h, wd = x.shape
+    m = W3.shape[1]
+    if W3.shape[2] != k or W3.dtype != torch.int16 or not W3.is_contiguous():
+        raise _lib.WfaeError("c1gemm_fwd: W3 must be the contiguous (3, M, K) int16 planes of the weight")
+    y = torch.empty((nb, m, h, wd), dtype=torch.float32, device=x.device)
+    fl = 2 * nb * h * wd * k * m
+    by = 4 * nb * h * wd * (k + m) + 6 * k * m + (0 if res is None else 4 * nb * h * wd * m)
+    ps, ph = (None, None) if st is None else (_p(st.scale), _p(st.shift))
+    if not stats:
+        _call("wfae_c1gemm_fwd", fl, by, W3.data_ptr(), _p(x), ps, ph, _p(res), _p(y), nb, k, m, h * wd, None, 0, None, _stream(),
+              label=label)
+        return y
+    rows_n = int(_lib.load().wfae_c1gemm_stat_rows(m, k, nb, h * wd))
+    part = torch.empty(2 * rows_n * m, dtype=torch.float64, device=x.device)
+    rows = ctypes.c_int(0)
+    _call("wfae_c1gemm_fwd", fl, by, W3.data_ptr(), _p(x), ps, ph, _p(res), _p(y), nb, k, m, h * wd, part.data_ptr(), part.numel(),
+          ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream(), label=label)
+    return y, StatRows(part, rows.value)
+
+
+def c1gemm_bnred(Wt3, dt, x, st, store=True):
+    """da = W^T dt with the reductions of the BatchNorm + GELU backward in front (sum dU, sum dU xhat over x) taken in the
+    epilogue -> (da | None, StatRows); store=False: da is not written (c1gemm_bndx recomputes it)"""
+    import ctypes
+    _chk(dt, x)
+    nb, k, h, wd = dt.shape
+    m = Wt3.shape[1]
+    da = torch.empty((nb, m, h, wd), dtype=torch.float32, device=dt.device) if store else None
+    rows_n = int(_lib.load().wfae_c1gemm_stat_rows(m, k, nb, h * wd))
+    part = torch.empty(2 * rows_n * m, dtype=torch.float64, device=dt.device)
+    rows = ctypes.c_int(0)
+    n = nb * h * wd
+    _call("wfae_c1gemm_bnred", 2 * n * k * m, 4 * n * (k + m + (m if store else 0)) + 6 * k * m, Wt3.data_ptr(), _p(dt), _p(x),
+          _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd), _p(da), nb, k, m, h * wd, part.data_ptr(), part.numel(),
+          ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream())
+    return da, StatRows(part, rows.value)
+
+
+def bn_act_bwd_from_rows(sr, c, dgamma, dbeta, accumulate=False):
+    """phase 1 of bn_act_bwd from the partial rows of c1gemm_bnred: dgamma / dbeta + the coefficients at the head of this
+    stream's workspace, where bn_act_bwd(..., phases=2) / c1gemm_bndx read them (no other workspace user in between)"""
+    _chk(dgamma, dbeta)
+    ws = workspace()
+    _call("wfae_bn_act_bwd_from_rows", 0, 8 * sr.part.numel(), sr.part.data_ptr(), sr.rows, c, _p(dgamma), _p(dbeta), int(accumulate),
+          ws.data_ptr(), ws.numel(), _stream(), label="wfae_bn_act_bwd[reduce]")
+    return ws
+
+
+def bn_act_bwd_dx(dy, x, gamma, st, res=None, act=1, training=True):
+    """phase 2 of bn_act_bwd alone (after bn_act_bwd_from_rows on the same stream)"""
+    _chk(dy, x, gamma, res)
+    nb, c, h, wd = x.shape
+    dx = torch.empty_like(x)
+    ws = workspace()
+    _call("wfae_bn_act_bwd", 0, 4 * x.numel() * (4 if res is not None else 3), _p(dy), _p(x), _p(gamma), _p(st.scale), _p(st.shift),
+          _p(st.mean), _p(st.invstd), _p(res), _p(dx), None, None, nb, c, h * wd, act, int(training), 0, 2, ws.data_ptr(),
+          ws.numel(), _stream(), label="wfae_bn_act_bwd[dx]")
+    return dx
+
+
+def c1gemm_bndx(Wt3, dt, x, gamma, st, res=None, training=True):
+    """dx of the BatchNorm + GELU in front of a 1x1 convolution with da = W^T dt recomputed on chip (after
+    c1gemm_bnred(store=False) + bn_act_bwd_from_rows on the same stream)"""
+    _chk(dt, x, gamma, res)
+    nb, k, h, wd = dt.shape
+    m = Wt3.shape[1]
+    dx = torch.empty((nb, m, h, wd), dtype=torch.float32, device=dt.device)
+    ws = workspace()
+    n = nb * h * wd
+    _call("wfae_c1gemm_bndx", 2 * n * k * m, 4 * n * (k + 2 * m + (m if res is not None else 0)) + 6 * k * m, Wt3.data_ptr(), _p(dt),
+          _p(x), _p(gamma), _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd), ws.data_ptr(), _p(res), _p(dx), nb, k, m,
+          h * wd, int(training), _stream())
+    return dx
+
+
 # ------------------------------------------------------------------- linear
 def linear_fwd(x, w, bias=None):
     _chk(x, w, bias)

@@ -153,6 +153,21 @@ int wfae_c1gemm_bnred(const uint16_t* W3, const float* dt, const float* x, const
 int wfae_c1gemm_bndx(const uint16_t* W3, const float* dt, const float* x, const float* gamma, const float* bn_scale,
                      const float* bn_shift, const float* save_mean, const float* save_invstd, const float* coef,
                      const float* res, float* dx, int NB, int K, int M, int HW, int training, wfae_stream_t stream);
+/* The same two fusions on the fp32 GEMM kernel of wfae_conv1x1_bwd_data (any Cin % 4 == 0, HW % 4 == 0; the short
+ * reductions K = C / 4 of the high-resolution stages, where that kernel's occupancy beats c1gemm's):
+ *   conv1x1_bwd_data_bnred: dx = da = conv1x1_bwd_data(dy, w) (dx may be null: not stored) + the partial rows
+ *                           sum dU [rows][Cin], sum dU xhat [rows][Cin] of the BatchNorm + GELU in front, x (NB,Cin,HW) its
+ *                           input; part_capacity >= 4 * ceil(NB * HW / 128) * Cin doubles; finish with
+ *                           wfae_bn_act_bwd_from_rows.
+ *   conv1x1_bwd_data_bndx:  dx = gamma invstd (dU - mean dU - xhat mean(dU xhat)) (+ res) with da recomputed on chip; coef =
+ *                           the head of the workspace wfae_bn_act_bwd_from_rows wrote. */
+int wfae_conv1x1_bwd_data_bnred(const float* dy, const float* w, const float* x, const float* bn_scale, const float* bn_shift,
+                                const float* save_mean, const float* save_invstd, float* dx, int NB, int Cin, int Cout, int HW,
+                                double* part, int64_t part_capacity, int* part_rows, wfae_stream_t stream);
+int wfae_conv1x1_bwd_data_bndx(const float* dy, const float* w, const float* x, const float* gamma, const float* bn_scale,
+                               const float* bn_shift, const float* save_mean, const float* save_invstd, const float* coef,
+                               const float* res, float* dx, int NB, int Cin, int Cout, int HW, int training,
+                               wfae_stream_t stream);
 /* wfae_bn_act_bwd phase 1 from partial rows a producer left (wfae_c1gemm_bnred): dgamma / dbeta and the coefficients at
  * the head of ws, exactly as phase 1 leaves them — follow with wfae_bn_act_bwd(phases = 2, same ws) or wfae_c1gemm_bndx
  * (coef = (const float*)ws). */

@@ -103,6 +103,21 @@ def test_c1gemm_bn_backward_epilogues(dev, shape, training):
     dx2 = ops.c1gemm_bndx(Wt3, dtd, xd, gamma, st, resd, training)
     assert torch.equal(dg2, dg1) and torch.equal(db2, db1)        # the same reduction, with or without the store
     assert relerr(dx2, dx0) < 3e-5
+    # the same two fusions on gemm.hip's kernel (wfae_conv1x1_bwd_data_bnred / _bndx): any channel count % 4
+    da3, sr3 = ops.conv1x1_bwd_data_bnred(dtd, wd, xd, st)
+    dg3, db3 = torch.empty(m, device=dev), torch.empty(m, device=dev)
+    ops.bn_act_bwd_from_rows(sr3, m, dg3, db3)
+    dx3 = ops.bn_act_bwd_dx(da3, xd, gamma, st, resd, 1, training)
+    assert relerr(da3, da0) < 2e-5      # the same GEMM up to the tile height (small grids: 64-row tiles for the epilogue)
+    assert (dg3 - dg0).abs().max().item() < 3e-5 * sc and (db3 - db0).abs().max().item() < 3e-5 * sc
+    assert relerr(dx3, dx0) < 3e-5
+    none, sr4 = ops.conv1x1_bwd_data_bnred(dtd, wd, xd, st, store=False)
+    assert none is None
+    dg4, db4 = torch.empty(m, device=dev), torch.empty(m, device=dev)
+    ops.bn_act_bwd_from_rows(sr4, m, dg4, db4)
+    dx4 = ops.conv1x1_bwd_data_bndx(dtd, wd, xd, gamma, st, resd, training)
+    assert torch.equal(dg4, dg3) and torch.equal(db4, db3)
+    assert relerr(dx4, dx0) < 3e-5
     # fp64 autograd of  res-branch + conv1x1(gelu(bn(x)))  for the training-mode case
     if training:
         x64 = x.double().requires_grad_(True)
@@ -112,6 +127,32 @@ def test_c1gemm_bn_backward_epilogues(dev, shape, training):
         (t * dt.double()).sum().backward()
         assert relerr(dx2, x64.grad + res.double()) < 3e-5
         assert relerr(dg2, g64.grad) < 3e-5 and relerr(db2, b64.grad) < 3e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 32, 12, 12), (3, 24, 20, 6, 6), (1, 16, 8, 4, 4), (2, 40, 132, 10, 10)])
+def test_fused_bn_backward_on_the_fp32_gemm_kernel(dev, shape):
+    """wfae_conv1x1_bwd_data_bnred / _bndx at channel counts c1gemm does not serve (Cin = 32: the C/4-wide data gradient of
+    the C = 128 stage; odd multiples of 4; M tails): against the unfused chain"""
+    from weatherforecastingtoolkit_amd import ops
+    nb, k, m, h, w = shape
+    assert ops.conv1x1_bn_fusable(m, h * w)
+    gen = torch.Generator().manual_seed(7 + hash(shape) % (2 ** 31))
+    dt, wt = _rnd(gen, nb, k, h, w).to(dev), _rnd(gen, k, m, scale=k ** -0.5).to(dev)
+    x, res = (_rnd(gen, nb, m, h, w, scale=2.0) + 0.3).to(dev), _rnd(gen, nb, m, h, w).to(dev)
+    gamma, beta = (_rnd(gen, m) + 1.5).to(dev), _rnd(gen, m).to(dev)
+    st = ops.bn_stats_train(x, gamma, beta, torch.zeros(m, device=dev), torch.ones(m, device=dev))
+    da0 = ops.conv1x1_bwd_data(dt, wt)
+    dg0, db0 = torch.empty(m, device=dev), torch.empty(m, device=dev)
+    dx0 = ops.bn_act_bwd(da0, x, gamma, st, dg0, db0, res, 1, True)
+    sc = max(dg0.abs().max().item(), db0.abs().max().item())
+    for store in (True, False):
+        da, sr = ops.conv1x1_bwd_data_bnred(dt, wt, x, st, store=store)
+        dg, db = torch.empty(m, device=dev), torch.empty(m, device=dev)
+        ops.bn_act_bwd_from_rows(sr, m, dg, db)
+        dx = ops.bn_act_bwd_dx(da, x, gamma, st, res, 1, True) if store else ops.conv1x1_bwd_data_bndx(dt, wt, x, gamma, st, res, True)
+        assert (da is None) == (not store) and (da is None or relerr(da, da0) < 2e-5)
+        assert (dg - dg0).abs().max().item() < 3e-5 * sc and (db - db0).abs().max().item() < 3e-5 * sc
+        assert relerr(dx, dx0) < 3e-5
 
 
 def test_bottleneck_paths_agree(dev):
@@ -129,19 +170,23 @@ def test_bottleneck_paths_agree(dev):
     x0 = torch.randn(4, 256, 32, 32, device=dev)
     dy = torch.randn(4, 256, 32, 32, device=dev)
     outs = {}
-    for name, on, rec in (("old", False, 0), ("c1", True, 0), ("c1_recompute", True, 1 << 30)):
-        ops.set_c1gemm(on)
-        Fn.C1_RECOMPUTE_MAXC = rec
-        try:
+    # (c1gemm on, its minimum K, fused BatchNorm-backward epilogues, recompute form)
+    cfgs = {"round2": (False, 512, False, 0), "fused": (False, 512, True, 0), "fused_recompute": (False, 512, True, 1 << 30),
+            "c1": (True, 32, True, 0), "c1_recompute": (True, 32, True, 1 << 30), "c1_unfused": (True, 32, False, 0)}
+    keep = (ops._C1GEMM, ops._C1_MIN_K, Fn.C1_BNRED, Fn.C1_RECOMPUTE_MAXC)
+    try:
+        for name, (on, mink, red, rec) in cfgs.items():
+            ops.set_c1gemm(on)
+            ops._C1_MIN_K, Fn.C1_BNRED, Fn.C1_RECOMPUTE_MAXC = mink, red, rec
             for p in blk.parameters():
                 p.grad = None
             x = x0.clone().requires_grad_(True)
             y = blk(x)
             y.backward(dy)
             outs[name] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
-        finally:
-            ops.set_c1gemm(True)
-            Fn.C1_RECOMPUTE_MAXC = 0
-    for name in ("c1", "c1_recompute"):
-        for a, b in zip(outs[name], outs["old"]):
+    finally:
+        ops.set_c1gemm(keep[0])
+        ops._C1_MIN_K, Fn.C1_BNRED, Fn.C1_RECOMPUTE_MAXC = keep[1:]
+    for name in cfgs:
+        for a, b in zip(outs[name], outs["round2"]):
             assert relerr(a, b) < 5e-5, name

@@ -163,8 +163,19 @@ def main():
                     _, sr = ops.c1gemm_bnred(W1t, t2, x, st, store=False)
                     ops.bn_act_bwd_from_rows(sr, c, dg, db)
                     ops.c1gemm_bndx(W1t, t2, x, g, st, x, True)
+                def seq_red0():
+                    da, sr = ops.conv1x1_bwd_data_bnred(t2, w1, x, st)
+                    ops.bn_act_bwd_from_rows(sr, c, dg, db)
+                    ops.bn_act_bwd_dx(da, x, g, st, x, 1, True)
+
+                def seq_rec0():
+                    _, sr = ops.conv1x1_bwd_data_bnred(t2, w1, x, st, store=False)
+                    ops.bn_act_bwd_from_rows(sr, c, dg, db)
+                    ops.conv1x1_bwd_data_bndx(t2, w1, x, g, st, x, True)
                 byo = 4 * n * (mid + c) + 4 * n * 2 * c + 4 * n * 4 * c
-                rows += [(f"bn1 bwd C={c}: dgrad + reduce + dx (old)", seq_old, fl, byo, "bn1seq_old"),
+                rows += [(f"bn1 bwd C={c}: gemm.hip bnred + dx", seq_red0, fl, byo - 4 * n * c, "bn1seq_gemm_bnred"),
+                         (f"bn1 bwd C={c}: gemm.hip bnred(no store) + bndx", seq_rec0, 2 * fl, 4 * n * (2 * mid + 5 * c), "bn1seq_gemm_recompute"),
+                         (f"bn1 bwd C={c}: dgrad + reduce + dx (old)", seq_old, fl, byo, "bn1seq_old"),
                          (f"bn1 bwd C={c}: bnred + dx", seq_red, fl, byo - 4 * n * c, "bn1seq_bnred"),
                          (f"bn1 bwd C={c}: bnred(no store) + bndx", seq_rec, 2 * fl, 4 * n * (2 * mid + 5 * c), "bn1seq_recompute")]
             for tag, fn, f_, b2, key in rows:

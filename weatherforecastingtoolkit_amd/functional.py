@@ -73,12 +73,17 @@ FUSE_A3_MAXC = int(os.environ.get("WFAE_FUSE_A3_MAXC", "128"))
 PRODUCER_STATS = os.environ.get("WFAE_PRODUCER_STATS", "1") == "1"
 
 
-# Bottleneck 1x1 convolutions on csrc/c1gemm.hip (ops.c1gemm_supported decides per shape).  C1_BNRED: the reductions of the
-# BatchNorm + GELU backward in front of a 1x1 convolution (sum dU, sum dU * xhat) ride in the epilogue of the data-gradient
-# GEMM that produces dA instead of costing a pass over (dA, x) (WFAE_C1_BNRED=0: separate reduce pass).
-# C1_RECOMPUTE_MAXC: for Bottlenecks of at most this many channels the C-wide dA of the first BatchNorm is never written:
-# the reduce GEMM drops it and a second GEMM recomputes it inside the dx epilogue (K = C / 4 is short, the stage is HBM-bound).
-C1_BNRED = os.environ.get("WFAE_C1_BNRED", "1") == "1"
+# Bottleneck 1x1 convolutions on csrc/c1gemm.hip where it measured faster (ops.c1gemm_preferred: reductions K >= 512).
+# C1_BNRED: the reductions of the BatchNorm + GELU backward in front of a 1x1 convolution (sum dU, sum dU * xhat) taken in the
+# epilogue of the data-gradient GEMM that produces dA instead of by a pass over (dA, x); C1_RECOMPUTE_MAXC: for Bottlenecks
+# of at most this many channels the C-wide dA of the first BatchNorm is never written (one GEMM reduces, a second
+# recomputes it inside the dx epilogue).  Both are built, parity-tested (tests/test_c1gemm_gpu.py) and OFF: measured at the
+# step's shapes (tools/kbench.py --only c1, profiles/r03_kbench_c1_fused_bn_backward.txt) the fused sequences move 14-38 %
+# fewer bytes and take the same time or longer (C = 256 @192: 1.55 ms fused / 1.61 recompute vs 1.55 separate passes;
+# C = 128 @384: 2.91 / 2.82 vs 2.90) — gelu' costs ~25 vector instructions per element (0.39 ms per C-wide tensor of the
+# 384 x 384 stage at 100 % VALU utilisation), which a streaming pass hides under its HBM time with 8 waves per SIMD and a
+# GEMM epilogue does not.
+C1_BNRED = os.environ.get("WFAE_C1_BNRED", "0") == "1"
 C1_RECOMPUTE_MAXC = int(os.environ.get("WFAE_C1_RECOMPUTE_MAXC", "0"))
 
 
@@ -556,6 +561,28 @@ def _mk_stats(mean, invstd, scale, shift):
     return st
 
 
+def _dgrad_bn(dt, w, Wt3, x, gamma, st, dgamma, dbeta, res, training, recompute):
+    """dx of  conv1x1(gelu(bn(x)), w)  given dt = dL/d(conv output): the data gradient dA = W^T dT followed by the
+    BatchNorm + GELU backward at x (+ res, the residual-branch gradient).  C1_BNRED: the per-channel reductions ride in the
+    GEMM epilogue; `recompute`: dA is never written — one GEMM reduces, a second recomputes it inside the dx epilogue.
+    Wt3: bf16 planes of w^T when this product runs on c1gemm (else an empty tensor: gemm.hip's kernel)."""
+    c = x.shape[1]
+    on_c1 = Wt3 is not None and Wt3.numel() > 0
+    if not (C1_BNRED and (on_c1 or ops.conv1x1_bn_fusable(c, x.shape[2] * x.shape[3]))):
+        da = ops.c1gemm_fwd(Wt3, dt, label="wfae_c1gemm_dgrad") if on_c1 else ops.conv1x1_bwd_data(dt, w)
+        return ops.bn_act_bwd(da, x, gamma, st, dgamma, dbeta, res, 1, training)
+    if on_c1:
+        da, sr = ops.c1gemm_bnred(Wt3, dt, x, st, store=not recompute)
+    else:
+        da, sr = ops.conv1x1_bwd_data_bnred(dt, w, x, st, store=not recompute)
+    ops.bn_act_bwd_from_rows(sr, c, dgamma, dbeta)
+    if not recompute:
+        return ops.bn_act_bwd_dx(da, x, gamma, st, res, 1, training)
+    if on_c1:
+        return ops.c1gemm_bndx(Wt3, dt, x, gamma, st, res, training)
+    return ops.conv1x1_bwd_data_bndx(dt, w, x, gamma, st, res, training)
+
+
 class BottleneckFn(Function):
     @staticmethod
     def forward(ctx, x, g1, b1, w1, g2, b2, wg, g3, b3, w3, mod, x_stats=None):
@@ -577,7 +604,7 @@ class BottleneckFn(Function):
         C, mid, hw = x.shape[1], w1.shape[0], x.shape[2] * x.shape[3]
         # csrc/c1gemm.hip serves (M = mid, K = C): the C -> C/4 forward and the C/4 -> C data gradient; (M = C, K = mid): the
         # C/4 -> C forward and the C -> C/4 data gradient.  The weight planes are written once here and reused in backward.
-        use1, use3 = ops.c1gemm_supported(mid, C, hw), ops.c1gemm_supported(C, mid, hw)
+        use1, use3 = ops.c1gemm_preferred(mid, C, hw), ops.c1gemm_preferred(C, mid, hw)
         W1p = ops.c1_split_weights(w1) if (use1 or use3) else (None, None)
         W3p = ops.c1_split_weights(w3) if (use1 or use3) else (None, None)
         st1 = _bn_stats_rows(x_stats if (fuse or isinstance(x_stats, ops.StatParts)) else None, x, bn1, training)
@@ -628,15 +655,7 @@ class BottleneckFn(Function):
         else:
             _wgrad(lambda: ops.conv1x1_bwd_weight(dy, a3, dw3), dy, a3)
         dg3, db3 = grad_buffer(g3), grad_buffer(ctx.betas[2])
-        if W3t.numel() and C1_BNRED:
-            # the data gradient's epilogue reduces sum dU, sum dU * xhat of the third BatchNorm while da3 is on chip
-            da3, sr = ops.c1gemm_bnred(W3t, dy, t2, st3)
-            ops.bn_act_bwd_from_rows(sr, mid, dg3, db3)
-            dt2 = ops.bn_act_bwd_dx(da3, t2, g3, st3, None, 1, tr)
-        else:
-            da3 = ops.c1gemm_fwd(W3t, dy, label="wfae_c1gemm_dgrad") if W3t.numel() else ops.conv1x1_bwd_data(dy, w3)
-            dt2 = ops.bn_act_bwd(da3, t2, g3, st3, dg3, db3, None, 1, tr)
-        del da3
+        dt2 = _dgrad_bn(dy, w3, W3t, t2, g3, st3, dg3, db3, None, tr, False)
         dwg = grad_buffer(wg)
         _wgrad(lambda: _g3_wgrad(dt2, a2, dwg, ctx.groups), dt2, a2)
         da2 = _g3_dgrad(dt2, wg, mid, ctx.groups)
@@ -650,18 +669,7 @@ class BottleneckFn(Function):
         else:
             _wgrad(lambda: ops.conv1x1_bwd_weight(dt1, a1, dw1), dt1, a1)
         dg1, db1 = grad_buffer(g1), grad_buffer(ctx.betas[0])
-        if W1t.numel() and C1_BNRED and x.shape[1] <= C1_RECOMPUTE_MAXC:
-            # the C-wide da1 = W1^T dt1 never exists in HBM: one GEMM reduces, a second recomputes it inside the dx epilogue
-            _, sr = ops.c1gemm_bnred(W1t, dt1, x, st1, store=False)
-            ops.bn_act_bwd_from_rows(sr, x.shape[1], dg1, db1)
-            dx = ops.c1gemm_bndx(W1t, dt1, x, g1, st1, dy, tr)
-        elif W1t.numel() and C1_BNRED:
-            da1, sr = ops.c1gemm_bnred(W1t, dt1, x, st1)
-            ops.bn_act_bwd_from_rows(sr, x.shape[1], dg1, db1)
-            dx = ops.bn_act_bwd_dx(da1, x, g1, st1, dy, 1, tr)
-        else:
-            da1 = ops.c1gemm_fwd(W1t, dt1, label="wfae_c1gemm_dgrad") if W1t.numel() else ops.conv1x1_bwd_data(dt1, w1)
-            dx = ops.bn_act_bwd(da1, x, g1, st1, dg1, db1, dy, 1, tr)
+        dx = _dgrad_bn(dt1, w1, W1t, x, g1, st1, dg1, db1, dy, tr, x.shape[1] <= C1_RECOMPUTE_MAXC)
         return dx, dg1, db1, dw1, dg2, db2, dwg, dg3, db3, dw3, None, None
 
 

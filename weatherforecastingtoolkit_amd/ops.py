@@ -207,6 +207,54 @@ def c1gemm_supported(m, k, hw):
             and bool(_lib.load().wfae_c1gemm_supported(int(m), int(k), int(hw))))
 
 
+_C1_MIN_K = int(os.environ.get("WFAE_C1_MIN_K", "512"))
+
+
+def c1gemm_preferred(m, k, hw):
+    """c1gemm where it measured faster than the round-2 kernels (tools/kbench.py --only c1, profiles/r03_*): the long
+    reductions K >= 512 (C -> C/4 forward and C/4 -> C data gradient of the C >= 512 stages).  With short reductions the
+    one-block-per-CU pipeline cannot hide its prologue / epilogue and gemm.hip's smaller tiles win."""
+    return k >= _C1_MIN_K and c1gemm_supported(m, k, hw)
+
+
+def conv1x1_bn_fusable(c, hw):
+    """shapes for which wfae_conv1x1_bwd_data_bnred / _bndx serve a data gradient with `c` result channels"""
+    return c % 4 == 0 and hw % 4 == 0
+
+
+def conv1x1_bwd_data_bnred(dy, w, x, st, store=True):
+    """da = conv1x1_bwd_data(dy, w) with the reductions of the BatchNorm + GELU backward in front (x: its input) taken in
+    the GEMM epilogue -> (da | None, StatRows)"""
+    import ctypes
+    _chk(dy, w, x)
+    nb, cout, h, wd = dy.shape
+    cin = w.shape[1]
+    da = torch.empty((nb, cin, h, wd), dtype=torch.float32, device=dy.device) if store else None
+    rows_n = 2 * ((nb * h * wd + 127) // 128)
+    part = torch.empty(2 * rows_n * cin, dtype=torch.float64, device=dy.device)
+    rows = ctypes.c_int(0)
+    n = nb * h * wd
+    _call("wfae_conv1x1_bwd_data_bnred", 2 * n * cin * cout, 4 * n * (cout + cin + (cin if store else 0)) + 4 * cin * cout, _p(dy),
+          _p(w), _p(x), _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd), _p(da), nb, cin, cout, h * wd, part.data_ptr(),
+          part.numel(), ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream())
+    return da, StatRows(part, rows.value)
+
+
+def conv1x1_bwd_data_bndx(dy, w, x, gamma, st, res=None, training=True):
+    """dx of the BatchNorm + GELU in front of a 1x1 convolution with da = conv1x1_bwd_data(dy, w) recomputed on chip (after
+    conv1x1_bwd_data_bnred(store=False) + bn_act_bwd_from_rows on the same stream)"""
+    _chk(dy, w, x, gamma, res)
+    nb, cout, h, wd = dy.shape
+    cin = w.shape[1]
+    dx = torch.empty((nb, cin, h, wd), dtype=torch.float32, device=dy.device)
+    ws = workspace()
+    n = nb * h * wd
+    _call("wfae_conv1x1_bwd_data_bndx", 2 * n * cin * cout, 4 * n * (cout + 2 * cin + (cin if res is not None else 0)) + 4 * cin * cout,
+          _p(dy), _p(w), _p(x), _p(gamma), _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd), ws.data_ptr(), _p(res), _p(dx),
+          nb, cin, cout, h * wd, int(training), _stream())
+    return dx
+
+
 def c1_split_weights(w):
     """w (Cout, Cin[,1,1]) -> (W3, Wt3): bf16 planes (int16) [3, Cout, Cin] of w and [3, Cin, Cout] of its transpose"""
     _chk(w)

@@ -207,13 +207,17 @@ def c1gemm_supported(m, k, hw):
             and bool(_lib.load().wfae_c1gemm_supported(int(m), int(k), int(hw))))
 
 
-_C1_MIN_K = int(os.environ.get("WFAE_C1_MIN_K", "512"))
+# c1gemm is taken for reductions K >= WFAE_C1_MIN_K.  Measured (profiles/r03_kbench_c1_fused_bn_backward.txt, tools/kbench.py
+# --only c1): in isolation it beats the round-2 kernels on the K >= 512 shapes (1024 -> 256 @48: fused-prologue forward
+# 0.376 -> 0.273 ms, data gradient 0.272 -> 0.237 ms = 163 TF fp32-equivalent; @24: 0.154 -> 0.086 ms) and loses on the short
+# reductions (one block of 144 KiB LDS per CU cannot hide its prologue / epilogue); inside the step the K >= 512 shapes came
+# out EQUAL (1x1 forward 29.6 -> 29.6 ms, data gradient 20.2 -> 20.2 ms per step, profiles/r03_v1_*), so the default keeps the
+# round-2 kernels (and their bit patterns) at fp32 precision; the kernel is the 1x1 path of the bf16-storage mode.
+_C1_MIN_K = int(os.environ.get("WFAE_C1_MIN_K", str(1 << 30)))
 
 
 def c1gemm_preferred(m, k, hw):
-    """c1gemm where it measured faster than the round-2 kernels (tools/kbench.py --only c1, profiles/r03_*): the long
-    reductions K >= 512 (C -> C/4 forward and C/4 -> C data gradient of the C >= 512 stages).  With short reductions the
-    one-block-per-CU pipeline cannot hide its prologue / epilogue and gemm.hip's smaller tiles win."""
+    """c1gemm for this product?  (reductions K >= WFAE_C1_MIN_K, see above)"""
     return k >= _C1_MIN_K and c1gemm_supported(m, k, hw)
 
 

@@ -279,6 +279,69 @@ int wfae_bn_act_bwd(const float* dy, const float* x, const float* gamma, const f
                     int act, int training, int accumulate, int phases, void* ws, size_t ws_bytes,
                     wfae_stream_t stream);
 
+/* ---- bf16 ACTIVATION STORAGE (ABI 102; BASELINE config 5: the reference's bf16 regime, experiments/ae_v2_2/train.py:223
+ * + Lightning precision).  In this mode the activation tensors of the convolution stacks — and their gradients — live in
+ * HBM as bf16 bit patterns (torch.bfloat16, passed as uint16_t*), halving the traffic of the HBM-bound kernels; parameters,
+ * parameter gradients, BatchNorm statistics, the latent vectors, the loss and every accumulation stay fp32, and each kernel
+ * widens its inputs to fp32 registers and rounds results to nearest even on the way out.  A `_bf16` entry point is its
+ * fp32 namesake with the activation pointers retyped; every lane still moves 16 bytes per access (8 elements instead
+ * of 4), so HW % 8 == 0 takes the vector path (other sizes: the scalar path, as HW % 4 != 0 does for fp32). */
+int wfae_convert_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, wfae_stream_t stream);
+int wfae_convert_bf16_to_f32(const uint16_t* src, float* dst, int64_t n, wfae_stream_t stream);
+int wfae_bn_stats_train_bf16(const uint16_t* x, int NB, int C, int HW, const float* gamma, const float* beta, float eps,
+                             float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                             float* scale, float* shift, void* ws, size_t ws_bytes, wfae_stream_t stream);
+int wfae_bn_act_fwd_bf16(const uint16_t* x, const float* scale, const float* shift, uint16_t* y, int NB, int C, int HW, int act,
+                         wfae_stream_t stream);
+/* the sums are those of the ROUNDED values written to y (what the next BatchNorm reads) */
+int wfae_bn_act_fwd_stats_bf16(const uint16_t* x, const float* scale, const float* shift, uint16_t* y, int NB, int C, int HW,
+                               int act, double* part, int64_t part_capacity, int* splits_out, wfae_stream_t stream);
+/* 1x1 convolutions on bf16-stored activations (x, res, y / dy, dx bf16; weights, bias, dw, BatchNorm vectors fp32; needs
+ * WFAE_PRECISION_BF16; Cin % 4 == 0, HW % 4 == 0).  One entry point per role covers the plain and the fused forms:
+ * bn_scale / bn_shift non-null = the BatchNorm + GELU prologue of wfae_conv1x1_fwd_bnact / wfae_conv1x1_bwd_weight_bnact,
+ * stat_part / stat_rows non-null = the BatchNorm sums of wfae_conv1x1_fwd_stats (sums of the ROUNDED results). */
+int wfae_conv1x1_fwd_bf16(const uint16_t* x, const float* bn_scale, const float* bn_shift, const float* w, const float* bias,
+                          const uint16_t* res, int64_t res_img_stride, uint16_t* y, int NB, int Cin, int Cout, int HW,
+                          double* stat_part, int64_t stat_capacity, int* stat_rows, wfae_stream_t stream);
+int wfae_conv1x1_bwd_data_bf16(const uint16_t* dy, const float* w, uint16_t* dx, int NB, int Cin, int Cout, int HW,
+                               wfae_stream_t stream);
+int wfae_conv1x1_bwd_weight_bf16(const uint16_t* dy, const uint16_t* x, const float* bn_scale, const float* bn_shift, float* dw,
+                                 int NB, int Cin, int Cout, int HW, int accumulate, void* ws, size_t ws_bytes,
+                                 wfae_stream_t stream);
+/* grouped 3x3 convolution of the Bottleneck on bf16-stored activations (weights / dw fp32) */
+int wfae_gconv3x3_fwd_bf16(const uint16_t* x, const float* w, uint16_t* y, int NB, int C, int H, int W, int groups,
+                           int transposed, void* ws, size_t ws_bytes, wfae_stream_t stream);
+int wfae_gconv3x3_bwd_weight_bf16(const uint16_t* dy, const uint16_t* x, float* dw, int NB, int C, int H, int W, int groups,
+                                  int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
+/* the two full-resolution convolutions with ONE channel on one side keep that side fp32:
+ *   dconv_fwd_bf16out:      Conv2d(1, C, 4, 2, 1) forward (encoder first layer): x fp32 (NB,1,H,W) -> y bf16 (NB,C,H/2,W/2)
+ *   dconv_fwd_bf16in:       Conv2d(Cin, Cout, 3, 1, 1) forward (the output convolution): x bf16 -> y fp32
+ *   dconv_bwd_data_bf16out: data gradient of Conv2d(Cin, 1, 3, 1, 1): dy fp32 (NB,1,H,W) -> dx bf16 (NB,Cin,H,W)
+ *   c1_wgrad_bf16:          their weight gradients; flip 0: big = dy bf16 (NB,C,H/2,W/2), small = x fp32 (NB,1,H,W) -> dw
+ *                           (C,1,4,4); flip 1: big = x bf16 (NB,C,H,W), small = dy fp32 (NB,1,H,W) -> dw (1,C,3,3) */
+int wfae_dconv_fwd_bf16out(const float* x, const float* w, const float* bias, uint16_t* y, int NB, int Cout, int H, int W,
+                           wfae_stream_t stream);
+int wfae_dconv_fwd_bf16in(const uint16_t* x, const float* w, const float* bias, float* y, int NB, int Cin, int Cout, int H,
+                          int W, wfae_stream_t stream);
+int wfae_dconv_bwd_data_bf16out(const float* dy, const float* w, uint16_t* dx, int NB, int Cin, int H, int W,
+                                wfae_stream_t stream);
+int wfae_c1_wgrad_bf16(int flip, const uint16_t* big, const float* small, float* dw, int NB, int C, int H, int W, int accumulate,
+                       void* ws, size_t ws_bytes, wfae_stream_t stream);
+/* Winograd transforms with the TENSOR side stored as bf16 (operands / products of the transform domain unchanged);
+ * wino_out_bf16 / wino_in_t_bf16: part null = plain transform, else also the BatchNorm sums of the rounded result */
+int wfae_wino_in_split_bf16(int variant, const uint16_t* hi, uint16_t* V3, int planes, int NB, int Chi, int Hlo, int Wlo,
+                            wfae_stream_t stream);
+int wfae_wino_out_t_split_bf16(int variant, const uint16_t* lo, uint16_t* Mt3, int planes, int NB, int Clo, int Hlo, int Wlo,
+                               wfae_stream_t stream);
+int wfae_wino_out_bf16(int variant, const float* M, uint16_t* lo, int NB, int Clo, int Hlo, int Wlo, double* part,
+                       int64_t part_capacity, int* splits_out, wfae_stream_t stream);
+int wfae_wino_in_t_bf16(int variant, const float* dV, uint16_t* hi, int NB, int Chi, int Hlo, int Wlo, double* part,
+                        int64_t part_capacity, int* splits_out, wfae_stream_t stream);
+int wfae_bn_act_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* gamma, const float* scale, const float* shift,
+                         const float* save_mean, const float* save_invstd, const uint16_t* res, uint16_t* dx, float* dgamma,
+                         float* dbeta, int NB, int C, int HW, int act, int training, int accumulate, int phases, void* ws,
+                         size_t ws_bytes, wfae_stream_t stream);
+
 /* ---- element-wise / reductions -------------------------------------------- */
 int wfae_gelu_fwd(const float* x, float* y, int64_t n, wfae_stream_t stream);   /* nn.GELU */
 int wfae_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, wfae_stream_t stream);

@@ -138,8 +138,12 @@ def test_conv4x4s1_bf16(medium, dev, nb, cin, cout, h, w, pad):
     assert relerr(dw, wr.grad) < TOL
 
 
-def test_ae_step_bf16_tracks_fp32(medium, dev):
-    """whole AE train step at 128^2, B=2 in 'medium' against the same step in fp32: loss within 2e-3 relative, the
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_ae_step_bf16_tracks_fp32(medium, dev, storage):
+    """(storage fp32: bf16 matrix-core operands on fp32 tensors, round 2's 'medium'; storage bf16: the activations and their
+    gradients also live in HBM as bf16 — every tensor of the convolution stacks is rounded once more per layer, so the bars
+    are wider: see the assertions)
+    whole AE train step at 128^2, B=2 in 'medium' against the same step in fp32: loss within 2e-3 relative, the
     reconstruction within 2e-2 on average, 0.15 at the worst pixel (the random-init network with B=2 batch statistics
     amplifies a relative perturbation ~300x — fp32 rounding, 6e-8, shows up as 1.8e-5 in smoke() — so 2.4e-3 per
     GEMM lands at the 1e-2 level; measured 7e-3 / 6.5e-2) — bf16-operand noise, not a different computation — and 10 steps of
@@ -153,8 +157,12 @@ def test_ae_step_bf16_tracks_fp32(medium, dev):
     np_sd = synth.synth_state_dict(synth.ae_state_dict_spec(128), seed=0)
     x = torch.from_numpy(synth.uniform_frames(2, 128, seed=1234)).to(dev)
 
+    from weatherforecastingtoolkit_amd import ops as _ops
+
     def run(prec, steps):
         pkg.set_float32_matmul_precision(prec)
+        if prec == "medium":
+            _ops.set_activation_storage(torch.bfloat16 if storage == "bf16" else torch.float32)
         net = PosAwareAE_TF().to(dev)
         net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in np_sd.items()}, strict=True)
         net.train()
@@ -173,14 +181,18 @@ def test_ae_step_bf16_tracks_fp32(medium, dev):
 
     l_bf, r_bf = run("medium", 10)
     l_fp, r_fp = run("highest", 10)
-    assert abs(l_bf[0] - l_fp[0]) / l_fp[0] < 2e-3, (l_bf[0], l_fp[0])
+    k = 1.0 if storage == "fp32" else 3.0
+    assert abs(l_bf[0] - l_fp[0]) / l_fp[0] < 2e-3 * k, (l_bf[0], l_fp[0])
     d = (r_bf - r_fp).abs()
-    assert float(d.mean()) < 2e-2 and float(d.max()) < 0.15, (float(d.mean()), float(d.max()))
+    assert float(d.mean()) < 2e-2 * k and float(d.max()) < 0.15 * k, (float(d.mean()), float(d.max()))
     assert l_bf[-1] < 0.9 * l_bf[0] and abs(l_bf[-1] - l_fp[-1]) / l_fp[-1] < 0.1, (l_bf, l_fp)
 
 
-def test_gan_step_384_medium_tracks_fp32(dev):
-    """BASELINE config 5's shape on one card: the AE+GAN step of experiments/ae_v2_2 at 384x384 (B = 4, discriminator
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_gan_step_384_medium_tracks_fp32(dev, storage):
+    """(storage bf16: the autoencoder's activations in HBM as bf16 — BASELINE config 5's regime; the discriminator reads the
+    fp32 reconstruction and stays fp32)
+    BASELINE config 5's shape on one card: the AE+GAN step of experiments/ae_v2_2 at 384x384 (B = 4, discriminator
     active) at 'medium' precision — bf16 MFMA operands, the Winograd products on 2-byte operand planes — against the same
     step in fp32 from the same weights: reconstruction and discriminator losses, logits and both gradient norms of the
     first step agree to bf16-operand noise, and three steps move the losses the same way"""
@@ -192,8 +204,11 @@ def test_gan_step_384_medium_tracks_fp32(dev):
     x = torch.from_numpy(synth.uniform_frames(4, 384, seed=77)).to(dev)
     out = {}
     try:
+        from weatherforecastingtoolkit_amd import ops as _ops
         for prec in ("highest", "medium"):
             pkg.set_float32_matmul_precision(prec)
+            if prec == "medium":
+                _ops.set_activation_storage(torch.bfloat16 if storage == "bf16" else torch.float32)
             cfg = C.load(os.path.join(os.path.dirname(exp.__file__), "config.yaml"), CARRIED_KEYS)
             cfg.trainer.total_train_steps = 1000
             cfg.lpips.disc_start = 0

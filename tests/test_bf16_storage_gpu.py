@@ -1,0 +1,245 @@
+"""GPU parity of the bf16 ACTIVATION STORAGE mode (include/wfae.h; BASELINE config 5's bf16 regime): every `_bf16` kernel
+against its fp32 namesake run on the SAME (bf16-representable) values — "fp32 arithmetic on bf16-rounded tensors", results
+rounded to bf16 once.  Kernels whose arithmetic is element-wise or a GEMM with bf16 operands must agree to the final
+rounding (at most one bf16 ulp where a fp32 sum lands on a rounding boundary); reductions to fp64-sum accuracy."""
+import pytest
+import torch
+
+from tests._util import relerr
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * (hi - lo) + lo).float()
+
+
+@pytest.fixture()
+def ops_medium(dev):
+    import weatherforecastingtoolkit_amd as pkg
+    from weatherforecastingtoolkit_amd import ops
+    pkg.set_float32_matmul_precision("medium")
+    assert ops.activation_dtype() == BF
+    try:
+        yield ops
+    finally:
+        pkg.set_float32_matmul_precision("highest")
+        ops.set_winograd("auto")
+        assert ops.activation_dtype() == torch.float32
+
+
+def ulp_close(a_bf16, ref_f32, frac=2e-3):
+    """a (bf16) == round_bf16(ref) except where the fp32 value sits at a rounding boundary: then one bf16 ulp (2^-8 rel)"""
+    a, r = a_bf16.float(), ref_f32.bfloat16().float()
+    exact = (a == r)
+    close = (a - r).abs() <= 2.0 ** -7 * r.abs().clamp_min(1e-30)
+    return bool(close.all()) and float((~exact).float().mean()) <= frac
+
+
+def test_storage_switch_and_convert(dev):
+    import weatherforecastingtoolkit_amd as pkg
+    from weatherforecastingtoolkit_amd import _lib, ops
+    assert ops.activation_dtype() == torch.float32
+    with pytest.raises(_lib.WfaeError):
+        ops.set_activation_storage(BF)            # needs 'medium'
+    pkg.set_float32_matmul_precision("medium")
+    try:
+        assert ops.activation_dtype() == BF
+        ops.set_activation_storage(torch.float32)
+        assert ops.activation_dtype() == torch.float32
+    finally:
+        pkg.set_float32_matmul_precision("highest")
+    for n in (8, 1000, 4099, 1 << 20):
+        x = rnd((n,), n, -3, 3).to(dev)
+        assert torch.equal(ops.to_bf16(x), x.bfloat16())                 # round to nearest even, like torch
+        assert torch.equal(ops.to_f32(x.bfloat16()), x.bfloat16().float())
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 16, 16), (3, 20, 6, 6), (2, 16, 5, 7), (1, 4, 64, 64)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_batchnorm_kernels_bf16(ops_medium, dev, shape, act):
+    ops = ops_medium
+    nb, c, h, w = shape
+    x = rnd(shape, 1, -2, 2).bfloat16().to(dev)
+    dy = rnd(shape, 2).bfloat16().to(dev)
+    res = rnd(shape, 3).bfloat16().to(dev)
+    gamma, beta = (rnd((c,), 4) + 1.5).to(dev), rnd((c,), 5).to(dev)
+    rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    rm2, rv2 = rm.clone(), rv.clone()
+    st = ops.bn_stats_train(x, gamma, beta, rm, rv)
+    st32 = ops.bn_stats_train(x.float(), gamma, beta, rm2, rv2)
+    for a, b in ((st.mean, st32.mean), (st.invstd, st32.invstd), (rm, rm2), (rv, rv2)):
+        assert relerr(a, b) < 2e-7
+    y = ops.bn_act_fwd(x, st32, act)
+    assert y.dtype == BF and ulp_close(y, ops.bn_act_fwd(x.float(), st32, act), 0.0)
+    y2, sp = ops.bn_act_fwd_stats(x, st32, act)
+    assert torch.equal(y2, y)
+    # the sums ride on the ROUNDED values: equal to a statistics pass over y
+    a = ops.bn_stats_from_parts(sp, shape, gamma, beta, None, None)
+    b = ops.bn_stats_train(y, gamma, beta, torch.zeros(c, device=dev), torch.ones(c, device=dev))
+    assert relerr(a.mean, b.mean) < 2e-7 and relerr(a.invstd, b.invstd) < 2e-7
+    for r in (None, res):
+        dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        dg32, db32 = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        dx = ops.bn_act_bwd(dy, x, gamma, st32, dg, db, r, act, True)
+        dx32 = ops.bn_act_bwd(dy.float(), x.float(), gamma, st32, dg32, db32, None if r is None else r.float(), act, True)
+        assert dx.dtype == BF and ulp_close(dx, dx32)
+        assert relerr(dg, dg32) < 2e-6 and relerr(db, db32) < 2e-6
+
+
+@pytest.mark.parametrize("nb,cin,cout,h,w", [(2, 32, 8, 8, 8), (3, 64, 256, 12, 12), (4, 256, 64, 16, 16), (2, 128, 32, 8, 8),
+                                             (1, 1024, 256, 24, 24), (1, 20, 40, 6, 6)])
+def test_conv1x1_bf16_storage(ops_medium, dev, nb, cin, cout, h, w):
+    """forward (+ residual, + BatchNorm / GELU prologue, + BatchNorm sums), data gradient and weight gradient (+ prologue)
+    on bf16-stored activations against the fp32-storage kernels of the same 'medium' arithmetic on the same values"""
+    ops = ops_medium
+    x = rnd((nb, cin, h, w), 1, -2, 2).bfloat16().to(dev)
+    res = rnd((nb, cout, h, w), 2).bfloat16().to(dev)
+    dy = rnd((nb, cout, h, w), 3).bfloat16().to(dev)
+    wt = (rnd((cout, cin, 1, 1), 4) * cin ** -0.5).to(dev)
+    st = ops.BnStats(cin, dev)
+    st.scale.copy_(rnd((cin,), 5) + 1.5)
+    st.shift.copy_(rnd((cin,), 6))
+    y = ops.conv1x1_fwd(x, wt, None, res)
+    assert y.dtype == BF and ulp_close(y, ops.conv1x1_fwd(x.float(), wt, None, res.float()))
+    y2, sr = ops.conv1x1_fwd_stats(x, wt, None, res)
+    assert torch.equal(y2, y)
+    if sr is not None:
+        g, b = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+        s_a = ops.bn_stats_from_rows(sr, tuple(y.shape), g, b, None, None)
+        s_b = ops.bn_stats_train(y, g, b, torch.zeros(cout, device=dev), torch.ones(cout, device=dev))
+        assert relerr(s_a.mean, s_b.mean) < 2e-6 and relerr(s_a.invstd, s_b.invstd) < 2e-6
+    if ops.conv1x1_bnact_supported(x, cout):
+        # prologue: gelu(bn(x)) is rebuilt from the bf16 x in fp32 and rounded to bf16 only as a matrix-core operand —
+        # exactly what the fp32-storage kernel does with the same x
+        yb = ops.conv1x1_fwd_bnact(x, st, wt)
+        assert yb.dtype == BF and ulp_close(yb, ops.conv1x1_fwd_bnact(x.float(), st, wt))
+        dwb, dwb32 = torch.empty_like(wt), torch.empty_like(wt)
+        ops.conv1x1_bwd_weight_bnact(dy, x, st, dwb)
+        ops.conv1x1_bwd_weight_bnact(dy.float(), x.float(), st, dwb32)
+        assert relerr(dwb, dwb32) < 2e-5
+    dx = ops.conv1x1_bwd_data(dy, wt)
+    assert dx.dtype == BF and ulp_close(dx, ops.conv1x1_bwd_data(dy.float(), wt))
+    dw, dw32 = torch.empty_like(wt), torch.empty_like(wt)
+    ops.conv1x1_bwd_weight(dy, x, dw)
+    ops.conv1x1_bwd_weight(dy.float(), x.float(), dw32)
+    assert dw.dtype == torch.float32 and relerr(dw, dw32) < 2e-5
+
+
+@pytest.mark.parametrize("nb,c,groups,h,w", [(2, 32, 8, 16, 16), (2, 64, 8, 12, 12), (1, 128, 8, 16, 16), (2, 256, 8, 8, 8),
+                                             (1, 32, 8, 20, 36)])
+def test_gconv3_bf16_storage(ops_medium, dev, nb, c, groups, h, w):
+    ops = ops_medium
+    x = rnd((nb, c, h, w), 1).bfloat16().to(dev)
+    dy = rnd((nb, c, h, w), 2).bfloat16().to(dev)
+    wt = (rnd((c, c // groups, 3, 3), 3) * 0.2).to(dev)
+    for tr in (False, True):
+        y = ops.gconv3x3_fwd(x, wt, groups, tr)
+        assert y.dtype == BF and ulp_close(y, ops.gconv3x3_fwd(x.float(), wt, groups, tr))
+    dw, dw32 = torch.empty_like(wt), torch.empty_like(wt)
+    ops.gconv3x3_bwd_weight(dy, x, dw, groups)
+    ops.gconv3x3_bwd_weight(dy.float(), x.float(), dw32, groups)
+    assert relerr(dw, dw32) < 2e-5
+
+
+@pytest.mark.parametrize("nb,chi,clo,hlo,wlo", [(2, 32, 64, 8, 8), (1, 64, 32, 16, 16), (2, 128, 256, 4, 8), (1, 32, 32, 64, 64)])
+def test_winograd_transforms_bf16_storage(ops_medium, dev, nb, chi, clo, hlo, wlo):
+    """the four transforms with the tensor side stored as bf16: operand transforms bit-identical to the fp32-tensor form on
+    the same values, result transforms = the fp32 result rounded once; the BatchNorm sums are those of the rounded result"""
+    ops = ops_medium
+    ops.WINO_STATS_MIN_TILES, keep = 0, ops.WINO_STATS_MIN_TILES
+    try:
+        pl = ops.wino_plan(nb, chi, clo, hlo, wlo)
+        assert pl is not None and pl.split and pl.planes == 1
+        hi = rnd((nb, chi, 2 * hlo, 2 * wlo), 1).bfloat16().to(dev)
+        lo = rnd((nb, clo, hlo, wlo), 2).bfloat16().to(dev)
+        wt = (rnd((clo, chi, 4, 4), 3) * 0.1).to(dev)
+        assert torch.equal(ops.wino_in(hi, pl), ops.wino_in(hi.float(), pl))
+        assert torch.equal(ops.wino_out_t(lo, pl), ops.wino_out_t(lo.float(), pl))
+        U = ops.wino_weights(wt, pl)
+        V, Mt = ops.wino_in(hi, pl), ops.wino_out_t(lo, pl)
+        d16, sp = ops.wino_down(U, V, pl, stats=True, out_dtype=BF)
+        d32 = ops.wino_down(U, V, pl)
+        assert d16.dtype == BF and ulp_close(d16, d32, 0.0) and torch.equal(ops.wino_down(U, V, pl, out_dtype=BF), d16)
+        u16, sp2 = ops.wino_up(U, Mt, pl, stats=True, out_dtype=BF)
+        u32 = ops.wino_up(U, Mt, pl)
+        assert u16.dtype == BF and ulp_close(u16, u32, 0.0) and torch.equal(ops.wino_up(U, Mt, pl, out_dtype=BF), u16)
+        for t, p, c in ((d16, sp, clo), (u16, sp2, chi)):
+            g, b = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+            s_a = ops.bn_stats_from_parts(p, tuple(t.shape), g, b, None, None)
+            s_b = ops.bn_stats_train(t, g, b, torch.zeros(c, device=dev), torch.ones(c, device=dev))
+            assert relerr(s_a.mean, s_b.mean) < 2e-6 and relerr(s_a.invstd, s_b.invstd) < 2e-6
+    finally:
+        ops.WINO_STATS_MIN_TILES = keep
+
+
+def test_first_and_last_layer_bf16_storage(ops_medium, dev):
+    """Conv2d(1, C, 4, 2, 1) (fp32 frame -> bf16) and Conv2d(C, 1, 3, 1, 1) (bf16 -> fp32 logits), their data / weight gradients"""
+    ops = ops_medium
+    nb, c, s = 2, 64, 32
+    x = rnd((nb, 1, s, s), 1, 0, 1).to(dev)
+    w1 = (rnd((c, 1, 4, 4), 2) * 0.25).to(dev)
+    t = ops.dconv_fwd(x, w1, None, 4, 2, 1, 1, out_dtype=BF)
+    assert t.dtype == BF and ulp_close(t, ops.dconv_fwd(x, w1, None, 4, 2, 1, 1), 0.0)
+    dt = rnd((nb, c, s // 2, s // 2), 3).bfloat16().to(dev)
+    dw, dw32 = torch.empty_like(w1), torch.empty_like(w1)
+    ops.dconv_bwd_weight(dt, x, dw, 4, 2, 1, 1)
+    ops.dconv_bwd_weight(dt.float(), x, dw32, 4, 2, 1, 1)
+    assert relerr(dw, dw32) < 2e-5
+    a = rnd((nb, c, s, s), 4).bfloat16().to(dev)
+    w2, b2 = (rnd((1, c, 3, 3), 5) * 0.1).to(dev), rnd((1,), 6).to(dev)
+    y = ops.dconv_fwd(a, w2, b2, 3, 1, 1, 1)
+    assert y.dtype == torch.float32 and relerr(y, ops.dconv_fwd(a.float(), w2, b2, 3, 1, 1, 1)) < 2e-6
+    dy = rnd((nb, 1, s, s), 7).to(dev)
+    da = ops.dconv_bwd_data(dy, w2, c, 3, 1, 1, out_dtype=BF)
+    assert da.dtype == BF and ulp_close(da, ops.dconv_bwd_data(dy, w2, c, 3, 1, 1), 0.0)
+    dw2, dw232 = torch.empty_like(w2), torch.empty_like(w2)
+    ops.dconv_bwd_weight(dy, a, dw2, 3, 1, 1, 1)
+    ops.dconv_bwd_weight(dy, a.float(), dw232, 3, 1, 1, 1)
+    assert relerr(dw2, dw232) < 2e-5
+
+
+def test_full_step_runs_in_bf16_storage_and_tracks_fp32_tensors(ops_medium, dev):
+    """the whole AE train step (128 x 128, B = 4): every activation between the kernels of the convolution stacks is bf16
+    (checked with hooks on the stage outputs), parameters / gradients / latent stay fp32, and 12 steps of training follow
+    the 'medium' run with fp32 tensors: same first loss to 5e-3, loss curve within 5 % at the end"""
+    import numpy as np
+    from weatherforecastingtoolkit_amd import functional as Fn, synth
+    from weatherforecastingtoolkit_amd.optim import FusedAdamW
+    from weatherforecastingtoolkit_amd.pipeline.models.ae_64x8x8_lin import PosAwareAE_TF
+    ops = ops_medium
+    np_sd = synth.synth_state_dict(synth.ae_state_dict_spec(128), seed=0)
+    x = torch.from_numpy(synth.blob_events(1, 128, 4, seed=5)[0].transpose(2, 0, 1)[:, None].astype(np.float32) / 255.0).to(dev)
+
+    def run(storage, steps):
+        ops.set_activation_storage(storage)
+        net = PosAwareAE_TF().to(dev)
+        net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in np_sd.items()}, strict=True)
+        net.train()
+        seen = {}
+        hooks = [m.register_forward_hook(lambda mod, i, o, n=n: seen.__setitem__(n, o.dtype))
+                 for n, m in net.named_modules() if n in ("enc.0", "enc.3", "enc.4", "dec.0", "dec.1", "dec.4", "dec.5")]
+        opt = FusedAdamW(net.parameters(), lr=5e-5, weight_decay=1e-4)
+        losses = []
+        for _ in range(steps):
+            recon, z = net(x)
+            loss = Fn.l1_loss(recon, x)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        for h in hooks:
+            h.remove()
+        assert recon.dtype == torch.float32 and z.dtype == torch.float32
+        assert all(p.grad.dtype == torch.float32 for p in net.parameters())
+        return losses, seen
+
+    l16, seen16 = run(BF, 12)
+    l32, seen32 = run(torch.float32, 12)
+    assert all(seen16[n] == BF for n in ("enc.0", "enc.3", "dec.1", "dec.4")), seen16
+    assert all(seen16[n] == torch.float32 for n in ("enc.4", "dec.0", "dec.5")), seen16
+    assert all(v == torch.float32 for v in seen32.values())
+    assert abs(l16[0] - l32[0]) < 5e-3 * l32[0], (l16[0], l32[0])
+    assert l16[-1] < 0.9 * l16[0] and abs(l16[-1] - l32[-1]) < 0.05 * l32[-1], (l16, l32)

@@ -113,10 +113,78 @@ __device__ __forceinline__ void split3(float x, unsigned short& h, unsigned shor
   l = __builtin_bit_cast(unsigned short, bl);
 }
 
+// ---- activation storage type: fp32, or bf16 bit patterns (torch.bfloat16) in the bf16-storage mode of 'medium' precision
+// (BASELINE config 5: the reference's bf16 regime).  All arithmetic stays fp32: a kernel templated on the element type T
+// reads W = 16 / sizeof(T) elements per 16-byte access (4 floats or 8 bf16 — every lane keeps moving whole 16-byte pieces,
+// the width this chip's memory pipeline is built for), widens them to fp32 registers and rounds results to nearest even
+// (v_cvt_pk_bf16_f32) on the way out.
+typedef unsigned short bf16_t;
+typedef float wfae_vf4 __attribute__((ext_vector_type(4)));
+typedef unsigned wfae_vu4 __attribute__((ext_vector_type(4)));
+typedef float wfae_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wfae_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {   // a -> low half, b -> high half
+  const wfae_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wfae_bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+template <typename T> struct ElemW { static constexpr int W = 16 / (int)sizeof(T); };
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return __builtin_bit_cast(float, (unsigned)*p << 16); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { *p = (bf16_t)(pack_bf16(v, 0.f) & 0xffffu); }
+// one 16-byte access: 4 floats / 8 bf16 -> v[0..W); NT: nontemporal
+template <bool NT = false>
+__device__ __forceinline__ void ldv(const float* p, float (&v)[4]) {
+  const wfae_vf4 r = NT ? __builtin_nontemporal_load(reinterpret_cast<const wfae_vf4*>(p)) : *reinterpret_cast<const wfae_vf4*>(p);
+  v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+}
+template <bool NT = false>
+__device__ __forceinline__ void ldv(const bf16_t* p, float (&v)[8]) {
+  const wfae_vu4 r = NT ? __builtin_nontemporal_load(reinterpret_cast<const wfae_vu4*>(p)) : *reinterpret_cast<const wfae_vu4*>(p);
+  v[0] = bf16_lo(r.x); v[1] = bf16_hi(r.x); v[2] = bf16_lo(r.y); v[3] = bf16_hi(r.y);
+  v[4] = bf16_lo(r.z); v[5] = bf16_hi(r.z); v[6] = bf16_lo(r.w); v[7] = bf16_hi(r.w);
+}
+template <bool NT = false>
+__device__ __forceinline__ void stv(float* p, const float (&v)[4]) {
+  const wfae_vf4 r = {v[0], v[1], v[2], v[3]};
+  if (NT) __builtin_nontemporal_store(r, reinterpret_cast<wfae_vf4*>(p));
+  else *reinterpret_cast<wfae_vf4*>(p) = r;
+}
+template <bool NT = false>
+__device__ __forceinline__ void stv(bf16_t* p, const float (&v)[8]) {
+  const wfae_vu4 r = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+  if (NT) __builtin_nontemporal_store(r, reinterpret_cast<wfae_vu4*>(p));
+  else *reinterpret_cast<wfae_vu4*>(p) = r;
+}
+// half-width access: 4 elements (16 bytes of fp32, 8 bytes of bf16) — loaders whose thread map is built on quads
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+  const uint2 r = *reinterpret_cast<const uint2*>(p);
+  return make_float4(bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y));
+}
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ float2 ld2(const bf16_t* p) {
+  const unsigned r = *reinterpret_cast<const unsigned*>(p);
+  return make_float2(bf16_lo(r), bf16_hi(r));
+}
+__device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+__device__ __forceinline__ void st2(bf16_t* p, float2 v) { *reinterpret_cast<unsigned*>(p) = pack_bf16(v.x, v.y); }
+// value a reader of a tensor of element type T sees after v was stored
+__device__ __forceinline__ float rounded_as(const float*, float v) { return v; }
+__device__ __forceinline__ float rounded_as(const bf16_t*, float v) { return bf16_lo(pack_bf16(v, 0.f)); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+}
+
 // Conv2d(C, 1, 3, padding=1): the decoder's full-resolution output convolution (c1conv.hip)
 int c1conv3_fwd(const float* x, const float* w, const float* bias, float* y, int NB, int C, int H, int W, hipStream_t st);
 int c1_wgrad_mfma(int flip, const float* big, const float* small, float* dw, int NB, int C, int H, int W, int accumulate,
                   void* ws, size_t ws_bytes, hipStream_t st);   // dconv.hip: weight gradients with one channel count = 1
+int c1_wgrad_mfma(int flip, const unsigned short* big, const float* small, float* dw, int NB, int C, int H, int W, int accumulate,
+                  void* ws, size_t ws_bytes, hipStream_t st);   // `big` stored as bf16
 int c1conv3_wgrad(const float* dy, const float* x, float* dw, int NB, int C, int H, int W, int accumulate, void* ws,
                   size_t ws_bytes, hipStream_t st);
 
@@ -134,6 +202,13 @@ int wino_weights(int variant, const float* w, float* U, int Clo, int Chi, hipStr
 // bf16-plane forms of the GEMM operands (splitgemm.hip) and the GEMM itself
 int wino_in_split(int variant, const float* hi, unsigned short* V3, int planes, int NB, int Chi, int Hlo, int Wlo, hipStream_t st);
 int wino_out_t_split(int variant, const float* lo, unsigned short* Mt3, int planes, int NB, int Clo, int Hlo, int Wlo, hipStream_t st);
+// bf16-stored tensors (hi / lo as bf16 bit patterns): the operand transforms read them, the result transforms write them
+int wino_in_split(int variant, const unsigned short* hi, unsigned short* V3, int planes, int NB, int Chi, int Hlo, int Wlo, hipStream_t st);
+int wino_out_t_split(int variant, const unsigned short* lo, unsigned short* Mt3, int planes, int NB, int Clo, int Hlo, int Wlo, hipStream_t st);
+int wino_in_t(int variant, const float* dV, unsigned short* hi, int NB, int Chi, int Hlo, int Wlo, hipStream_t st);
+int wino_in_t_stats(int variant, const float* dV, unsigned short* hi, int NB, int Chi, int Hlo, int Wlo, double* part, hipStream_t st);
+int wino_out(int variant, const float* M, unsigned short* lo, int NB, int Clo, int Hlo, int Wlo, hipStream_t st);
+int wino_out_stats(int variant, const float* M, unsigned short* lo, int NB, int Clo, int Hlo, int Wlo, double* part, hipStream_t st);
 int wino_weights_split(int variant, const float* w, unsigned short* U3, unsigned short* Ut3, int planes, int Clo, int Chi,
                        hipStream_t st);
 int split_gemm(int kind, int planes, const unsigned short* A, const unsigned short* B, float* C, int M, int N, int K,
@@ -150,5 +225,7 @@ int gconv3_wgrad_valu(const float* dy, const float* x, float* dw, int NB, int C,
                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 int gconv3_wgrad_mfma(const float* dy, const float* x, float* dw, int NB, int C, int H, int W, int groups,
                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+int gconv3_wgrad_mfma(const unsigned short* dy, const unsigned short* x, float* dw, int NB, int C, int H, int W, int groups,
+                      int accumulate, void* ws, size_t ws_bytes, hipStream_t st);   // bf16-stored activations
 
 }  // namespace wfae

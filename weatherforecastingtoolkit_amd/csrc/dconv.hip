@@ -15,10 +15,10 @@ using namespace wfae;
 namespace {
 
 struct DConvP {
-  const float* x;
+  const void* x;   // element type XT of the kernel (float, or bf16_t in the bf16-storage mode)
   const float* w;
   const float* bias;
-  float* y;
+  void* y;         // element type YT
   int Cin, Cout, H, W, Ho, Wo, pad, groups;
   int tiles_x;
 };
@@ -26,7 +26,7 @@ struct DConvP {
 // TRANSPOSED: weights are read as the data-gradient operator of a stride-1
 // conv: w'(o,i,tap) = w[(g*IG + i)][o][KK-1-tap] with the original tensor laid
 // out [groups*IG][OG][KS][KS].
-template <int KS, int S, int OCB, bool TRANSPOSED>
+template <int KS, int S, int OCB, bool TRANSPOSED, typename XT = float, typename YT = float>
 __global__ __launch_bounds__(256) void dconv_fwd_kernel(DConvP p) {
   constexpr int KK = KS * KS;
   // 8 x 32 output tiles: a tile row is one whole 128-byte line of y (measured a few % better than 16 x 16 on the
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(DConvP p) {
 #pragma unroll
   for (int o = 0; o < OCB; ++o) acc[o] = 0.f;
 
-  const float* xg = p.x + ((long)n * p.Cin + (long)g * IG) * p.H * p.W;
+  const XT* xg = reinterpret_cast<const XT*>(p.x) + ((long)n * p.Cin + (long)g * IG) * p.H * p.W;
   const int iy_base = oy0 * S - p.pad, ix_base = ox0 * S - p.pad;
 
   for (int ci0 = 0; ci0 < IG; ci0 += CIB) {
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(DConvP p) {
         const int ry = r / TIW, rx = r - ry * TIW;
         const int iy = iy_base + ry, ix = ix_base + rx;
         const bool ok = idx < CIB * TIH * TIW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        const float v = xg[ok ? ((long)(ci0 + c) * p.H + iy) * p.W + ix : 0];
+        const float v = ld1(xg + (ok ? ((long)(ci0 + c) * p.H + iy) * p.W + ix : 0));
         rv[j] = ok ? v : 0.f;
       }
 #pragma unroll
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(DConvP p) {
         const int ry = r / TIW, rx = r - ry * TIW;
         const int iy = iy_base + ry, ix = ix_base + rx;
         float v = 0.f;
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = xg[((long)(ci0 + c) * p.H + iy) * p.W + ix];
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = ld1(xg + ((long)(ci0 + c) * p.H + iy) * p.W + ix);
         xs[c][ry][rx] = v;
       }
     }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(DConvP p) {
     for (int o = 0; o < OCB; ++o) {
       float v = acc[o];
       if (p.bias) v += p.bias[o0 + o];
-      p.y[(((long)n * p.Cout + o0 + o) * p.Ho + oy) * p.Wo + ox] = v;
+      st1(reinterpret_cast<YT*>(p.y) + (((long)n * p.Cout + o0 + o) * p.Ho + oy) * p.Wo + ox, v);
     }
   }
 }
@@ -131,9 +131,9 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(DConvP p) {
 // pixels in registers, walks the channels with wave-uniform (scalar) weight loads and streams one float4 per channel
 // to HBM — no LDS, whole 1 KB row segments per wave store.  HBM-bound on the write of y.
 // -------------------------------------------------------------------------------------
-template <int KS, int S, bool FLIP>
+template <int KS, int S, bool FLIP, typename YT = float>
 __global__ __launch_bounds__(256) void c1in_conv_kernel(const float* __restrict__ s_, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* __restrict__ y, int C,
+                                                        const float* __restrict__ bias, YT* __restrict__ y, int C,
                                                         int Hs, int Ws, int Ho, int Wo, int pad, int cpb) {
   constexpr int KK = KS * KS, NW = 3 * S + KS;   // neighbourhood: KS rows x NW columns
   const int WQ = Wo >> 2;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void c1in_conv_kernel(const float* __restrict_
   }
   const int c0 = blockIdx.y * cpb;
   const int c1 = min(C, c0 + cpb);
-  float* __restrict__ yp = y + ((long)n * C + c0) * Ho * Wo + (long)oy * Wo + ox;
+  YT* __restrict__ yp = y + ((long)n * C + c0) * Ho * Wo + (long)oy * Wo + ox;
   const long plane = (long)Ho * Wo;
 #pragma unroll 2
   for (int c = c0; c < c1; ++c) {
@@ -173,20 +173,25 @@ __global__ __launch_bounds__(256) void c1in_conv_kernel(const float* __restrict_
         o2 = fmaf(nb[ky][2 * S + kx], wv, o2);
         o3 = fmaf(nb[ky][3 * S + kx], wv, o3);
       }
-    typedef float vf4s __attribute__((ext_vector_type(4)));
-    const vf4s o = {o0, o1, o2, o3};
-    __builtin_nontemporal_store(o, reinterpret_cast<vf4s*>(yp));
+    if constexpr (sizeof(YT) == 4) {
+      typedef float vf4s __attribute__((ext_vector_type(4)));
+      const vf4s o = {o0, o1, o2, o3};
+      __builtin_nontemporal_store(o, reinterpret_cast<vf4s*>(yp));
+    } else {
+      typedef unsigned vu2s __attribute__((ext_vector_type(2)));
+      const vu2s o = {pack_bf16(o0, o1), pack_bf16(o2, o3)};
+      __builtin_nontemporal_store(o, reinterpret_cast<vu2s*>(yp));
+    }
     yp += plane;
   }
 }
 
 // s: (N,1,Hs,Ws); y: (N,C,Ho,Wo); w: C x KS x KS taps (flip: used mirrored).  WFAE_ERR_UNSUPPORTED when Wo % 4 != 0
 // or y is not 16-byte aligned (the generic kernels then run).
-template <int KS, int S, bool FLIP>
-int launch_c1in_conv(const float* s_, const float* w, const float* bias, float* y, int NB, int C, int Hs, int Ws, int Ho,
+template <int KS, int S, bool FLIP, typename YT = float>
+int launch_c1in_conv(const float* s_, const float* w, const float* bias, YT* y, int NB, int C, int Hs, int Ws, int Ho,
                      int Wo, int pad, hipStream_t st) {
-  static const int on = getenv("WFAE_C1IN_CONV") ? atoi(getenv("WFAE_C1IN_CONV")) : 1;
-  if (!on || Wo % 4 != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0 || NB > 65535) return WFAE_ERR_UNSUPPORTED;
+  if (Wo % 4 != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0 || NB > 65535) return WFAE_ERR_UNSUPPORTED;
   const long threads = (long)Ho * (Wo / 4);
   const int bx = cdiv(threads, 256);
   // channel chunks so that the grid has a few thousand blocks; every chunk re-reads the (tiny) one-channel input
@@ -194,22 +199,22 @@ int launch_c1in_conv(const float* s_, const float* w, const float* bias, float* 
   if (chunks < 1) chunks = 1;
   if (chunks > C) chunks = C;
   const int cpb = cdiv(C, chunks);
-  hipLaunchKernelGGL((c1in_conv_kernel<KS, S, FLIP>), dim3(bx, cdiv(C, cpb), NB), dim3(256), 0, st, s_, w, bias, y, C, Hs,
+  hipLaunchKernelGGL((c1in_conv_kernel<KS, S, FLIP, YT>), dim3(bx, cdiv(C, cpb), NB), dim3(256), 0, st, s_, w, bias, y, C, Hs,
                      Ws, Ho, Wo, pad, cpb);
   return check_launch("c1in_conv");
 }
 
-template <int KS, int S, bool TR>
+template <int KS, int S, bool TR, typename XT = float, typename YT = float>
 int launch_dconv(const DConvP& p, int NB, hipStream_t st) {
   const int OG = p.Cout / p.groups;
   const int tiles = p.tiles_x * cdiv(p.Ho, 8);
   dim3 block(256);
   if (OG % 8 == 0) {
-    hipLaunchKernelGGL((dconv_fwd_kernel<KS, S, 8, TR>), dim3(tiles, p.Cout / 8, NB), block, 0, st, p);
+    hipLaunchKernelGGL((dconv_fwd_kernel<KS, S, 8, TR, XT, YT>), dim3(tiles, p.Cout / 8, NB), block, 0, st, p);
   } else if (OG % 4 == 0) {
-    hipLaunchKernelGGL((dconv_fwd_kernel<KS, S, 4, TR>), dim3(tiles, p.Cout / 4, NB), block, 0, st, p);
+    hipLaunchKernelGGL((dconv_fwd_kernel<KS, S, 4, TR, XT, YT>), dim3(tiles, p.Cout / 4, NB), block, 0, st, p);
   } else {
-    hipLaunchKernelGGL((dconv_fwd_kernel<KS, S, 1, TR>), dim3(tiles, p.Cout, NB), block, 0, st, p);
+    hipLaunchKernelGGL((dconv_fwd_kernel<KS, S, 1, TR, XT, YT>), dim3(tiles, p.Cout, NB), block, 0, st, p);
   }
   return check_launch("dconv");
 }
@@ -364,7 +369,7 @@ int wfae_dconv_fwd(const float* x, const float* w, const float* bias, float* y, 
       return c1conv3_fwd(x, w, bias, y, NB, Cin, H, W, (hipStream_t)stream);
   }
   if (Cin == 1 && groups == 1 && KS == 4 && stride == 2 && pad == 1 && !(H & 1) && !(W & 1)) {
-    const int rc = launch_c1in_conv<4, 2, false>(x, w, bias, y, NB, Cout, H, W, H / 2, W / 2, 1, (hipStream_t)stream);
+    const int rc = launch_c1in_conv<4, 2, false, float>(x, w, bias, y, NB, Cout, H, W, H / 2, W / 2, 1, (hipStream_t)stream);
     if (rc != WFAE_ERR_UNSUPPORTED) return rc;
   }
   DConvP p = {};
@@ -391,7 +396,7 @@ int wfae_dconv_bwd_data(const float* dy, const float* w, float* dx, int NB, int 
   WFAE_REQUIRE(NB <= 65535, WFAE_ERR_BAD_SHAPE, "dconv_bwd_data: batch > 65535");
   if (Cout == 1 && groups == 1 && KS == 3 && pad == 1) {
     // one-channel dy: dx[c][p] = sum_tap w[0][c][tap] dy[p + 1 - tap] = a 3x3 convolution of dy with the flipped taps
-    const int rc = launch_c1in_conv<3, 1, true>(dy, w, nullptr, dx, NB, Cin, H, W, H, W, 1, (hipStream_t)stream);
+    const int rc = launch_c1in_conv<3, 1, true, float>(dy, w, nullptr, dx, NB, Cin, H, W, H, W, 1, (hipStream_t)stream);
     if (rc != WFAE_ERR_UNSUPPORTED) return rc;
   }
   // data gradient = stride-1 convolution of dy (Cout channels, (H+2pad-KS+1) x (W+2pad-KS+1)) producing the
@@ -490,6 +495,49 @@ int wfae_dconv_bwd_weight(const float* dy, const float* x, float* dw, int NB, in
   return slab_reduce((const float*)ws, dw, nullptr, (long)out_elems, 1, (int)parts, accumulate, st);
 }
 
+// bf16 storage: the two full-resolution convolutions with ONE channel on one side keep that side fp32 —
+//   dconv_fwd_bf16out:      Conv2d(1, C, 4, 2, 1) forward (the encoder's first layer, ae_64x8x8_lin.py:31): x fp32 -> y bf16
+//   dconv_fwd_bf16in:       Conv2d(C, 1, 3, 1, 1) forward (the output convolution, :84): x bf16 -> y fp32
+//   dconv_bwd_data_bf16out: its data gradient, dy fp32 (one channel) -> dx bf16
+//   c1_wgrad_bf16:          their weight gradients: flip 0: big = dy bf16 (N,C,H/2,W/2), small = x fp32 (N,1,H,W);
+//                           flip 1: big = x bf16 (N,C,H,W), small = dy fp32 (N,1,H,W)
+int wfae_dconv_fwd_bf16out(const float* x, const float* w, const float* bias, uint16_t* y, int NB, int Cout, int H, int W,
+                           wfae_stream_t stream) {
+  WFAE_REQUIRE(x && w && y, WFAE_ERR_NULL_POINTER, "dconv_fwd_bf16out: null pointer");
+  WFAE_REQUIRE(NB > 0 && Cout > 0 && H > 0 && W > 0 && !(H & 1) && !(W & 1), WFAE_ERR_BAD_SHAPE, "dconv_fwd_bf16out: bad shape");
+  const int rc = launch_c1in_conv<4, 2, false, bf16_t>(x, w, bias, y, NB, Cout, H, W, H / 2, W / 2, 1, (hipStream_t)stream);
+  if (rc == WFAE_ERR_UNSUPPORTED) return fail(rc, "dconv_fwd_bf16out: needs W %% 8 == 0 and a 16-byte aligned result");
+  return rc;
+}
+int wfae_dconv_fwd_bf16in(const uint16_t* x, const float* w, const float* bias, float* y, int NB, int Cin, int Cout, int H,
+                          int W, wfae_stream_t stream) {
+  WFAE_REQUIRE(x && w && y, WFAE_ERR_NULL_POINTER, "dconv_fwd_bf16in: null pointer");
+  WFAE_REQUIRE(NB > 0 && NB <= 65535 && Cin > 0 && Cout > 0 && H > 0 && W > 0, WFAE_ERR_BAD_SHAPE, "dconv_fwd_bf16in: bad shape");
+  DConvP p = {};
+  p.x = x; p.w = w; p.bias = bias; p.y = y;
+  p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.pad = 1; p.groups = 1;
+  p.Ho = H; p.Wo = W;
+  p.tiles_x = cdiv(p.Wo, 32);
+  return launch_dconv<3, 1, false, bf16_t, float>(p, NB, (hipStream_t)stream);
+}
+int wfae_dconv_bwd_data_bf16out(const float* dy, const float* w, uint16_t* dx, int NB, int Cin, int H, int W,
+                                wfae_stream_t stream) {
+  WFAE_REQUIRE(dy && w && dx, WFAE_ERR_NULL_POINTER, "dconv_bwd_data_bf16out: null pointer");
+  WFAE_REQUIRE(NB > 0 && Cin > 0 && H > 0 && W > 0, WFAE_ERR_BAD_SHAPE, "dconv_bwd_data_bf16out: bad shape");
+  const int rc = launch_c1in_conv<3, 1, true, bf16_t>(dy, w, nullptr, dx, NB, Cin, H, W, H, W, 1, (hipStream_t)stream);
+  if (rc == WFAE_ERR_UNSUPPORTED) return fail(rc, "dconv_bwd_data_bf16out: needs W %% 4 == 0 and a 16-byte aligned result");
+  return rc;
+}
+int wfae_c1_wgrad_bf16(int flip, const uint16_t* big, const float* small, float* dw, int NB, int C, int H, int W, int accumulate,
+                       void* ws, size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(big && small && dw, WFAE_ERR_NULL_POINTER, "c1_wgrad_bf16: null pointer");
+  WFAE_REQUIRE(NB > 0 && C > 0 && H > 0 && W > 0, WFAE_ERR_BAD_SHAPE, "c1_wgrad_bf16: bad shape");
+  const int rc = c1_wgrad_mfma(flip, big, small, dw, NB, C, H, W, accumulate, ws, ws_bytes, (hipStream_t)stream);
+  if (rc == WFAE_ERR_UNSUPPORTED)
+    return fail(rc, "c1_wgrad_bf16: needs C %% 64 == 0, even sizes, W %% 4 == 0 of the big tensor, aligned tensors, workspace");
+  return rc;
+}
+
 }  // extern "C"
 
 // =====================================================================================
@@ -501,9 +549,9 @@ int wfae_dconv_bwd_weight(const float* dy, const float* x, float* dw, int NB, in
 // =====================================================================================
 namespace {
 
-template <int CPG, int PY>
-__global__ __launch_bounds__(256) void gconv3_kernel(const float* __restrict__ x, const float* __restrict__ wp,
-                                                     float* __restrict__ y, int C, int H, int W, int tiles_x) {
+template <int CPG, int PY, typename T = float>
+__global__ __launch_bounds__(256) void gconv3_kernel(const T* __restrict__ x, const float* __restrict__ wp,
+                                                     T* __restrict__ y, int C, int H, int W, int tiles_x) {
   constexpr int TH = 16 * PY, TW = 32;
   constexpr int CIB = CPG < 8 ? CPG : 8;
   constexpr int IH = TH + 2, IWU = TW + 2, IW = 36;
@@ -512,7 +560,7 @@ __global__ __launch_bounds__(256) void gconv3_kernel(const float* __restrict__ x
   const int tx = t & 15, ty = t >> 4;
   const int oy0 = (blockIdx.x / tiles_x) * TH, ox0 = (blockIdx.x % tiles_x) * TW;
   const int g = blockIdx.y, n = blockIdx.z;
-  const float* xg = x + ((long)n * C + (long)g * CPG) * H * W;
+  const T* xg = x + ((long)n * C + (long)g * CPG) * H * W;
 
   float acc[PY][2][CPG];
 #pragma unroll
@@ -540,7 +588,7 @@ __global__ __launch_bounds__(256) void gconv3_kernel(const float* __restrict__ x
       const int ry = r / IWU, rx = r - ry * IWU;
       const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
       const bool ok = idx < NEL && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      sv[i] = xg[ok ? ((long)(ci0 + c) * H + iy) * W + ix : 0];
+      sv[i] = ld1(xg + (ok ? ((long)(ci0 + c) * H + iy) * W + ix : 0));
       so[i] = idx < NEL ? (ok ? (c * IH + ry) * IW + rx : -1 - ((c * IH + ry) * IW + rx)) : (1 << 30);
     }
     __syncthreads();
@@ -579,14 +627,17 @@ __global__ __launch_bounds__(256) void gconv3_kernel(const float* __restrict__ x
   for (int a = 0; a < PY; ++a) {
     const int oy = oy0 + ty * PY + a;
     if (oy < H && ox < W) {
-      float* yp = y + (((long)n * C + (long)g * CPG) * H + oy) * W + ox;
+      T* yp = y + (((long)n * C + (long)g * CPG) * H + oy) * W + ox;
 #pragma unroll
       for (int o = 0; o < CPG; ++o) {
-        if (ox + 1 < W && (W & 1) == 0)
-          *reinterpret_cast<float2*>(yp + (long)o * H * W) = make_float2(acc[a][0][o], acc[a][1][o]);
-        else {
-          yp[(long)o * H * W] = acc[a][0][o];
-          if (ox + 1 < W) yp[(long)o * H * W + 1] = acc[a][1][o];
+        if (ox + 1 < W && (W & 1) == 0) {
+          if constexpr (sizeof(T) == 4)
+            *reinterpret_cast<float2*>(yp + (long)o * H * W) = make_float2(acc[a][0][o], acc[a][1][o]);
+          else
+            *reinterpret_cast<unsigned*>(yp + (long)o * H * W) = pack_bf16(acc[a][0][o], acc[a][1][o]);
+        } else {
+          st1(yp + (long)o * H * W, acc[a][0][o]);
+          if (ox + 1 < W) st1(yp + (long)o * H * W + 1, acc[a][1][o]);
         }
       }
     }
@@ -606,9 +657,9 @@ __global__ __launch_bounds__(256) void gconv3_kernel(const float* __restrict__ x
 typedef float g3_f32x16 __attribute__((ext_vector_type(16)));
 typedef float g3_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int CPG>
-__global__ __launch_bounds__(256) void gconv3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
-                                                          float* __restrict__ y, int C, int H, int W, int tiles_x) {
+template <int CPG, typename T = float>
+__global__ __launch_bounds__(256) void gconv3_mfma_kernel(const T* __restrict__ x, const float* __restrict__ wp,
+                                                          T* __restrict__ y, int C, int H, int W, int tiles_x) {
   static_assert(CPG == 32 || CPG == 16, "one MFMA tile of output channels");
   constexpr int MF = CPG;             // MFMA tile edge
   constexpr int KL = 64 / MF;         // k lane groups of the MFMA: 2 (32x32x2) / 4 (16x16x4)
@@ -629,7 +680,7 @@ __global__ __launch_bounds__(256) void gconv3_mfma_kernel(const float* __restric
   const int oy0 = (blockIdx.x / tiles_x) * 16, ox0 = (blockIdx.x % tiles_x) * 16;
   const int g = blockIdx.y, n = blockIdx.z;
   const long HW = (long)H * W;
-  const float* __restrict__ xg = x + ((long)n * C + (long)g * CPG) * HW;
+  const T* __restrict__ xg = x + ((long)n * C + (long)g * CPG) * HW;
   const float* __restrict__ wg = wp + (long)g * CPG * 9 * CPG;
 
   int goff[NSLOT], loff[NSLOT];
@@ -660,8 +711,8 @@ __global__ __launch_bounds__(256) void gconv3_mfma_kernel(const float* __restric
 
 #define WFAE_G3_LOAD(CH)                                                                     \
   {                                                                                          \
-    const float* __restrict__ xc = xg + (long)(CH) * 8 * HW;                                 \
-    _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) rx_[j] = xc[goff[j]];                  \
+    const T* __restrict__ xc = xg + (long)(CH) * 8 * HW;                                     \
+    _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) rx_[j] = ld1(xc + goff[j]);            \
     const float4* __restrict__ wc = reinterpret_cast<const float4*>(wg + (long)(CH) * WS);   \
     _Pragma("unroll") for (int j = 0; j < WSLOT; ++j) {                                      \
       const int idx = t + j * 256;                                                           \
@@ -715,7 +766,7 @@ __global__ __launch_bounds__(256) void gconv3_mfma_kernel(const float* __restric
 
   // C/D layout: column = lane % MF (the pixel), row = output channel:
   //   32x32: (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5);   16x16: 4 (lane >> 4) + reg
-  float* __restrict__ yg = y + ((long)n * C + (long)g * CPG) * HW + (long)oy0 * W + ox0 + xl;
+  T* __restrict__ yg = y + ((long)n * C + (long)g * CPG) * HW + (long)oy0 * W + ox0 + xl;
   const bool xin = ox0 + xl < W;  // partial tiles at the right / bottom edge
 #pragma unroll
   for (int i = 0; i < NTW; ++i) {
@@ -724,7 +775,7 @@ __global__ __launch_bounds__(256) void gconv3_mfma_kernel(const float* __restric
 #pragma unroll
     for (int r = 0; r < NACC; ++r) {
       const int m = MF == 32 ? (r & 3) + 8 * (r >> 2) + 4 * kk : 4 * kk + r;
-      yg[(long)m * HW + (long)row * W] = acc[i][r];
+      st1(yg + (long)m * HW + (long)row * W, acc[i][r]);
     }
   }
 }
@@ -744,26 +795,25 @@ __global__ void gconv3_pack_kernel(const float* __restrict__ w, float* __restric
                       : w[((long)(g * CPG + o) * CPG + i) * 9 + tap];
 }
 
-template <int CPG>
-int launch_gconv3_mfma(const float* x, const float* wp, float* y, int NB, int C, int H, int W, hipStream_t st) {
+template <int CPG, typename T>
+int launch_gconv3_mfma(const T* x, const float* wp, T* y, int NB, int C, int H, int W, hipStream_t st) {
   const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, 16);
-  hipLaunchKernelGGL((gconv3_mfma_kernel<CPG>), dim3(tiles_x * tiles_y, C / CPG, NB), dim3(256), 0, st, x, wp, y, C, H,
+  hipLaunchKernelGGL((gconv3_mfma_kernel<CPG, T>), dim3(tiles_x * tiles_y, C / CPG, NB), dim3(256), 0, st, x, wp, y, C, H,
                      W, tiles_x);
   return check_launch("gconv3_mfma");
 }
 
-template <int CPG, int PY>
-int launch_gconv3(const float* x, const float* wp, float* y, int NB, int C, int H, int W, hipStream_t st) {
+template <int CPG, int PY, typename T>
+int launch_gconv3(const T* x, const float* wp, T* y, int NB, int C, int H, int W, hipStream_t st) {
   const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 16 * PY);
-  hipLaunchKernelGGL((gconv3_kernel<CPG, PY>), dim3(tiles_x * tiles_y, C / CPG, NB), dim3(256), 0, st, x, wp, y, C, H,
+  hipLaunchKernelGGL((gconv3_kernel<CPG, PY, T>), dim3(tiles_x * tiles_y, C / CPG, NB), dim3(256), 0, st, x, wp, y, C, H,
                      W, tiles_x);
   return check_launch("gconv3");
 }
 
-}  // namespace
-
-extern "C" int wfae_gconv3x3_fwd(const float* x, const float* w, float* y, int NB, int C, int H, int W, int groups,
-                                 int transposed, void* ws, size_t ws_bytes, wfae_stream_t stream) {
+template <typename T>
+int gconv3x3_fwd_impl(const T* x, const float* w, T* y, int NB, int C, int H, int W, int groups, int transposed, void* ws,
+                      size_t ws_bytes, wfae_stream_t stream) {
   WFAE_REQUIRE(x && w && y, WFAE_ERR_NULL_POINTER, "gconv3x3_fwd: null pointer");
   WFAE_REQUIRE(NB > 0 && NB <= 65535 && C > 0 && H > 0 && W > 0 && groups > 0 && C % groups == 0, WFAE_ERR_BAD_SHAPE,
                "gconv3x3_fwd: bad shape");
@@ -778,36 +828,29 @@ extern "C" int wfae_gconv3x3_fwd(const float* x, const float* w, float* y, int N
   int rc = check_launch("gconv3_pack");
   if (rc) return rc;
   const float* wp = (const float*)ws;
-  // 16 / 32 channels per group: the MFMA form on 16 x 16 pixel tiles (partial at the edges) (WFAE_G3_FWD_MFMA=0 keeps the VALU kernel)
-  static const int use_mfma = getenv("WFAE_G3_FWD_MFMA") ? atoi(getenv("WFAE_G3_FWD_MFMA")) : 1;
-  if (use_mfma && cpg >= 16 && (long)cpg * H * W < (1l << 28)) {
+  // 16 / 32 channels per group: the MFMA form on 16 x 16 pixel tiles (partial at the edges)
+  if (cpg >= 16 && (long)cpg * H * W < (1l << 28)) {
     if (cpg == 32) return launch_gconv3_mfma<32>(x, wp, y, NB, C, H, W, st);
     return launch_gconv3_mfma<16>(x, wp, y, NB, C, H, W, st);
   }
-  // rows per thread: measured 1 < 2 < 4 in time (the kernel is latency-bound: smaller LDS tiles, more blocks per CU)
-  static const int py_big = getenv("WFAE_G3_PY") ? atoi(getenv("WFAE_G3_PY")) : 1;
-  if (py_big == 1) {
-    switch (cpg) {
-      case 4: return launch_gconv3<4, 1>(x, wp, y, NB, C, H, W, st);
-      case 8: return launch_gconv3<8, 1>(x, wp, y, NB, C, H, W, st);
-      case 16: return launch_gconv3<16, 1>(x, wp, y, NB, C, H, W, st);
-      default: return launch_gconv3<32, 1>(x, wp, y, NB, C, H, W, st);
-    }
-  }
-  if (py_big == 4) {
-    switch (cpg) {
-      case 4: return launch_gconv3<4, 4>(x, wp, y, NB, C, H, W, st);
-      case 8: return launch_gconv3<8, 4>(x, wp, y, NB, C, H, W, st);
-      case 16: return launch_gconv3<16, 4>(x, wp, y, NB, C, H, W, st);
-      default: return launch_gconv3<32, 2>(x, wp, y, NB, C, H, W, st);
-    }
-  }
+  // one row per thread: measured 1 < 2 < 4 in time (the kernel is latency-bound: smaller LDS tiles, more blocks per CU)
   switch (cpg) {
-    case 4: return launch_gconv3<4, 2>(x, wp, y, NB, C, H, W, st);
-    case 8: return launch_gconv3<8, 2>(x, wp, y, NB, C, H, W, st);
-    case 16: return launch_gconv3<16, 2>(x, wp, y, NB, C, H, W, st);
+    case 4: return launch_gconv3<4, 1>(x, wp, y, NB, C, H, W, st);
+    case 8: return launch_gconv3<8, 1>(x, wp, y, NB, C, H, W, st);
+    case 16: return launch_gconv3<16, 1>(x, wp, y, NB, C, H, W, st);
     default: return launch_gconv3<32, 1>(x, wp, y, NB, C, H, W, st);
   }
+}
+
+}  // namespace
+
+extern "C" int wfae_gconv3x3_fwd(const float* x, const float* w, float* y, int NB, int C, int H, int W, int groups,
+                                 int transposed, void* ws, size_t ws_bytes, wfae_stream_t stream) {
+  return gconv3x3_fwd_impl(x, w, y, NB, C, H, W, groups, transposed, ws, ws_bytes, stream);
+}
+extern "C" int wfae_gconv3x3_fwd_bf16(const uint16_t* x, const float* w, uint16_t* y, int NB, int C, int H, int W, int groups,
+                                      int transposed, void* ws, size_t ws_bytes, wfae_stream_t stream) {
+  return gconv3x3_fwd_impl(x, w, y, NB, C, H, W, groups, transposed, ws, ws_bytes, stream);
 }
 
 // =====================================================================================
@@ -935,8 +978,8 @@ __global__ __launch_bounds__(256, (OCW * CPG * 9 <= 72 ? 4 : 2)) void gconv3_wgr
 // RCPG < CPG: CPG / RCPG real groups of RCPG channels share one MFMA tile; the tile then also holds the products
 // between different groups, which are simply not written (8 ch/group: half of the tile is used and the kernel
 // still runs 2x faster than the VALU form; 4 ch/group: a quarter, +20 %)
-template <int CPG, int RCPG = CPG>
-__global__ __launch_bounds__(192) void gconv3_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int CPG, int RCPG = CPG, typename T = float>
+__global__ __launch_bounds__(192) void gconv3_wgrad_mfma_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                 float* __restrict__ part, int NB, int C, int H, int W,
                                                                 int tiles_x, int tiles_y, int parts) {
   static_assert(CPG == 32 || CPG == 16, "one MFMA tile of (oc, ci)");
@@ -979,19 +1022,19 @@ __global__ __launch_bounds__(192) void gconv3_wgrad_mfma_kernel(const float* __r
     const long gbase = ((long)n * C + (long)g * CPG) * HW;
     const int iy = oy0 - 1 + xry, ix = ox0 - 1 + xrx;
     const bool xok = xthr && iy >= 0 && iy < H && ix >= 0 && ix < W;
-    const float* __restrict__ xp = x + gbase + (xok ? (long)iy * W + ix : 0);
+    const T* __restrict__ xp = x + gbase + (xok ? (long)iy * W + ix : 0);
 #pragma unroll
     for (int j = 0; j < XSLOT; ++j) {
-      const float v = xp[(long)j * HW];
+      const float v = ld1(xp + (long)j * HW);
       rxv[j] = xok ? v : 0.f;
     }
     const int oy = oy0 + dr, ox = ox0 + dq * 4;
     const bool dok = oy < H && ox < W;   // W % 4 == 0: a float4 is inside or outside as a whole
-    const float* __restrict__ dp = dy + gbase + (dok ? (long)oy * W + ox : 0);
+    const T* __restrict__ dp = dy + gbase + (dok ? (long)oy * W + ox : 0);
 #pragma unroll
     for (int j = 0; j < DSLOT; ++j) {
       const int oc = doc0 + 6 * j;
-      const float4 v = *reinterpret_cast<const float4*>(dp + (long)(oc < CPG ? oc : 0) * HW);
+      const float4 v = ld4(dp + (long)(oc < CPG ? oc : 0) * HW);
       rdv[j] = dok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
@@ -1053,8 +1096,8 @@ __global__ __launch_bounds__(192) void gconv3_wgrad_mfma_kernel(const float* __r
 // single-channel patch with a row stride that keeps the taps of a pixel on different banks; tile i + 1 is prefetched into registers while
 // tile i is multiplied.  (Generic dconv_wgrad_kernel: 1.49 ms on the first layer; c1conv3_wgrad: 1.45 ms.)
 // -------------------------------------------------------------------------------------
-template <int KS, int S, bool FLIP>
-__global__ __launch_bounds__(256) void c1_wgrad_mfma_kernel(const float* __restrict__ big, const float* __restrict__ small,
+template <int KS, int S, bool FLIP, typename BT = float>
+__global__ __launch_bounds__(256) void c1_wgrad_mfma_kernel(const BT* __restrict__ big, const float* __restrict__ small,
                                                             float* __restrict__ part, int NB, int C, int Hs, int Ws,
                                                             int Hb, int Wb, int pad, int tiles_x, int tiles_y, int parts) {
   // 4 x 32 pixel tiles: a tile row of one channel is one whole 128-byte line of `big` (16-pixel-wide tiles read half
@@ -1086,10 +1129,10 @@ __global__ __launch_bounds__(256) void c1_wgrad_mfma_kernel(const float* __restr
     const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
     const int oy = oy0 + dr, ox = ox0 + dq * 4;
     const bool dok = oy < Hb && ox < Wb;            // Wb % 4 == 0
-    const float* __restrict__ dp = big + ((long)n * C + c0 + dcl) * HWb + (dok ? (long)oy * Wb + ox : 0);
+    const BT* __restrict__ dp = big + ((long)n * C + c0 + dcl) * HWb + (dok ? (long)oy * Wb + ox : 0);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float4 v = *reinterpret_cast<const float4*>(dp + (long)(8 * j) * HWb);
+      const float4 v = ld4(dp + (long)(8 * j) * HWb);
       rd[j] = dok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float* __restrict__ xp = small + (long)n * Hs * Ws;
@@ -1142,12 +1185,12 @@ __global__ __launch_bounds__(256) void c1_wgrad_mfma_kernel(const float* __restr
 namespace wfae {
 // Conv2d(1, C, 4, 2, 1) (flip = 0: big = dy (N,C,H/2,W/2), small = x (N,1,H,W)) or Conv2d(C, 1, 3, 1, 1) (flip = 1:
 // big = x (N,C,H,W), small = dy (N,1,H,W)) weight gradient on c1_wgrad_mfma_kernel; WFAE_ERR_UNSUPPORTED for shapes
-// it does not take (odd sizes, C % 64, unaligned `big`, workspace)
-int c1_wgrad_mfma(int flip, const float* big, const float* small, float* dw, int NB, int C, int H, int W,
-                  int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
-  static const int on = getenv("WFAE_C1_WGRAD_MFMA") ? atoi(getenv("WFAE_C1_WGRAD_MFMA")) : 1;
+// it does not take (odd sizes, C % 64, unaligned `big`, workspace).  `big` is fp32 or bf16, `small` always fp32.
+template <typename BT>
+static int c1_wgrad_mfma_t(int flip, const BT* big, const float* small, float* dw, int NB, int C, int H, int W,
+                           int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
   const int Hb = flip ? H : H / 2, Wb = flip ? W : W / 2;
-  if (!on || (!flip && ((H & 1) || (W & 1))) || C % 64 != 0 || Wb % 4 != 0 ||
+  if ((!flip && ((H & 1) || (W & 1))) || C % 64 != 0 || Wb % 4 != 0 ||
       (reinterpret_cast<uintptr_t>(big) & 15) != 0 || C / 64 > 65535)
     return WFAE_ERR_UNSUPPORTED;
   const int tiles_x = cdiv(Wb, 32), tiles_y = cdiv(Hb, 4);
@@ -1159,24 +1202,31 @@ int c1_wgrad_mfma(int flip, const float* big, const float* small, float* dw, int
   if (!ws || (size_t)parts * out_elems * sizeof(float) > ws_bytes) return WFAE_ERR_UNSUPPORTED;
   dim3 grid((unsigned)parts, gy);
   if (flip)
-    hipLaunchKernelGGL((c1_wgrad_mfma_kernel<3, 1, true>), grid, dim3(256), 0, st, big, small, (float*)ws, NB, C, H, W, Hb,
+    hipLaunchKernelGGL((c1_wgrad_mfma_kernel<3, 1, true, BT>), grid, dim3(256), 0, st, big, small, (float*)ws, NB, C, H, W, Hb,
                        Wb, 1, tiles_x, tiles_y, (int)parts);
   else
-    hipLaunchKernelGGL((c1_wgrad_mfma_kernel<4, 2, false>), grid, dim3(256), 0, st, big, small, (float*)ws, NB, C, H, W, Hb,
+    hipLaunchKernelGGL((c1_wgrad_mfma_kernel<4, 2, false, BT>), grid, dim3(256), 0, st, big, small, (float*)ws, NB, C, H, W, Hb,
                        Wb, 1, tiles_x, tiles_y, (int)parts);
   int rc = check_launch("c1_wgrad_mfma");
   if (rc) return rc;
   return slab_reduce((const float*)ws, dw, nullptr, (long)out_elems, 1, (int)parts, accumulate, st);
 }
+int c1_wgrad_mfma(int flip, const float* big, const float* small, float* dw, int NB, int C, int H, int W, int accumulate,
+                  void* ws, size_t ws_bytes, hipStream_t st) {
+  return c1_wgrad_mfma_t(flip, big, small, dw, NB, C, H, W, accumulate, ws, ws_bytes, st);
+}
+int c1_wgrad_mfma(int flip, const bf16_t* big, const float* small, float* dw, int NB, int C, int H, int W, int accumulate,
+                  void* ws, size_t ws_bytes, hipStream_t st) {
+  return c1_wgrad_mfma_t(flip, big, small, dw, NB, C, H, W, accumulate, ws, ws_bytes, st);
+}
 
 // weight gradient of the grouped 3x3 conv for 4 / 8 / 16 / 32 channels per group on the MFMA kernel above;
-// returns WFAE_ERR_UNSUPPORTED otherwise (WFAE_G3_WGRAD_MFMA=0: always)
-int gconv3_wgrad_mfma(const float* dy, const float* x, float* dw, int NB, int C, int H, int W, int groups,
-                      int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+// returns WFAE_ERR_UNSUPPORTED otherwise
+template <typename T>
+static int gconv3_wgrad_mfma_t(const T* dy, const T* x, float* dw, int NB, int C, int H, int W, int groups,
+                               int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
   const int cpg = C / groups;
-  static const int on = getenv("WFAE_G3_WGRAD_MFMA") ? atoi(getenv("WFAE_G3_WGRAD_MFMA")) : 1;
-  if (!on || !(cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32) || W % 4 != 0 ||
-      (reinterpret_cast<uintptr_t>(dy) & 15) != 0)
+  if (!(cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32) || W % 4 != 0 || (reinterpret_cast<uintptr_t>(dy) & 15) != 0)
     return WFAE_ERR_UNSUPPORTED;
   const int vcpg = cpg == 32 ? 32 : 16;        // channels per MFMA tile ("virtual group")
   if (C % vcpg != 0 || C / vcpg > 65535) return WFAE_ERR_UNSUPPORTED;
@@ -1191,8 +1241,8 @@ int gconv3_wgrad_mfma(const float* dy, const float* x, float* dw, int NB, int C,
     return fail(WFAE_ERR_WORKSPACE, "gconv3x3_bwd_weight: workspace %zu too small", ws_bytes);
   dim3 grid((unsigned)parts, vgroups), block(192);
   float* part = (float*)ws;
-#define WFAE_G3W(V_, R_)                                                                                      \
-  hipLaunchKernelGGL((gconv3_wgrad_mfma_kernel<V_, R_>), grid, block, 0, st, dy, x, part, NB, C, H, W, tiles_x, \
+#define WFAE_G3W(V_, R_)                                                                                         \
+  hipLaunchKernelGGL((gconv3_wgrad_mfma_kernel<V_, R_, T>), grid, block, 0, st, dy, x, part, NB, C, H, W, tiles_x, \
                      tiles_y, (int)parts)
   if (cpg == 32) WFAE_G3W(32, 32);
   else if (cpg == 16) WFAE_G3W(16, 16);
@@ -1203,17 +1253,21 @@ int gconv3_wgrad_mfma(const float* dy, const float* x, float* dw, int NB, int C,
   if (rc) return rc;
   return slab_reduce(part, dw, nullptr, (long)out_elems, 1, (int)parts, accumulate, st);
 }
+int gconv3_wgrad_mfma(const float* dy, const float* x, float* dw, int NB, int C, int H, int W, int groups, int accumulate,
+                      void* ws, size_t ws_bytes, hipStream_t st) {
+  return gconv3_wgrad_mfma_t(dy, x, dw, NB, C, H, W, groups, accumulate, ws, ws_bytes, st);
+}
+int gconv3_wgrad_mfma(const bf16_t* dy, const bf16_t* x, float* dw, int NB, int C, int H, int W, int groups, int accumulate,
+                      void* ws, size_t ws_bytes, hipStream_t st) {
+  return gconv3_wgrad_mfma_t(dy, x, dw, NB, C, H, W, groups, accumulate, ws, ws_bytes, st);
+}
 
 // weight gradient of the grouped 3x3 conv for cpg in {4, 8, 16}; returns WFAE_ERR_UNSUPPORTED otherwise
 int gconv3_wgrad_valu(const float* dy, const float* x, float* dw, int NB, int C, int H, int W, int groups,
                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
   const int cpg = C / groups;
   if (!(cpg == 4 || cpg == 8 || cpg == 16)) return WFAE_ERR_UNSUPPORTED;
-  {
-    static const char* e = getenv("WFAE_G3_MFMA_MIN_CPG");   // A/B: channels per group from which the MFMA path is used
-    const int mfma_from = e ? atoi(e) : 16;   // measured: 16 ch/group 0.55 ms on the MFMA path vs 1.3 ms here
-    if (cpg >= mfma_from) return WFAE_ERR_UNSUPPORTED;
-  }
+  if (cpg >= 16) return WFAE_ERR_UNSUPPORTED;   // measured: 16 ch/group 0.55 ms on the MFMA path vs 1.3 ms here
   // output channels per wave: 4 ch/group runs 1.4x faster with 72 accumulators per lane (twice the occupancy),
   // 8 ch/group is faster with 144 (it would re-read x twice as often otherwise)
   int ocw = 144 / (cpg * 9);

@@ -49,11 +49,13 @@ enum BKind { B_NCONTIG = 0, B_KCONTIG = 1, B_DOWN = 2, B_UP = 3, B_WGRAD = 4, B_
 enum EKind { E_BATCHED = 0, E_SLAB = 1, E_UP = 2 };
 
 struct GemmP {
-  const float* A;
-  const float* B;
-  float* C;
+  // A / B / C / res are typed by the kernel's element-type parameters AT / BT / CT (float, or bf16_t for activation tensors
+  // in the bf16-storage mode): offsets and strides below are always in ELEMENTS
+  const void* A;
+  const void* B;
+  void* C;
   const float* bias;  // [M] or null
-  const float* res;   // residual, E_BATCHED only
+  const void* res;    // residual (element type CT), E_BATCHED only
   int M, N, K;
   int k_per_split;  // multiple of BK; == K rounded up when not split
   // A(m,k): KCONTIG  A[(k / a_hw) * a_img + m * a_ld + k % a_hw]
@@ -75,15 +77,7 @@ struct GemmP {
   // batch over blockIdx.y (plain operand kinds): element offsets added per y (Winograd: y = transform position)
   long a_y, b_y, c_y;
   int big_ok;        // 256-row tiles allowed for this launch (long-K plain GEMMs)
-  int swizzle;       // XCD-aware tile order (set by launch_gemm_v from WFAE_SWIZZLE, default off)
-  int nt_store;      // nontemporal stores of the result tile (WFAE_GEMM_NT)
   int a_vec, b_vec, c_vec;  // 16-byte vector accesses are legal for this operand / the result
-  // issue-priority policy for the waves that share a SIMD (WFAE_GEMM_PRIO): two co-resident waves running this
-  // same loop at equal priority drift into lockstep — both multiply, then both sit in their load/store/barrier gap
-  // and the matrix pipe idles (MI355X_MICROARCH.md "Two waves per SIMD", items 2-4).  1: static s_setprio 1 for the
-  // waves in odd hardware wave slots, so one wave of a pair always wins the pipe and the other fills its gaps;
-  // 2: s_setprio 1 only around the multiply phase; 0: none
-  int prio;
   // BatchNorm statistics of the result, fused into the E_BATCHED vector epilogue (kernels with two wave columns):
   // (fp64: the 16-lane DPP reduction runs on doubles, so the partial sums are exact to fp64 rounding like the separate
   // statistics pass) stat_sum / stat_sq [2 * ntiles][M] receive, per output row m (= channel) and 64-column wave tile, the sum and the
@@ -172,9 +166,17 @@ __device__ __forceinline__ double dpp_row_sum(double v) {
 // PREC: WFAE_PRECISION_FP32 — v_mfma_f32_32x32x2_f32; WFAE_PRECISION_BF16 — same loaders, LDS images and epilogue,
 // but the operand fragments are rounded to bf16 (v_cvt_pk_bf16_f32, RNE) after the LDS read and one
 // v_mfma_f32_32x32x16_bf16 consumes a whole 16-deep stage (fp32 accumulation).
-template <int BM, int WMW, int WNW, int AK, int BKD, int EK, bool VEC, int MF, int PREC = 0, int PRO = 0>
+// AT / BT / CT: element types of the A / B operands and of the result (+ residual): float, or bf16_t for ACTIVATION tensors in
+// the bf16-storage mode (plain operand kinds only; four elements per access = 8-byte loads / stores, widened to fp32
+// before the LDS images, which stay fp32; results rounded to nearest even)
+template <int BM, int WMW, int WNW, int AK, int BKD, int EK, bool VEC, int MF, int PREC = 0, int PRO = 0, typename AT = float,
+          typename BT = float, typename CT = float>
 __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP || PREC != 0) ? 3 : 4))) void gemm_kernel(GemmP p) {
   static_assert(WMW * WNW == 4, "4 waves");
+  static_assert((std::is_same<AT, float>::value && std::is_same<BT, float>::value && std::is_same<CT, float>::value) ||
+                    ((BKD == B_NCONTIG || BKD == B_KCONTIG) && EK != E_UP),
+                "bf16 storage: plain operand kinds");
+  static_assert(EK == E_BATCHED || std::is_same<CT, float>::value, "split-K slabs are fp32");
   // PRO 1: prologue on the B operand; PRO 2: on a K-contiguous A operand (the weight gradient with swapped roles)
   static_assert(PRO == 0 || (VEC && (BKD == B_NCONTIG || BKD == B_KCONTIG)), "prologue: vector kernels, plain B kinds");
   static_assert(PRO != 2 || AK == A_KCONTIG, "A-side prologue: K-contiguous A");
@@ -197,26 +199,15 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
-  if (p.prio == 1) {
-    // HW_REG_HW_ID (4), bits [3:0] = wave slot within the SIMD
-    if (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1) __builtin_amdgcn_s_setprio(1);
-  } else if (p.prio == 3) {
-    if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(1);
-  }
   const int mtiles = (p.M + BM - 1) / BM;
-  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2), so
-  // give every XCD a CONTIGUOUS run of tile indices — the blocks resident on one XCD then work on the same B
-  // columns (all M tiles of an N tile are neighbours) and on neighbouring A rows, and re-read them from that
-  // XCD's L2 instead of HBM.
-  int bid = blockIdx.x;
-  if (p.swizzle && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  const int bid = blockIdx.x;
   const int m0 = (bid % mtiles) * BM;
   const int n0 = (bid / mtiles) * BN;
   const int z = blockIdx.z;
 
   int k_begin = 0, k_end = p.K;
   int py = 0, px = 0;
-  const float* __restrict__ Ap = p.A;
+  const AT* __restrict__ Ap = reinterpret_cast<const AT*>(p.A);
   if constexpr (BKD == B_UP) {
     py = z >> 1;
     px = z & 1;
@@ -225,7 +216,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
     k_begin = z * p.k_per_split;
     k_end = min(p.K, k_begin + p.k_per_split);
   }
-  const float* __restrict__ Bp = p.B;
+  const BT* __restrict__ Bp = reinterpret_cast<const BT*>(p.B);
   if constexpr (BKD == B_WGRAD3) Ap += (long)blockIdx.y * p.cpg * p.a_hw;  // dY channels of this group
   if constexpr (BKD == B_NCONTIG || BKD == B_KCONTIG) {
     Ap += (long)blockIdx.y * p.a_y;
@@ -315,25 +306,23 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
   // applied only when the registers are written to LDS (store_a / store_b), AFTER the MFMAs of the
   // current stage, so the wave never waits for its prefetch before it starts multiplying.
   unsigned a_okbits = 0, b_okbits = 0, g_okbits = 0;
-  auto ld4 = [&](const float* base, long off, bool ok) -> float4 {  // immediate select (scalar fallback paths)
-    float4 v = *reinterpret_cast<const float4*>(base + (ok ? off : 0));
+  auto ld4 = [&](auto base, long off, bool ok) -> float4 {  // immediate select (scalar fallback paths)
+    float4 v = wfae::ld4(base + (ok ? off : 0));
     if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
     return v;
   };
-  auto ld4raw = [&](const float* base, long off, bool ok) -> float4 {
-    return *reinterpret_cast<const float4*>(base + (ok ? off : 0));
-  };
+  auto ld4raw = [&](auto base, long off, bool ok) -> float4 { return wfae::ld4(base + (ok ? off : 0)); };
   auto ld4raw_u = [&](const float* base, long off, bool ok) -> float4 {
     return load4u(base + (ok ? off : 0));
   };
   auto tap_off = [&](int tap) -> int { return (tap >> 2) * p.Wlo + (tap & 3); };
   (void)ld4raw_u;
   (void)tap_off;
-  auto ld1 = [&](const float* base, long off, bool ok) -> float {
-    const float v = base[ok ? off : 0];
+  auto ld1 = [&](auto base, long off, bool ok) -> float {
+    const float v = wfae::ld1(base + (ok ? off : 0));
     return ok ? v : 0.f;
   };
-  auto ld1raw = [&](const float* base, long off, bool ok) -> float { return base[ok ? off : 0]; };
+  auto ld1raw = [&](auto base, long off, bool ok) -> float { return wfae::ld1(base + (ok ? off : 0)); };
   auto sel4 = [&](float4 v, unsigned bits, int i) -> float4 {
     return ((bits >> i) & 1u) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
   };
@@ -490,7 +479,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
   auto load_a_lean = [&]() {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      ra[i] = *reinterpret_cast<const float4*>(Ap + la_off[i]);
+      ra[i] = wfae::ld4(Ap + la_off[i]);
       if constexpr (AK == A_KCONTIG) {
         la_off[i] += BK;
         if (a_batched) {  // wave-uniform: plain weight matrices skip the image-wrap arithmetic
@@ -514,7 +503,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
         if constexpr (BKD == B_TAPN || BKD == B_TAPK)
           rb[i] = load4u(Bp + lb_off[i]);
         else
-          rb[i] = *reinterpret_cast<const float4*>(Bp + lb_off[i]);
+          rb[i] = wfae::ld4(Bp + lb_off[i]);
         if constexpr (PRO == 1 && BKD == B_NCONTIG) {  // full stages: k < K, no clamp needed
           pb_s[i] = p.b_scale[pb_k + i * 8];
           pb_h[i] = p.b_shift[pb_k + i * 8];
@@ -1050,9 +1039,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
     const int buf = s & 1;
     if (s + 1 < nstages) load_stage(s + 1);
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch's consumers below the MFMAs
-    if (p.prio == 2) __builtin_amdgcn_s_setprio(1);
     compute(buf);
-    if (p.prio == 2) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     if (s + 1 < nstages) {
       store_a(buf ^ 1);
@@ -1077,12 +1064,12 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
     const int c4 = lane % F4R, rsub = lane / F4R;
     const int n = n0 + wn0 + c4 * 4;
     const bool nok = n < p.N;
-    float* cb = p.C;
-    const float* rbp = nullptr;
+    CT* cb = reinterpret_cast<CT*>(p.C);
+    const CT* rbp = nullptr;
     const float* xbp = nullptr;
     (void)xbp;
-    // BatchNorm-backward epilogues (GemmP::bn_mode): 1x1 data-gradient launches only
-    constexpr bool BNE = EK == E_BATCHED && BKD == B_NCONTIG && PRO == 0 && WNW == 2;
+    // BatchNorm-backward epilogues (GemmP::bn_mode): 1x1 data-gradient launches only (fp32 storage)
+    constexpr bool BNE = EK == E_BATCHED && BKD == B_NCONTIG && PRO == 0 && WNW == 2 && std::is_same<CT, float>::value;
     long mstride;
     if constexpr (EK == E_BATCHED) {
       cb += (long)blockIdx.y * p.c_y;
@@ -1090,7 +1077,7 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
       const int img = nn / p.c_hw;
       const int pn = nn - img * p.c_hw;
       cb += (long)img * p.c_img + pn;
-      if (p.res) rbp = p.res + (long)img * p.res_img + pn;
+      if (p.res) rbp = reinterpret_cast<const CT*>(p.res) + (long)img * p.res_img + pn;
       if constexpr (BNE) {
         if (p.bn_mode) xbp = p.bn_x + (long)img * p.c_img + pn;
       }
@@ -1155,28 +1142,26 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
           }
         }
         if (nok && m < p.M) {
-          float* dst = cb + (long)m * mstride;
+          CT* dst = cb + (long)m * mstride;
           if constexpr (EK == E_BATCHED) {
             if (p.bias) {
               const float bv = p.bias[m];
               v.x += bv; v.y += bv; v.z += bv; v.w += bv;
             }
             if (rbp) {
-              const float4 rv = *reinterpret_cast<const float4*>(rbp + (long)m * mstride);
+              const float4 rv = wfae::ld4(rbp + (long)m * mstride);
               v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             }
             if (p.beta) {
-              const float4 ov = *reinterpret_cast<const float4*>(dst);
+              const float4 ov = wfae::ld4(dst);
               v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
             }
           }
-          if (p.nt_store) {
-            typedef float vf4 __attribute__((ext_vector_type(4)));
-            const vf4 o = {v.x, v.y, v.z, v.w};
-            __builtin_nontemporal_store(o, reinterpret_cast<vf4*>(dst));
-          } else {
-            *reinterpret_cast<float4*>(dst) = v;
+          if constexpr (sizeof(CT) == 2) {   // the BatchNorm sums below are those of the values a reader of C will see
+            const unsigned q0 = pack_bf16(v.x, v.y), q1 = pack_bf16(v.z, v.w);
+            v = make_float4(bf16_lo(q0), bf16_hi(q0), bf16_lo(q1), bf16_hi(q1));
           }
+          wfae::st4(dst, v);
         }
         if constexpr (EK == E_BATCHED && WNW == 2) {
           if (p.stat_sum) {  // wave-uniform: every lane takes part in the shuffles
@@ -1203,23 +1188,23 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn0 + l31 * TN + j;
       if (n >= p.N) continue;
-      float* cb;
-      const float* rbp = nullptr;
+      CT* cb;
+      const CT* rbp = nullptr;
       long mstride;
       if constexpr (EK == E_BATCHED) {
         const int img = n / p.c_hw;
         const int pn = n - img * p.c_hw;
-        cb = p.C + (long)blockIdx.y * p.c_y + (long)img * p.c_img + pn;
-        if (p.res) rbp = p.res + (long)img * p.res_img + pn;
+        cb = reinterpret_cast<CT*>(p.C) + (long)blockIdx.y * p.c_y + (long)img * p.c_img + pn;
+        if (p.res) rbp = reinterpret_cast<const CT*>(p.res) + (long)img * p.res_img + pn;
         mstride = p.c_ld;
       } else if constexpr (EK == E_SLAB) {
-        cb = p.C + ((long)z * gridDim.y + blockIdx.y) * p.M * p.N + n;
+        cb = reinterpret_cast<CT*>(p.C) + ((long)z * gridDim.y + blockIdx.y) * p.M * p.N + n;
         mstride = p.N;
       } else {  // E_UP
         const int img = n / HWlo;
         const int r = n - img * HWlo;
         const int a = r / p.Wlo, b = r - a * p.Wlo;
-        cb = p.C + (long)img * p.Chi * H * W + (long)(2 * a + py) * W + (2 * b + px);
+        cb = reinterpret_cast<CT*>(p.C) + (long)img * p.Chi * H * W + (long)(2 * a + py) * W + (2 * b + px);
         mstride = (long)H * W;
       }
 #pragma unroll
@@ -1231,10 +1216,10 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
             float v = acc[i][j][r];
             if constexpr (EK == E_BATCHED) {
               if (p.bias) v += p.bias[m];
-              if (rbp) v += rbp[(long)m * mstride];
-              if (p.beta) v += cb[(long)m * mstride];
+              if (rbp) v += wfae::ld1(rbp + (long)m * mstride);
+              if (p.beta) v += wfae::ld1(cb + (long)m * mstride);
             }
-            cb[(long)m * mstride] = v;
+            wfae::st1(cb + (long)m * mstride, v);
           }
         }
     }
@@ -1377,33 +1362,21 @@ inline int env_int(const char* name, int dflt) {
 // (PMC: SQ_VALU_MFMA_BUSY_CYCLES vs SQ_INSTS_VALU).  WFAE_BM256=0 disables it (A/B testing).
 // tile height: the tallest of 128 / 64 / 32 rows that M fills, stepped down while the grid would leave most of the
 // chip's 1024 resident-block slots empty (small batches, the 24x24 stage: 288 blocks of 128 rows ran 0.157 ms,
-// 576 of 64 rows 0.132 ms).  Large grids are unaffected.  WFAE_BM_FORCE=64 caps the height (A/B).
+// 576 of 64 rows 0.132 ms).  Large grids are unaffected.
 inline int pick_bm(int M, long col_blocks) {
-  static const int bm_force = env_int("WFAE_BM_FORCE", 0);
   int bm = M > 64 ? 128 : (M > 32 ? 64 : 32);
-  if (bm_force == 64 && bm > 64) bm = 64;
   while (bm > 32 && (long)cdiv(M, bm) * col_blocks < 512) bm >>= 1;
   return bm;
 }
 
-template <int AK, int BKD, int EK, bool VEC, int PRO = 0>
+template <int AK, int BKD, int EK, bool VEC, int PRO = 0, typename AT = float, typename BT = float, typename CT = float>
 int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what, int ydim = 1) {
   static const int use256 = env_int("WFAE_BM256", 1);
-  static const int swz = env_int("WFAE_SWIZZLE", 0);  // measured: no change (the GEMMs are not L2-miss bound), kept for A/B
-  // nontemporal result stores: 0 never (default), 1 always, 2 only for launches that also stream a residual.
-  // Measured neutral for every GEMM of the step (unlike the BatchNorm dx kernel): kept for A/B only
-  static const int nts = env_int("WFAE_GEMM_NT", 0);
-  static const int prio = env_int("WFAE_GEMM_PRIO", 0);
-  // A/B: extra (unused) dynamic LDS per block caps the blocks per CU, leaving registers / wave slots for the
-  // HBM-bound kernels of the other stream to run beside the GEMM (tools/overlap_probe.py)
-  static const int dyn_lds = env_int("WFAE_GEMM_DYNLDS", 0);
   GemmP p = p_in;
-  p.prio = prio;
-  p.swizzle = swz;
-  p.nt_store = nts == 1 || (nts == 2 && p_in.res != nullptr);
   const int ntiles = cdiv(p.N, BN);
   dim3 block(NT);
   bool big = false;
+  constexpr bool all_f32 = std::is_same<AT, float>::value && std::is_same<BT, float>::value && std::is_same<CT, float>::value;
   if constexpr (VEC) {
     if (wfae::matmul_precision() == WFAE_PRECISION_BF16) {
       // bf16 operands: the MFMA time of a stage falls 16x, the kernels turn loader / HBM bound and the
@@ -1411,57 +1384,64 @@ int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what,
       const int bm = pick_bm(p.M, (long)ntiles * ydim * zdim);
       if (bm == 128) {
         dim3 grid(cdiv(p.M, 128) * ntiles, ydim, zdim);
-        hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, true, 32, 1, PRO>), grid, block, dyn_lds, st, p);
+        hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, true, 32, 1, PRO, AT, BT, CT>), grid, block, 0, st, p);
       } else if (bm == 64) {
         dim3 grid(cdiv(p.M, 64) * ntiles, ydim, zdim);
-        hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK, true, 32, 1, PRO>), grid, block, dyn_lds, st, p);
+        hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK, true, 32, 1, PRO, AT, BT, CT>), grid, block, 0, st, p);
       } else {
         dim3 grid(cdiv(p.M, 32) * ntiles, ydim, zdim);
-        hipLaunchKernelGGL((gemm_kernel<32, 1, 4, AK, BKD, EK, true, 32, 1, PRO>), grid, block, dyn_lds, st, p);
+        hipLaunchKernelGGL((gemm_kernel<32, 1, 4, AK, BKD, EK, true, 32, 1, PRO, AT, BT, CT>), grid, block, 0, st, p);
       }
       return check_launch(what);
     }
-    if constexpr (BKD == B_NCONTIG || BKD == B_KCONTIG || BKD == B_TAPN || BKD == B_TAPK) {
-      // fp32 products on the bf16 matrix pipe, operands split in registers (PREC 2): for the MFMA-bound shapes
-      static const int split_min_k = env_int("WFAE_SPLIT_MIN_K", 128);
-      static const int split_min_m = env_int("WFAE_SPLIT_MIN_M", 64);
-      if (wfae::split_gemm_enabled() && p.K >= split_min_k && p.M >= split_min_m) {
-        int bm = pick_bm(p.M, (long)ntiles * ydim * zdim);
-        if (p.bn_mode && bm == 32) bm = 64;
-        if (bm == 128) {
-          dim3 grid(cdiv(p.M, 128) * ntiles, ydim, zdim);
-          hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, true, 32, 2, PRO>), grid, block, dyn_lds, st, p);
-          return check_launch(what);
-        } else if (bm == 64) {
-          dim3 grid(cdiv(p.M, 64) * ntiles, ydim, zdim);
-          hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK, true, 32, 2, PRO>), grid, block, dyn_lds, st, p);
-          return check_launch(what);
+  }
+  if constexpr (!all_f32) {
+    // bf16-stored activations exist only in the bf16 arithmetic mode (and on the vector kernels)
+    return fail(WFAE_ERR_UNSUPPORTED, "%s: bf16 activation storage needs wfae_set_matmul_precision(WFAE_PRECISION_BF16) and "
+                "vector-aligned operands", what);
+  } else {
+    if constexpr (VEC) {
+      if constexpr (BKD == B_NCONTIG || BKD == B_KCONTIG || BKD == B_TAPN || BKD == B_TAPK) {
+        // fp32 products on the bf16 matrix pipe, operands split in registers (PREC 2): for the MFMA-bound shapes
+        static const int split_min_k = env_int("WFAE_SPLIT_MIN_K", 128);
+        static const int split_min_m = env_int("WFAE_SPLIT_MIN_M", 64);
+        if (wfae::split_gemm_enabled() && p.K >= split_min_k && p.M >= split_min_m) {
+          int bm = pick_bm(p.M, (long)ntiles * ydim * zdim);
+          if (p.bn_mode && bm == 32) bm = 64;
+          if (bm == 128) {
+            dim3 grid(cdiv(p.M, 128) * ntiles, ydim, zdim);
+            hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, true, 32, 2, PRO>), grid, block, 0, st, p);
+            return check_launch(what);
+          } else if (bm == 64) {
+            dim3 grid(cdiv(p.M, 64) * ntiles, ydim, zdim);
+            hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK, true, 32, 2, PRO>), grid, block, 0, st, p);
+            return check_launch(what);
+          }
         }
       }
+      // measured (tools/kbench.py): pays for the gather GEMMs once the grid fills the 512 resident slots twice
+      constexpr bool gather = BKD == B_DOWN || BKD == B_UP || BKD == B_WGRAD;
+      if ((gather || p.big_ok) && use256 && p.M >= 256 && (long)cdiv(p.M, 256) * ntiles * zdim * ydim >= 1024) {
+        big = true;
+        dim3 grid(cdiv(p.M, 256) * ntiles, ydim, zdim);
+        hipLaunchKernelGGL((gemm_kernel<256, 2, 2, AK, BKD, EK, true, 32, 0, PRO>), grid, block, 0, st, p);
+      }
     }
-    // measured (tools/kbench.py): pays for the gather GEMMs once the grid fills the 512 resident slots twice
-    constexpr bool gather = BKD == B_DOWN || BKD == B_UP || BKD == B_WGRAD;
-    static const int bm_force256 = env_int("WFAE_BM_FORCE", 0) == 256;
-    if ((gather || p.big_ok || bm_force256) && use256 && p.M >= 256 && (long)cdiv(p.M, 256) * ntiles * zdim * ydim >= 1024) {
-      big = true;
-      dim3 grid(cdiv(p.M, 256) * ntiles, ydim, zdim);
-      hipLaunchKernelGGL((gemm_kernel<256, 2, 2, AK, BKD, EK, true, 32, 0, PRO>), grid, block, dyn_lds, st, p);
+    int bm = big ? 256 : pick_bm(p.M, (long)ntiles * ydim * zdim);
+    if (p.bn_mode && bm == 32) bm = 64;   // the BatchNorm-backward epilogues live in the two-wave-column kernels
+    if (big) {
+    } else if (bm == 128) {
+      dim3 grid(cdiv(p.M, 128) * ntiles, ydim, zdim);
+      hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, VEC, 32, 0, PRO>), grid, block, 0, st, p);
+    } else if (bm == 64) {
+      dim3 grid(cdiv(p.M, 64) * ntiles, ydim, zdim);
+      hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK, VEC, 32, 0, PRO>), grid, block, 0, st, p);
+    } else {
+      dim3 grid(cdiv(p.M, 32) * ntiles, ydim, zdim);
+      hipLaunchKernelGGL((gemm_kernel<32, 1, 4, AK, BKD, EK, VEC, 32, 0, PRO>), grid, block, 0, st, p);
     }
+    return check_launch(what);
   }
-  int bm = big ? 256 : pick_bm(p.M, (long)ntiles * ydim * zdim);
-  if (p.bn_mode && bm == 32) bm = 64;   // the BatchNorm-backward epilogues live in the two-wave-column kernels
-  if (big) {
-  } else if (bm == 128) {
-    dim3 grid(cdiv(p.M, 128) * ntiles, ydim, zdim);
-    hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, VEC, 32, 0, PRO>), grid, block, dyn_lds, st, p);
-  } else if (bm == 64) {
-    dim3 grid(cdiv(p.M, 64) * ntiles, ydim, zdim);
-    hipLaunchKernelGGL((gemm_kernel<64, 2, 2, AK, BKD, EK, VEC, 32, 0, PRO>), grid, block, dyn_lds, st, p);
-  } else {
-    dim3 grid(cdiv(p.M, 32) * ntiles, ydim, zdim);
-    hipLaunchKernelGGL((gemm_kernel<32, 1, 4, AK, BKD, EK, VEC, 32, 0, PRO>), grid, block, dyn_lds, st, p);
-  }
-  return check_launch(what);
 }
 
 // p.a_vec / p.b_vec / p.c_vec say whether 16-byte accesses are legal for that operand; the
@@ -1519,8 +1499,10 @@ int splitk_finish(const float* slab, float* out, const float* bias_n, long MN, i
 
 extern "C" {
 
-static int conv1x1_fwd_impl(const float* x, const float* bn_scale, const float* bn_shift, const float* w, const float* bias,
-                            const float* res, int64_t res_img_stride, float* y, int NB, int Cin, int Cout, int HW,
+extern "C++" {
+template <typename T>
+static int conv1x1_fwd_impl(const T* x, const float* bn_scale, const float* bn_shift, const float* w, const float* bias,
+                            const T* res, int64_t res_img_stride, T* y, int NB, int Cin, int Cout, int HW,
                             double* stat_part, int64_t stat_capacity, int* stat_rows, wfae_stream_t stream) {
   WFAE_REQUIRE(x && w && y, WFAE_ERR_NULL_POINTER, "conv1x1_fwd: null pointer");
   WFAE_REQUIRE(NB > 0 && Cin > 0 && Cout > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "conv1x1_fwd: bad shape");
@@ -1554,14 +1536,31 @@ static int conv1x1_fwd_impl(const float* x, const float* bn_scale, const float* 
       p.stat_sq = stat_part + rows * Cout;
     }
   }
-  if (bn_scale) return launch_gemm_v<A_KCONTIG, B_NCONTIG, E_BATCHED, true, 1>(p, 1, (hipStream_t)stream, "conv1x1_fwd_bnact");
-  return launch_gemm<A_KCONTIG, B_NCONTIG, E_BATCHED>(p, 1, (hipStream_t)stream, "conv1x1_fwd");
+  if constexpr (!std::is_same<T, float>::value) {
+    WFAE_REQUIRE(vec, WFAE_ERR_UNSUPPORTED, "conv1x1_fwd (bf16 storage): needs Cin %% 4 == 0, HW %% 4 == 0, aligned tensors");
+    if (bn_scale)
+      return launch_gemm_v<A_KCONTIG, B_NCONTIG, E_BATCHED, true, 1, float, T, T>(p, 1, (hipStream_t)stream, "conv1x1_fwd_bnact");
+    return launch_gemm_v<A_KCONTIG, B_NCONTIG, E_BATCHED, true, 0, float, T, T>(p, 1, (hipStream_t)stream, "conv1x1_fwd");
+  } else {
+    if (bn_scale) return launch_gemm_v<A_KCONTIG, B_NCONTIG, E_BATCHED, true, 1>(p, 1, (hipStream_t)stream, "conv1x1_fwd_bnact");
+    return launch_gemm<A_KCONTIG, B_NCONTIG, E_BATCHED>(p, 1, (hipStream_t)stream, "conv1x1_fwd");
+  }
 }
+}  // extern "C++"
 
 int wfae_conv1x1_fwd(const float* x, const float* w, const float* bias, const float* res,
                      int64_t res_img_stride, float* y, int NB, int Cin, int Cout, int HW,
                      wfae_stream_t stream) {
   return conv1x1_fwd_impl(x, nullptr, nullptr, w, bias, res, res_img_stride, y, NB, Cin, Cout, HW, nullptr, 0, nullptr, stream);
+}
+/* bf16 storage: stat_part / stat_rows may be null (no sums); bn_scale / bn_shift may be null (no prologue) */
+int wfae_conv1x1_fwd_bf16(const uint16_t* x, const float* bn_scale, const float* bn_shift, const float* w, const float* bias,
+                          const uint16_t* res, int64_t res_img_stride, uint16_t* y, int NB, int Cin, int Cout, int HW,
+                          double* stat_part, int64_t stat_capacity, int* stat_rows, wfae_stream_t stream) {
+  WFAE_REQUIRE((bn_scale != nullptr) == (bn_shift != nullptr) && (stat_part != nullptr) == (stat_rows != nullptr),
+               WFAE_ERR_NULL_POINTER, "conv1x1_fwd_bf16: scale / shift and stat_part / stat_rows go together");
+  return conv1x1_fwd_impl(x, bn_scale, bn_shift, w, bias, res, res_img_stride, y, NB, Cin, Cout, HW, stat_part, stat_capacity,
+                          stat_rows, stream);
 }
 
 int wfae_conv1x1_fwd_stats(const float* x, const float* w, const float* bias, const float* res,
@@ -1583,19 +1582,22 @@ int wfae_conv1x1_fwd_bnact(const float* x, const float* bn_scale, const float* b
                           stat_rows, stream);
 }
 
-int wfae_conv1x1_bwd_weight_bnact(const float* dy, const float* x, const float* bn_scale, const float* bn_shift,
-                                  float* dw, int NB, int Cin, int Cout, int HW, int accumulate, void* ws,
-                                  size_t ws_bytes, wfae_stream_t stream) {
-  WFAE_REQUIRE(dy && x && bn_scale && bn_shift && dw, WFAE_ERR_NULL_POINTER, "conv1x1_bwd_weight_bnact: null pointer");
-  WFAE_REQUIRE(NB > 0 && Cin > 0 && Cout > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "conv1x1_bwd_weight_bnact: bad shape");
-  WFAE_REQUIRE((int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "conv1x1_bwd_weight_bnact: NB*HW too large");
+// dW (M = Cout, N = Cin) = dY * A^T, A = x or (bn_scale given) gelu(bn(x)) rebuilt in the loader of whichever operand x is: B
+// normally, A when the roles are swapped (Cin is the small side: dW^T = A dY^T, no MFMA work spent on padding the 128-wide
+// N tile; the slab reduce writes it back transposed)
+extern "C++" {
+template <typename T>
+static int conv1x1_bwd_weight_impl(const T* dy, const T* x, const float* bn_scale, const float* bn_shift, float* dw, int NB,
+                                   int Cin, int Cout, int HW, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream,
+                                   const char* what) {
+  WFAE_REQUIRE(dy && x && dw, WFAE_ERR_NULL_POINTER, "%s: null pointer", what);
+  WFAE_REQUIRE(NB > 0 && Cin > 0 && Cout > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "%s: bad shape", what);
+  WFAE_REQUIRE((int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "%s: NB*HW too large", what);
   const size_t slab = (size_t)Cout * Cin * sizeof(float);
-  WFAE_REQUIRE(ws && ws_bytes >= slab, WFAE_ERR_WORKSPACE, "conv1x1_bwd_weight_bnact: workspace %zu < %zu", ws_bytes, slab);
-  // dW (M = Cout, N = Cin) = dY * A^T with A = gelu(bn(x)) rebuilt in the loader of whichever operand x is: B normally,
-  // A when the roles are swapped (Cin is the small side: dW^T = A dY^T, as in wfae_conv1x1_bwd_weight)
+  WFAE_REQUIRE(ws && ws_bytes >= slab, WFAE_ERR_WORKSPACE, "%s: workspace %zu < %zu", what, ws_bytes, slab);
   const bool swap = Cin < Cout && Cin < 128;
-  const float* a = swap ? x : dy;
-  const float* b = swap ? dy : x;
+  const T* a = swap ? x : dy;
+  const T* b = swap ? dy : x;
   const int Ma = swap ? Cin : Cout, Nb = swap ? Cout : Cin;
   GemmP p = {};
   p.K = NB * HW;
@@ -1604,19 +1606,51 @@ int wfae_conv1x1_bwd_weight_bnact(const float* dy, const float* x, const float* 
   p.M = Ma; p.N = Nb;
   p.a_hw = HW; p.a_img = (long)Ma * HW; p.a_ld = HW;
   p.b_hw = HW; p.b_img = (long)Nb * HW; p.b_ld = HW;
-  const bool vec = (HW % 4 == 0) && HW >= BK && aligned16(dy) && aligned16(x) && (Nb % 4 == 0) && aligned16(ws);
-  WFAE_REQUIRE(vec, WFAE_ERR_UNSUPPORTED, "conv1x1_bwd_weight_bnact: needs HW %% 4 == 0, HW >= 16, channel counts %% 4 == 0, aligned tensors");
-  p.a_vec = p.b_vec = p.c_vec = 1;
+  p.a_vec = (HW % 4 == 0) && HW >= BK && aligned16(a);   // lean cursors step one image at most per stage
+  p.b_vec = (HW % 4 == 0) && HW >= BK && aligned16(b);
+  p.c_vec = (Nb % 4 == 0) && aligned16(ws);
+  const bool vec = p.a_vec && p.b_vec && p.c_vec;
   const int splits = pick_splits(p.M, p.N, p.K, ws_bytes, &p.k_per_split);
-  int rc = swap ? launch_gemm_v<A_KCONTIG, B_KCONTIG, E_SLAB, true, 2>(p, splits, (hipStream_t)stream, "conv1x1_bwd_weight_bnact")
-                : launch_gemm_v<A_KCONTIG, B_KCONTIG, E_SLAB, true, 1>(p, splits, (hipStream_t)stream, "conv1x1_bwd_weight_bnact");
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if constexpr (!std::is_same<T, float>::value) {
+    WFAE_REQUIRE(vec, WFAE_ERR_UNSUPPORTED, "%s (bf16 storage): needs HW %% 4 == 0, HW >= 16, channel counts %% 4 == 0", what);
+    if (!bn_scale) rc = launch_gemm_v<A_KCONTIG, B_KCONTIG, E_SLAB, true, 0, T, T, float>(p, splits, st, what);
+    else if (swap) rc = launch_gemm_v<A_KCONTIG, B_KCONTIG, E_SLAB, true, 2, T, T, float>(p, splits, st, what);
+    else rc = launch_gemm_v<A_KCONTIG, B_KCONTIG, E_SLAB, true, 1, T, T, float>(p, splits, st, what);
+  } else {
+    if (bn_scale) {
+      WFAE_REQUIRE(vec, WFAE_ERR_UNSUPPORTED, "%s: needs HW %% 4 == 0, HW >= 16, channel counts %% 4 == 0, aligned tensors", what);
+      rc = swap ? launch_gemm_v<A_KCONTIG, B_KCONTIG, E_SLAB, true, 2>(p, splits, st, what)
+                : launch_gemm_v<A_KCONTIG, B_KCONTIG, E_SLAB, true, 1>(p, splits, st, what);
+    } else {
+      rc = launch_gemm<A_KCONTIG, B_KCONTIG, E_SLAB>(p, splits, st, what);
+    }
+  }
   if (rc) return rc;
-  return splitk_finish((float*)ws, dw, nullptr, (long)Cout * Cin, Nb, splits, accumulate, (hipStream_t)stream,
-                       swap ? Ma : 0);
+  return splitk_finish((float*)ws, dw, nullptr, (long)Cout * Cin, Nb, splits, accumulate, st, swap ? Ma : 0);
+}
+}  // extern "C++"
+
+int wfae_conv1x1_bwd_weight_bnact(const float* dy, const float* x, const float* bn_scale, const float* bn_shift,
+                                  float* dw, int NB, int Cin, int Cout, int HW, int accumulate, void* ws,
+                                  size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(bn_scale && bn_shift, WFAE_ERR_NULL_POINTER, "conv1x1_bwd_weight_bnact: null pointer");
+  return conv1x1_bwd_weight_impl(dy, x, bn_scale, bn_shift, dw, NB, Cin, Cout, HW, accumulate, ws, ws_bytes, stream,
+                                 "conv1x1_bwd_weight_bnact");
+}
+/* bf16 storage: dy, x bf16; dw fp32; bn_scale / bn_shift null = plain weight gradient */
+int wfae_conv1x1_bwd_weight_bf16(const uint16_t* dy, const uint16_t* x, const float* bn_scale, const float* bn_shift, float* dw,
+                                 int NB, int Cin, int Cout, int HW, int accumulate, void* ws, size_t ws_bytes,
+                                 wfae_stream_t stream) {
+  WFAE_REQUIRE((bn_scale != nullptr) == (bn_shift != nullptr), WFAE_ERR_NULL_POINTER, "conv1x1_bwd_weight_bf16: scale / shift go together");
+  return conv1x1_bwd_weight_impl(dy, x, bn_scale, bn_shift, dw, NB, Cin, Cout, HW, accumulate, ws, ws_bytes, stream,
+                                 "conv1x1_bwd_weight_bf16");
 }
 
-int wfae_conv1x1_bwd_data(const float* dy, const float* w, float* dx, int NB, int Cin, int Cout,
-                          int HW, wfae_stream_t stream) {
+extern "C++" {
+template <typename T>
+static int conv1x1_bwd_data_impl(const T* dy, const float* w, T* dx, int NB, int Cin, int Cout, int HW, wfae_stream_t stream) {
   WFAE_REQUIRE(dy && w && dx, WFAE_ERR_NULL_POINTER, "conv1x1_bwd_data: null pointer");
   WFAE_REQUIRE(NB > 0 && Cin > 0 && Cout > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "conv1x1_bwd_data: bad shape");
   WFAE_REQUIRE((int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "conv1x1_bwd_data: NB*HW too large");
@@ -1629,7 +1663,22 @@ int wfae_conv1x1_bwd_data(const float* dy, const float* w, float* dx, int NB, in
   p.a_vec = (Cin % 4 == 0) && aligned16(w);
   p.b_vec = (HW % 4 == 0) && aligned16(dy);
   p.c_vec = (HW % 4 == 0) && aligned16(dx);
-  return launch_gemm<A_MCONTIG, B_NCONTIG, E_BATCHED>(p, 1, (hipStream_t)stream, "conv1x1_bwd_data");
+  if constexpr (!std::is_same<T, float>::value) {
+    WFAE_REQUIRE(p.a_vec && p.b_vec && p.c_vec, WFAE_ERR_UNSUPPORTED,
+                 "conv1x1_bwd_data (bf16 storage): needs Cin %% 4 == 0, HW %% 4 == 0, aligned tensors");
+    return launch_gemm_v<A_MCONTIG, B_NCONTIG, E_BATCHED, true, 0, float, T, T>(p, 1, (hipStream_t)stream, "conv1x1_bwd_data");
+  } else {
+    return launch_gemm<A_MCONTIG, B_NCONTIG, E_BATCHED>(p, 1, (hipStream_t)stream, "conv1x1_bwd_data");
+  }
+}
+}  // extern "C++"
+int wfae_conv1x1_bwd_data(const float* dy, const float* w, float* dx, int NB, int Cin, int Cout,
+                          int HW, wfae_stream_t stream) {
+  return conv1x1_bwd_data_impl(dy, w, dx, NB, Cin, Cout, HW, stream);
+}
+int wfae_conv1x1_bwd_data_bf16(const uint16_t* dy, const float* w, uint16_t* dx, int NB, int Cin, int Cout, int HW,
+                               wfae_stream_t stream) {
+  return conv1x1_bwd_data_impl(dy, w, dx, NB, Cin, Cout, HW, stream);
 }
 
 // wfae_conv1x1_bwd_data with the BatchNorm + GELU backward of the layer in front fused into its epilogue (GemmP::bn_mode)
@@ -1686,31 +1735,8 @@ int wfae_conv1x1_bwd_data_bndx(const float* dy, const float* w, const float* x, 
 
 int wfae_conv1x1_bwd_weight(const float* dy, const float* x, float* dw, int NB, int Cin, int Cout,
                             int HW, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream) {
-  WFAE_REQUIRE(dy && x && dw, WFAE_ERR_NULL_POINTER, "conv1x1_bwd_weight: null pointer");
-  WFAE_REQUIRE(NB > 0 && Cin > 0 && Cout > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "conv1x1_bwd_weight: bad shape");
-  WFAE_REQUIRE((int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "conv1x1_bwd_weight: NB*HW too large");
-  const size_t slab = (size_t)Cout * Cin * sizeof(float);
-  WFAE_REQUIRE(ws && ws_bytes >= slab, WFAE_ERR_WORKSPACE, "conv1x1_bwd_weight: workspace %zu < %zu", ws_bytes, slab);
-  GemmP p = {};
-  p.K = NB * HW;
-  // The N tile is 128 wide: when Cin is the small side (< 128 and < Cout) compute dW^T = X dY^T
-  // (M = Cin, N = Cout) so no MFMA work is spent on padding; the slab reduce writes it back transposed.
-  const bool swap = Cin < Cout && Cin < 128;
-  const float* a = swap ? x : dy;
-  const float* b = swap ? dy : x;
-  const int Ma = swap ? Cin : Cout, Nb = swap ? Cout : Cin;
-  p.A = a; p.B = b; p.C = (float*)ws;
-  p.M = Ma; p.N = Nb;
-  p.a_hw = HW; p.a_img = (long)Ma * HW; p.a_ld = HW;
-  p.b_hw = HW; p.b_img = (long)Nb * HW; p.b_ld = HW;
-  p.a_vec = (HW % 4 == 0) && HW >= BK && aligned16(a);   // lean cursors step one image at most per stage
-  p.b_vec = (HW % 4 == 0) && HW >= BK && aligned16(b);
-  p.c_vec = (Nb % 4 == 0) && aligned16(ws);
-  const int splits = pick_splits(p.M, p.N, p.K, ws_bytes, &p.k_per_split);
-  int rc = launch_gemm<A_KCONTIG, B_KCONTIG, E_SLAB>(p, splits, (hipStream_t)stream, "conv1x1_bwd_weight");
-  if (rc) return rc;
-  return splitk_finish((float*)ws, dw, nullptr, (long)Cout * Cin, Nb, splits, accumulate, (hipStream_t)stream,
-                       swap ? Ma : 0);
+  return conv1x1_bwd_weight_impl(dy, x, nullptr, nullptr, dw, NB, Cin, Cout, HW, accumulate, ws, ws_bytes, stream,
+                                 "conv1x1_bwd_weight");
 }
 
 int wfae_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In,
@@ -1873,6 +1899,17 @@ int wfae_conv4x4s2_wgrad(const float* lo, const float* hi, float* dw, int NB, in
   if (rc) return rc;
   return splitk_finish((float*)ws, dw, nullptr, (long)Clo * Chi * 16, Chi * 16, splits, accumulate,
                        (hipStream_t)stream);
+}
+
+int wfae_gconv3x3_bwd_weight_bf16(const uint16_t* dy, const uint16_t* x, float* dw, int NB, int C, int H, int W, int groups,
+                                  int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(dy && x && dw, WFAE_ERR_NULL_POINTER, "gconv3x3_bwd_weight_bf16: null pointer");
+  WFAE_REQUIRE(NB > 0 && C > 0 && H > 0 && W > 0 && groups > 0 && groups <= 65535 && C % groups == 0,
+               WFAE_ERR_BAD_SHAPE, "gconv3x3_bwd_weight_bf16: bad shape");
+  const int rc = gconv3_wgrad_mfma(dy, x, dw, NB, C, H, W, groups, accumulate, ws, ws_bytes, (hipStream_t)stream);
+  if (rc == WFAE_ERR_UNSUPPORTED)
+    return fail(rc, "gconv3x3_bwd_weight_bf16: needs 4 / 8 / 16 / 32 channels per group, W %% 4 == 0, aligned tensors");
+  return rc;
 }
 
 int wfae_gconv3x3_bwd_weight(const float* dy, const float* x, float* dw, int NB, int C, int H, int W,
@@ -2216,6 +2253,45 @@ int wfae_wino_out_t_split(int variant, const float* lo, uint16_t* Mt3, int plane
   WFAE_WINO_TILE_CHECK("wino_out_t_split", Clo);
   WFAE_REQUIRE(planes == 1 || planes == 3, WFAE_ERR_BAD_SHAPE, "wino_out_t_split: planes must be 1 or 3");
   return wino_out_t_split(variant, lo, Mt3, planes, NB, Clo, Hlo, Wlo, (hipStream_t)stream);
+}
+
+// bf16-stored tensors on the tensor side of the four transforms (the transform-domain operands / products are unchanged)
+int wfae_wino_in_split_bf16(int variant, const uint16_t* hi, uint16_t* V3, int planes, int NB, int Chi, int Hlo, int Wlo,
+                            wfae_stream_t stream) {
+  WFAE_REQUIRE(hi && V3, WFAE_ERR_NULL_POINTER, "wino_in_split_bf16: null pointer");
+  WFAE_WINO_TILE_CHECK("wino_in_split_bf16", Chi);
+  WFAE_REQUIRE(planes == 1 || planes == 3, WFAE_ERR_BAD_SHAPE, "wino_in_split_bf16: planes must be 1 or 3");
+  return wino_in_split(variant, hi, V3, planes, NB, Chi, Hlo, Wlo, (hipStream_t)stream);
+}
+int wfae_wino_out_t_split_bf16(int variant, const uint16_t* lo, uint16_t* Mt3, int planes, int NB, int Clo, int Hlo, int Wlo,
+                               wfae_stream_t stream) {
+  WFAE_REQUIRE(lo && Mt3, WFAE_ERR_NULL_POINTER, "wino_out_t_split_bf16: null pointer");
+  WFAE_WINO_TILE_CHECK("wino_out_t_split_bf16", Clo);
+  WFAE_REQUIRE(planes == 1 || planes == 3, WFAE_ERR_BAD_SHAPE, "wino_out_t_split_bf16: planes must be 1 or 3");
+  return wino_out_t_split(variant, lo, Mt3, planes, NB, Clo, Hlo, Wlo, (hipStream_t)stream);
+}
+/* part null: plain transform; else also the BatchNorm sums of the ROUNDED result (part_capacity / splits_out as the fp32 forms) */
+int wfae_wino_out_bf16(int variant, const float* M, uint16_t* lo, int NB, int Clo, int Hlo, int Wlo, double* part,
+                       int64_t part_capacity, int* splits_out, wfae_stream_t stream) {
+  WFAE_REQUIRE(M && lo && (part != nullptr) == (splits_out != nullptr), WFAE_ERR_NULL_POINTER, "wino_out_bf16: null pointer");
+  WFAE_WINO_TILE_CHECK("wino_out_bf16", Clo);
+  if (!part) return wino_out(variant, M, lo, NB, Clo, Hlo, Wlo, (hipStream_t)stream);
+  const int splits = wino_out_stat_splits(variant, NB, Hlo, Wlo);
+  WFAE_REQUIRE(part_capacity >= (int64_t)splits * Clo * 2, WFAE_ERR_WORKSPACE, "wino_out_bf16: part holds %lld doubles, needs %lld",
+               (long long)part_capacity, (long long)splits * Clo * 2);
+  *splits_out = splits;
+  return wino_out_stats(variant, M, lo, NB, Clo, Hlo, Wlo, part, (hipStream_t)stream);
+}
+int wfae_wino_in_t_bf16(int variant, const float* dV, uint16_t* hi, int NB, int Chi, int Hlo, int Wlo, double* part,
+                        int64_t part_capacity, int* splits_out, wfae_stream_t stream) {
+  WFAE_REQUIRE(dV && hi && (part != nullptr) == (splits_out != nullptr), WFAE_ERR_NULL_POINTER, "wino_in_t_bf16: null pointer");
+  WFAE_WINO_TILE_CHECK("wino_in_t_bf16", Chi);
+  if (!part) return wino_in_t(variant, dV, hi, NB, Chi, Hlo, Wlo, (hipStream_t)stream);
+  const int splits = wino_out_stat_splits(variant, NB, Hlo, Wlo);
+  WFAE_REQUIRE(part_capacity >= (int64_t)splits * Chi * 2, WFAE_ERR_WORKSPACE, "wino_in_t_bf16: part holds %lld doubles, needs %lld",
+               (long long)part_capacity, (long long)splits * Chi * 2);
+  *splits_out = splits;
+  return wino_in_t_stats(variant, dV, hi, NB, Chi, Hlo, Wlo, part, (hipStream_t)stream);
 }
 
 int wfae_wino_gemm_down_split(int variant, const uint16_t* U3, const uint16_t* V3, float* M, int planes, int NB, int Chi, int Clo,

@@ -31,7 +31,7 @@ __device__ __forceinline__ float act_grad_f(float u) {
 // block (c, s) reduces the s-th slice of the (outer*inner) index space.
 struct RedGeom {
   int outer, C, inner, splits;
-  long per_split;  // elements per split (multiple of 4 when vectorised)
+  long per_split;  // elements per split (multiple of 8: whole vector accesses of fp32 and bf16 tensors)
 };
 
 inline RedGeom red_geom(int outer, int C, int inner, long max_parts_per_c) {
@@ -44,7 +44,7 @@ inline RedGeom red_geom(int outer, int C, int inner, long max_parts_per_c) {
   if (splits > (total + min_chunk - 1) / min_chunk) splits = (total + min_chunk - 1) / min_chunk;
   if (splits < 1) splits = 1;
   long per = (total + splits - 1) / splits;
-  per = (per + 3) / 4 * 4;
+  per = (per + 7) / 8 * 8;   // whole 16-byte accesses of either element type
   g.per_split = per;
   g.splits = (int)((total + per - 1) / per);
   return g;
@@ -52,9 +52,10 @@ inline RedGeom red_geom(int outer, int C, int inner, long max_parts_per_c) {
 
 // mode 0: (sum x, sum x^2)          stats
 // mode 1: (sum x, 0)                plain sum
-template <int MODE>
-__global__ __launch_bounds__(RT) void chan_reduce_kernel(const float* __restrict__ x, double* __restrict__ part,
+template <int MODE, typename T = float>
+__global__ __launch_bounds__(RT) void chan_reduce_kernel(const T* __restrict__ x, double* __restrict__ part,
                                                          RedGeom g, int vec) {
+  constexpr int W = ElemW<T>::W;
   __shared__ double sm[16];
   const int c = blockIdx.x, s = blockIdx.y;
   const long total = (long)g.outer * g.inner;
@@ -63,23 +64,27 @@ __global__ __launch_bounds__(RT) void chan_reduce_kernel(const float* __restrict
   if (end > total) end = total;
   double s1 = 0.0, s2 = 0.0;
   if (vec) {
-    // (outer, inner) cursor advanced incrementally: no 64-bit division in the loop; the four values of a float4
-    // are combined in fp32 before they enter the fp64 accumulators (the kernels were VALU-, not HBM-bound)
-    long i = beg + (long)threadIdx.x * 4;
+    // (outer, inner) cursor advanced incrementally: no 64-bit division in the loop; the values of a 16-byte access
+    // are combined four at a time in fp32 before they enter the fp64 accumulators (the kernels were VALU-, not HBM-bound)
+    long i = beg + (long)threadIdx.x * W;
     long o = i / g.inner;
     long in = i - o * g.inner;
-    for (; i < end; i += RT * 4) {
-      const float4 v = *reinterpret_cast<const float4*>(x + (o * g.C + c) * g.inner + in);
-      s1 += (double)((v.x + v.y) + (v.z + v.w));
-      if (MODE == 0) s2 += (double)(fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w));
-      in += RT * 4;
+    for (; i < end; i += RT * W) {
+      float v[W];
+      ldv(x + (o * g.C + c) * g.inner + in, v);
+#pragma unroll
+      for (int q = 0; q < W; q += 4) {
+        s1 += (double)((v[q] + v[q + 1]) + (v[q + 2] + v[q + 3]));
+        if (MODE == 0) s2 += (double)(fmaf(v[q], v[q], v[q + 1] * v[q + 1]) + fmaf(v[q + 2], v[q + 2], v[q + 3] * v[q + 3]));
+      }
+      in += RT * W;
       while (in >= g.inner) { in -= g.inner; ++o; }
     }
   } else {
     for (long i = beg + threadIdx.x; i < end; i += RT) {
       const long o = i / g.inner;
       const long in = i - o * g.inner;
-      const float v = x[(o * g.C + c) * g.inner + in];
+      const float v = ld1(x + (o * g.C + c) * g.inner + in);
       s1 += v;
       if (MODE == 0) s2 += (double)v * v;
     }
@@ -198,37 +203,51 @@ __global__ void sum_finalize_kernel(const double* __restrict__ part, int splits,
 // STATS: the block also reduces the sum / sum of squares of the values it WRITES (fp64 accumulators fed with fp32 sums of
 // four, exactly like chan_reduce_kernel) and leaves them in part[(split * C + c) * 2 + {0,1}], split = n * gridDim.y +
 // blockIdx.y — the BatchNorm that reads y next (the first Bottleneck after a Down/Up unit) needs no statistics pass
-template <int ACT, bool STATS = false>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x,
+template <int ACT, bool STATS = false, typename T = float>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x,
                                                          const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, float* __restrict__ y,
+                                                         const float* __restrict__ shift, T* __restrict__ y,
                                                          int C, int HW, int vec, int nt, double* __restrict__ part = nullptr) {
+  constexpr int W = ElemW<T>::W;
   __shared__ double sm[16];
   const int plane = blockIdx.x;
   const int c = plane % C;
   const float a = scale[c], b = shift[c];
-  const float* xp = x + (long)plane * HW;
-  float* yp = y + (long)plane * HW;
+  const T* xp = x + (long)plane * HW;
+  T* yp = y + (long)plane * HW;
   double s1 = 0.0, s2 = 0.0;
   if (vec) {
-    const int n4 = HW >> 2;
-    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n4; i += gridDim.y * blockDim.x) {
-      float4 v = reinterpret_cast<const float4*>(xp)[i];
-      v.x = fmaf(v.x, a, b); v.y = fmaf(v.y, a, b); v.z = fmaf(v.z, a, b); v.w = fmaf(v.w, a, b);
-      typedef float vf4 __attribute__((ext_vector_type(4)));
-      const vf4 o = {act_f<ACT>(v.x), act_f<ACT>(v.y), act_f<ACT>(v.z), act_f<ACT>(v.w)};
-      if (nt) __builtin_nontemporal_store(o, reinterpret_cast<vf4*>(yp) + i);
-      else reinterpret_cast<vf4*>(yp)[i] = o;
+    const int nv = HW / W;
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < nv; i += gridDim.y * blockDim.x) {
+      float v[W], o[W];
+      ldv(xp + (long)i * W, v);
+#pragma unroll
+      for (int q = 0; q < W; ++q) o[q] = act_f<ACT>(fmaf(v[q], a, b));
+      if (nt) stv<true>(yp + (long)i * W, o);
+      else stv(yp + (long)i * W, o);
       if constexpr (STATS) {
-        s1 += (double)((o.x + o.y) + (o.z + o.w));
-        s2 += (double)(fmaf(o.x, o.x, o.y * o.y) + fmaf(o.z, o.z, o.w * o.w));
+        // the sums are those of the values a reader of y will see: rounded to the storage type first
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+          for (int q = 0; q < W; q += 2) {
+            const unsigned pk = pack_bf16(o[q], o[q + 1]);
+            o[q] = bf16_lo(pk);
+            o[q + 1] = bf16_hi(pk);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < W; q += 4) {
+          s1 += (double)((o[q] + o[q + 1]) + (o[q + 2] + o[q + 3]));
+          s2 += (double)(fmaf(o[q], o[q], o[q + 1] * o[q + 1]) + fmaf(o[q + 2], o[q + 2], o[q + 3] * o[q + 3]));
+        }
       }
     }
   } else {
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < HW; i += gridDim.y * blockDim.x) {
-      const float o = act_f<ACT>(fmaf(xp[i], a, b));
-      yp[i] = o;
+      float o = act_f<ACT>(fmaf(ld1(xp + i), a, b));
+      st1(yp + i, o);
       if constexpr (STATS) {
+        if constexpr (sizeof(T) == 2) o = ld1(yp + i);
         s1 += o;
         s2 += (double)o * o;
       }
@@ -281,14 +300,15 @@ __global__ __launch_bounds__(64) void bn_finalize_parts_kernel(const double* __r
 }
 
 // backward pass 1: per channel  sum dU  and  sum dU * xhat,  dU = dy * act'(u)
-template <int ACT>
-__global__ __launch_bounds__(RT) void bn_act_bwd_reduce_kernel(const float* __restrict__ dy,
-                                                               const float* __restrict__ x,
+template <int ACT, typename T = float>
+__global__ __launch_bounds__(RT) void bn_act_bwd_reduce_kernel(const T* __restrict__ dy,
+                                                               const T* __restrict__ x,
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ shift,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ invstd,
                                                                double* __restrict__ part, RedGeom g, int vec) {
+  constexpr int W = ElemW<T>::W;
   __shared__ double sm[16];
   const int c = blockIdx.x, s = blockIdx.y;
   const long total = (long)g.outer * g.inner;
@@ -303,39 +323,44 @@ __global__ __launch_bounds__(RT) void bn_act_bwd_reduce_kernel(const float* __re
     s2 += (double)du * ((xv - mu) * is);
   };
   if (vec) {
-    long i = beg + (long)threadIdx.x * 4;
+    long i = beg + (long)threadIdx.x * W;
     long o = i / g.inner;
     long in = i - o * g.inner;
     // two chunks per iteration, all four loads issued before the arithmetic (the fp64 accumulation chain kept the compiler
     // from overlapping iterations: 5.2 TB/s against 6.1 of the dx pass); sums are added in the same order as one chunk
-    // per iteration would, a missing second chunk re-reads the first and is multiplied by zero
-    auto quad = [&](const float4& xv, const float4& dv, float m) {
-      const float d0 = m * dv.x * act_grad_f<ACT>(fmaf(xv.x, a, b)), d1 = m * dv.y * act_grad_f<ACT>(fmaf(xv.y, a, b));
-      const float d2 = m * dv.z * act_grad_f<ACT>(fmaf(xv.z, a, b)), d3 = m * dv.w * act_grad_f<ACT>(fmaf(xv.w, a, b));
+    // per iteration would, a missing second chunk re-reads the first and is skipped
+    auto quad = [&](const float* xv, const float* dv) {
+      const float d0 = dv[0] * act_grad_f<ACT>(fmaf(xv[0], a, b)), d1 = dv[1] * act_grad_f<ACT>(fmaf(xv[1], a, b));
+      const float d2 = dv[2] * act_grad_f<ACT>(fmaf(xv[2], a, b)), d3 = dv[3] * act_grad_f<ACT>(fmaf(xv[3], a, b));
       s1 += (double)((d0 + d1) + (d2 + d3));
-      const float h0 = (xv.x - mu) * is, h1 = (xv.y - mu) * is, h2 = (xv.z - mu) * is, h3 = (xv.w - mu) * is;
+      const float h0 = (xv[0] - mu) * is, h1 = (xv[1] - mu) * is, h2 = (xv[2] - mu) * is, h3 = (xv[3] - mu) * is;
       s2 += (double)(fmaf(d0, h0, d1 * h1) + fmaf(d2, h2, d3 * h3));
     };
-    for (; i < end; i += 2 * RT * 4) {
+    for (; i < end; i += 2 * RT * W) {
       const long off0 = (o * g.C + c) * g.inner + in;
-      in += RT * 4;
+      in += RT * W;
       while (in >= g.inner) { in -= g.inner; ++o; }
-      const bool two = i + RT * 4 < end;
+      const bool two = i + RT * W < end;
       const long off1 = two ? (o * g.C + c) * g.inner + in : off0;
-      in += RT * 4;
+      in += RT * W;
       while (in >= g.inner) { in -= g.inner; ++o; }
-      const float4 xv0 = *reinterpret_cast<const float4*>(x + off0);
-      const float4 dv0 = *reinterpret_cast<const float4*>(dy + off0);
-      const float4 xv1 = *reinterpret_cast<const float4*>(x + off1);
-      const float4 dv1 = *reinterpret_cast<const float4*>(dy + off1);
-      quad(xv0, dv0, 1.f);
-      if (two) quad(xv1, dv1, 1.f);
+      float xv0[W], dv0[W], xv1[W], dv1[W];
+      ldv(x + off0, xv0);
+      ldv(dy + off0, dv0);
+      ldv(x + off1, xv1);
+      ldv(dy + off1, dv1);
+#pragma unroll
+      for (int q = 0; q < W; q += 4) quad(xv0 + q, dv0 + q);
+      if (two) {
+#pragma unroll
+        for (int q = 0; q < W; q += 4) quad(xv1 + q, dv1 + q);
+      }
     }
   } else {
     for (long i = beg + threadIdx.x; i < end; i += RT) {
       const long o = i / g.inner;
       const long off = (o * g.C + c) * g.inner + (i - o * g.inner);
-      one(x[off], dy[off]);
+      one(ld1(x + off), ld1(dy + off));
     }
   }
   const double r1 = block_sum(s1, sm);
@@ -364,16 +389,17 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int spli
 }
 
 // backward pass 2: dx = gamma*invstd*(dU - sum_dU/n - xhat*sum_dUxhat/n) (+res)
-template <int ACT, int NTMODE>
-__global__ __launch_bounds__(256) void bn_act_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int ACT, int NTMODE, typename T = float>
+__global__ __launch_bounds__(256) void bn_act_bwd_dx_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ coef,
-                                                            const float* __restrict__ res, float* __restrict__ dx,
+                                                            const T* __restrict__ res, T* __restrict__ dx,
                                                             int C, int HW, float inv_count, int training, int vec) {
+  constexpr int W = ElemW<T>::W;
   const int plane = blockIdx.x;
   const int c = plane % C;
   const float a = scale[c], b = shift[c], mu = mean[c], is = invstd[c];
@@ -387,32 +413,23 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dx_kernel(const float* __restr
     return gi * (du - k1 - xh * k2) + rv;
   };
   if (vec) {
-    const int n4 = HW >> 2;
-    typedef float vf4 __attribute__((ext_vector_type(4)));
-    const vf4* __restrict__ x4 = reinterpret_cast<const vf4*>(x + base);
-    const vf4* __restrict__ d4 = reinterpret_cast<const vf4*>(dy + base);
-    const vf4* __restrict__ r4 = res ? reinterpret_cast<const vf4*>(res + base) : nullptr;
-    vf4* __restrict__ o4 = reinterpret_cast<vf4*>(dx + base);
-    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n4; i += gridDim.y * blockDim.x) {
-      vf4 xv, dv, rv = {0.f, 0.f, 0.f, 0.f};
-      if (NTMODE) {   // streamed once: keep them out of the way of the GEMM operands in L2
-        xv = __builtin_nontemporal_load(x4 + i);
-        dv = __builtin_nontemporal_load(d4 + i);
-        if (r4) rv = __builtin_nontemporal_load(r4 + i);
-      } else {
-        xv = x4[i];
-        dv = d4[i];
-        if (r4) rv = r4[i];
-      }
-      vf4 o;
-      o.x = one(xv.x, dv.x, rv.x); o.y = one(xv.y, dv.y, rv.y);
-      o.z = one(xv.z, dv.z, rv.z); o.w = one(xv.w, dv.w, rv.w);
-      if (NTMODE == 2) __builtin_nontemporal_store(o, o4 + i);
-      else o4[i] = o;
+    const int nv = HW / W;
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < nv; i += gridDim.y * blockDim.x) {
+      const long off = base + (long)i * W;
+      float xv[W], dv[W], rv[W], o[W];
+#pragma unroll
+      for (int q = 0; q < W; ++q) rv[q] = 0.f;
+      // streamed once: keep them out of the way of the GEMM operands in L2
+      ldv<NTMODE != 0>(x + off, xv);
+      ldv<NTMODE != 0>(dy + off, dv);
+      if (res) ldv<NTMODE != 0>(res + off, rv);
+#pragma unroll
+      for (int q = 0; q < W; ++q) o[q] = one(xv[q], dv[q], rv[q]);
+      stv<NTMODE == 2>(dx + off, o);
     }
   } else {
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < HW; i += gridDim.y * blockDim.x)
-      dx[base + i] = one(x[base + i], dy[base + i], res ? res[base + i] : 0.f);
+      st1(dx + base + i, one(ld1(x + base + i), ld1(dy + base + i), res ? ld1(res + base + i) : 0.f));
   }
 }
 
@@ -655,11 +672,156 @@ __global__ void adaptive_weight_kernel(const double* __restrict__ ss_rec, const 
   }
 }
 
+// fp32 <-> bf16 storage conversion (the boundaries of the bf16-storage mode: latent projections, tests)
+template <bool TO_BF16>
+__global__ __launch_bounds__(256) void convert_kernel(const void* __restrict__ src, void* __restrict__ dst, long n) {
+  const long stride = (long)gridDim.x * blockDim.x * 8;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      float v[8];
+      if (TO_BF16) {
+        float a[4], b[4];
+        ldv((const float*)src + i, a);
+        ldv((const float*)src + i + 4, b);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] = a[q]; v[4 + q] = b[q]; }
+        stv((bf16_t*)dst + i, v);
+      } else {
+        ldv((const bf16_t*)src + i, v);
+        const float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
+        stv((float*)dst + i, a);
+        stv((float*)dst + i + 4, b);
+      }
+    } else {
+      for (long j = i; j < n; ++j) {
+        if (TO_BF16) st1((bf16_t*)dst + j, ((const float*)src)[j]);
+        else ((float*)dst)[j] = ld1((const bf16_t*)src + j);
+      }
+    }
+  }
+}
+
 inline int grid_1d(long n, int per_thread = 4) {
   long b = (n / per_thread + 255) / 256;
   if (b > 4096) b = 4096;
   if (b < 1) b = 1;
   return (int)b;
+}
+
+template <typename T>
+int bn_stats_train_impl(const T* x, int NB, int C, int HW, const float* gamma, const float* beta, float eps, float momentum,
+                        float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* scale,
+                        float* shift, void* ws, size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(x && gamma && beta && save_mean && save_invstd && scale && shift, WFAE_ERR_NULL_POINTER,
+               "bn_stats_train: null pointer");
+  WFAE_REQUIRE(NB > 0 && C > 0 && HW > 0 && C <= 65535 * 32, WFAE_ERR_BAD_SHAPE, "bn_stats_train: bad shape");
+  const long maxp = (long)(ws_bytes / (sizeof(double) * 2 * (size_t)C));
+  WFAE_REQUIRE(ws && maxp >= 1, WFAE_ERR_WORKSPACE, "bn_stats_train: workspace too small");
+  RedGeom g = red_geom(NB, C, HW, maxp < 65535 ? maxp : 65535);
+  const int vec = (HW % ElemW<T>::W == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((chan_reduce_kernel<0, T>), dim3(C, g.splits), dim3(RT), 0, st, x, (double*)ws, g, vec);
+  int rc = check_launch("bn_stats");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, g.splits,
+                     (long)NB * HW, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
+                     save_invstd, scale, shift);
+  return check_launch("bn_finalize");
+}
+
+template <typename T>
+int bn_act_fwd_impl(const T* x, const float* scale, const float* shift, T* y, int NB, int C, int HW, int act,
+                    double* part, int64_t part_capacity, int* splits_out, wfae_stream_t stream) {
+  WFAE_REQUIRE(x && scale && shift && y, WFAE_ERR_NULL_POINTER, "bn_act_fwd: null pointer");
+  WFAE_REQUIRE(NB > 0 && C > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "bn_act_fwd: bad shape");
+  constexpr int W = ElemW<T>::W;
+  const int vec = (HW % W == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
+  int gy = cdiv(vec ? HW / W : HW, 256 * 4);
+  if (gy < 1) gy = 1;
+  if (gy > 1024) gy = 1024;
+  dim3 grid((unsigned)((long)NB * C), gy);
+  hipStream_t st = (hipStream_t)stream;
+  const int nt_fwd = 0;   // nontemporal store of y: measured neutral in round 2
+  if (splits_out) {
+    const int64_t splits = (int64_t)NB * gy;
+    WFAE_REQUIRE(part && part_capacity >= splits * C * 2, WFAE_ERR_WORKSPACE, "bn_act_fwd_stats: part holds %lld doubles, needs %lld",
+                 (long long)part_capacity, (long long)(splits * C * 2));
+    WFAE_REQUIRE(splits < (1ll << 31), WFAE_ERR_BAD_SHAPE, "bn_act_fwd_stats: too many partial rows");
+    *splits_out = (int)splits;
+    if (act == 1)
+      hipLaunchKernelGGL((bn_act_fwd_kernel<1, true, T>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, part);
+    else if (act == 2)
+      hipLaunchKernelGGL((bn_act_fwd_kernel<2, true, T>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, part);
+    else
+      hipLaunchKernelGGL((bn_act_fwd_kernel<0, true, T>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, part);
+    return check_launch("bn_act_fwd_stats");
+  }
+  if (act == 1)
+    hipLaunchKernelGGL((bn_act_fwd_kernel<1, false, T>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, (double*)nullptr);
+  else if (act == 2)
+    hipLaunchKernelGGL((bn_act_fwd_kernel<2, false, T>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, (double*)nullptr);
+  else
+    hipLaunchKernelGGL((bn_act_fwd_kernel<0, false, T>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, (double*)nullptr);
+  return check_launch("bn_act_fwd");
+}
+
+template <typename T>
+int bn_act_bwd_impl(const T* dy, const T* x, const float* gamma, const float* scale, const float* shift,
+                    const float* save_mean, const float* save_invstd, const T* res, T* dx, float* dgamma, float* dbeta, int NB,
+                    int C, int HW, int act, int training, int accumulate, int phases, void* ws, size_t ws_bytes,
+                    wfae_stream_t stream) {
+  WFAE_REQUIRE(dy && x && gamma && scale && shift && save_mean && save_invstd, WFAE_ERR_NULL_POINTER,
+               "bn_act_bwd: null pointer");
+  WFAE_REQUIRE(phases >= 1 && phases <= 3, WFAE_ERR_BAD_SHAPE, "bn_act_bwd: phases must be 1, 2 or 3");
+  WFAE_REQUIRE(NB > 0 && C > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "bn_act_bwd: bad shape");
+  // workspace: coef[2C] floats (16-byte aligned) followed by fp64 partials
+  const size_t coef_bytes = ((size_t)2 * C * sizeof(float) + 15) / 16 * 16;
+  WFAE_REQUIRE(ws && ws_bytes > coef_bytes + sizeof(double) * 2 * (size_t)C, WFAE_ERR_WORKSPACE,
+               "bn_act_bwd: workspace too small");
+  constexpr int W = ElemW<T>::W;
+  float* coef = (float*)ws;
+  double* part = (double*)((char*)ws + coef_bytes);
+  const long maxp = (long)((ws_bytes - coef_bytes) / (sizeof(double) * 2 * (size_t)C));
+  RedGeom g = red_geom(NB, C, HW, maxp < 65535 ? maxp : 65535);
+  const int vec = (HW % W == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) |
+                                      reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(res)) & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = WFAE_OK;
+  if (phases & 1) {
+    if (act == 1)
+      hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<1, T>), dim3(C, g.splits), dim3(RT), 0, st, dy, x, scale, shift,
+                         save_mean, save_invstd, part, g, vec);
+    else if (act == 2)
+      hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<2, T>), dim3(C, g.splits), dim3(RT), 0, st, dy, x, scale, shift,
+                         save_mean, save_invstd, part, g, vec);
+    else
+      hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<0, T>), dim3(C, g.splits), dim3(RT), 0, st, dy, x, scale, shift,
+                         save_mean, save_invstd, part, g, vec);
+    rc = check_launch("bn_act_bwd_reduce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, g.splits,
+                       C, dgamma, dbeta, coef, accumulate);
+    rc = check_launch("bn_bwd_finalize");
+    if (rc) return rc;
+  }
+  if ((phases & 2) && dx) {
+    int gy = cdiv(vec ? HW / W : HW, 256 * 4);
+    if (gy < 1) gy = 1;
+    if (gy > 1024) gy = 1024;
+    dim3 grid((unsigned)((long)NB * C), gy);
+    const float inv_count = 1.0f / (float)((double)NB * HW);
+    // nontemporal loads + stores for the GELU form (measured, tools/kbench.py, B = 32: the nontemporal STORE of dx lifts
+    // the kernel pair from 5.0-5.4 to 5.7-6.0 TB/s; the loads alone change nothing)
+#define WFAE_DX(ACT_, NT_)                                                                                       \
+  hipLaunchKernelGGL((bn_act_bwd_dx_kernel<ACT_, NT_, T>), grid, dim3(256), 0, st, dy, x, gamma, scale, shift, save_mean, \
+                     save_invstd, coef, res, dx, C, HW, inv_count, training, vec)
+    if (act == 1) WFAE_DX(1, 2);
+    else if (act == 2) WFAE_DX(2, 0);
+    else WFAE_DX(0, 0);
+#undef WFAE_DX
+    rc = check_launch("bn_act_bwd_dx");
+  }
+  return rc;
 }
 
 }  // namespace
@@ -670,21 +832,15 @@ int wfae_bn_stats_train(const float* x, int NB, int C, int HW, const float* gamm
                         float eps, float momentum, float* running_mean, float* running_var,
                         float* save_mean, float* save_invstd, float* scale, float* shift, void* ws,
                         size_t ws_bytes, wfae_stream_t stream) {
-  WFAE_REQUIRE(x && gamma && beta && save_mean && save_invstd && scale && shift, WFAE_ERR_NULL_POINTER,
-               "bn_stats_train: null pointer");
-  WFAE_REQUIRE(NB > 0 && C > 0 && HW > 0 && C <= 65535 * 32, WFAE_ERR_BAD_SHAPE, "bn_stats_train: bad shape");
-  const long maxp = (long)(ws_bytes / (sizeof(double) * 2 * (size_t)C));
-  WFAE_REQUIRE(ws && maxp >= 1, WFAE_ERR_WORKSPACE, "bn_stats_train: workspace too small");
-  RedGeom g = red_geom(NB, C, HW, maxp < 65535 ? maxp : 65535);
-  const int vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((chan_reduce_kernel<0>), dim3(C, g.splits), dim3(RT), 0, st, x, (double*)ws, g, vec);
-  int rc = check_launch("bn_stats");
-  if (rc) return rc;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, g.splits,
-                     (long)NB * HW, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
-                     save_invstd, scale, shift);
-  return check_launch("bn_finalize");
+  return bn_stats_train_impl(x, NB, C, HW, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale,
+                             shift, ws, ws_bytes, stream);
+}
+int wfae_bn_stats_train_bf16(const uint16_t* x, int NB, int C, int HW, const float* gamma, const float* beta,
+                             float eps, float momentum, float* running_mean, float* running_var,
+                             float* save_mean, float* save_invstd, float* scale, float* shift, void* ws,
+                             size_t ws_bytes, wfae_stream_t stream) {
+  return bn_stats_train_impl(x, NB, C, HW, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale,
+                             shift, ws, ws_bytes, stream);
 }
 
 int wfae_bn_stats_from_rows(const double* stat_part, int rows, int NB, int C, int HW, const float* gamma,
@@ -723,47 +879,22 @@ int wfae_bn_fold_eval(const float* gamma, const float* beta, const float* runnin
   return check_launch("bn_fold_eval");
 }
 
-static int bn_act_fwd_impl(const float* x, const float* scale, const float* shift, float* y, int NB, int C, int HW, int act,
-                           double* part, int64_t part_capacity, int* splits_out, wfae_stream_t stream) {
-  WFAE_REQUIRE(x && scale && shift && y, WFAE_ERR_NULL_POINTER, "bn_act_fwd: null pointer");
-  WFAE_REQUIRE(NB > 0 && C > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "bn_act_fwd: bad shape");
-  const int vec = (HW % 4 == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
-  int gy = cdiv(vec ? HW / 4 : HW, 256 * 4);
-  if (gy < 1) gy = 1;
-  if (gy > 1024) gy = 1024;
-  dim3 grid((unsigned)((long)NB * C), gy);
-  hipStream_t st = (hipStream_t)stream;
-  static const int nt_fwd = getenv("WFAE_BN_NT_FWD") ? atoi(getenv("WFAE_BN_NT_FWD")) : 0;   // A/B: nontemporal store of y
-  if (splits_out) {
-    const int64_t splits = (int64_t)NB * gy;
-    WFAE_REQUIRE(part && part_capacity >= splits * C * 2, WFAE_ERR_WORKSPACE, "bn_act_fwd_stats: part holds %lld doubles, needs %lld",
-                 (long long)part_capacity, (long long)(splits * C * 2));
-    WFAE_REQUIRE(splits < (1ll << 31), WFAE_ERR_BAD_SHAPE, "bn_act_fwd_stats: too many partial rows");
-    *splits_out = (int)splits;
-    if (act == 1)
-      hipLaunchKernelGGL((bn_act_fwd_kernel<1, true>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, part);
-    else if (act == 2)
-      hipLaunchKernelGGL((bn_act_fwd_kernel<2, true>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, part);
-    else
-      hipLaunchKernelGGL((bn_act_fwd_kernel<0, true>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, part);
-    return check_launch("bn_act_fwd_stats");
-  }
-  if (act == 1)
-    hipLaunchKernelGGL((bn_act_fwd_kernel<1>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, (double*)nullptr);
-  else if (act == 2)
-    hipLaunchKernelGGL((bn_act_fwd_kernel<2>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, (double*)nullptr);
-  else
-    hipLaunchKernelGGL((bn_act_fwd_kernel<0>), grid, dim3(256), 0, st, x, scale, shift, y, C, HW, vec, nt_fwd, (double*)nullptr);
-  return check_launch("bn_act_fwd");
-}
-
 int wfae_bn_act_fwd(const float* x, const float* scale, const float* shift, float* y, int NB, int C,
                     int HW, int act, wfae_stream_t stream) {
+  return bn_act_fwd_impl(x, scale, shift, y, NB, C, HW, act, nullptr, 0, nullptr, stream);
+}
+int wfae_bn_act_fwd_bf16(const uint16_t* x, const float* scale, const float* shift, uint16_t* y, int NB, int C,
+                         int HW, int act, wfae_stream_t stream) {
   return bn_act_fwd_impl(x, scale, shift, y, NB, C, HW, act, nullptr, 0, nullptr, stream);
 }
 
 int wfae_bn_act_fwd_stats(const float* x, const float* scale, const float* shift, float* y, int NB, int C, int HW, int act,
                           double* part, int64_t part_capacity, int* splits_out, wfae_stream_t stream) {
+  WFAE_REQUIRE(part && splits_out, WFAE_ERR_NULL_POINTER, "bn_act_fwd_stats: null pointer");
+  return bn_act_fwd_impl(x, scale, shift, y, NB, C, HW, act, part, part_capacity, splits_out, stream);
+}
+int wfae_bn_act_fwd_stats_bf16(const uint16_t* x, const float* scale, const float* shift, uint16_t* y, int NB, int C, int HW,
+                               int act, double* part, int64_t part_capacity, int* splits_out, wfae_stream_t stream) {
   WFAE_REQUIRE(part && splits_out, WFAE_ERR_NULL_POINTER, "bn_act_fwd_stats: null pointer");
   return bn_act_fwd_impl(x, scale, shift, y, NB, C, HW, act, part, part_capacity, splits_out, stream);
 }
@@ -808,58 +939,33 @@ int wfae_bn_act_bwd(const float* dy, const float* x, const float* gamma, const f
                     const float* res, float* dx, float* dgamma, float* dbeta, int NB, int C, int HW,
                     int act, int training, int accumulate, int phases, void* ws, size_t ws_bytes,
                     wfae_stream_t stream) {
-  WFAE_REQUIRE(dy && x && gamma && scale && shift && save_mean && save_invstd, WFAE_ERR_NULL_POINTER,
-               "bn_act_bwd: null pointer");
-  WFAE_REQUIRE(phases >= 1 && phases <= 3, WFAE_ERR_BAD_SHAPE, "bn_act_bwd: phases must be 1, 2 or 3");
-  WFAE_REQUIRE(NB > 0 && C > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "bn_act_bwd: bad shape");
-  // workspace: coef[2C] floats (16-byte aligned) followed by fp64 partials
-  const size_t coef_bytes = ((size_t)2 * C * sizeof(float) + 15) / 16 * 16;
-  WFAE_REQUIRE(ws && ws_bytes > coef_bytes + sizeof(double) * 2 * (size_t)C, WFAE_ERR_WORKSPACE,
-               "bn_act_bwd: workspace too small");
-  float* coef = (float*)ws;
-  double* part = (double*)((char*)ws + coef_bytes);
-  const long maxp = (long)((ws_bytes - coef_bytes) / (sizeof(double) * 2 * (size_t)C));
-  RedGeom g = red_geom(NB, C, HW, maxp < 65535 ? maxp : 65535);
-  const int vec = (HW % 4 == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) |
-                                      reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(res)) & 15) == 0);
-  hipStream_t st = (hipStream_t)stream;
-  int rc = WFAE_OK;
-  if (phases & 1) {
-  if (act == 1)
-    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<1>), dim3(C, g.splits), dim3(RT), 0, st, dy, x, scale, shift,
-                       save_mean, save_invstd, part, g, vec);
-  else if (act == 2)
-    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<2>), dim3(C, g.splits), dim3(RT), 0, st, dy, x, scale, shift,
-                       save_mean, save_invstd, part, g, vec);
-  else
-    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<0>), dim3(C, g.splits), dim3(RT), 0, st, dy, x, scale, shift,
-                       save_mean, save_invstd, part, g, vec);
-  rc = check_launch("bn_act_bwd_reduce");
-  if (rc) return rc;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, g.splits,
-                     C, dgamma, dbeta, coef, accumulate);
-  rc = check_launch("bn_bwd_finalize");
-  if (rc) return rc;
-  }
-  if ((phases & 2) && dx) {
-    int gy = cdiv(vec ? HW / 4 : HW, 256 * 4);
-    if (gy < 1) gy = 1;
-    if (gy > 1024) gy = 1024;
-    dim3 grid((unsigned)((long)NB * C), gy);
-    const float inv_count = 1.0f / (float)((double)NB * HW);
-    // 0 plain, 1 nontemporal loads, 2 nontemporal loads + stores.  Measured (tools/kbench.py, B = 32): the
-    // nontemporal STORE of dx lifts the kernel pair from 5.0-5.4 to 5.7-6.0 TB/s; the loads alone change nothing
-    static const int ntmode = getenv("WFAE_BN_NT") ? atoi(getenv("WFAE_BN_NT")) : 2;
-#define WFAE_DX(ACT_, NT_)                                                                                       \
-  hipLaunchKernelGGL((bn_act_bwd_dx_kernel<ACT_, NT_>), grid, dim3(256), 0, st, dy, x, gamma, scale, shift, save_mean, \
-                     save_invstd, coef, res, dx, C, HW, inv_count, training, vec)
-    if (act == 1) { if (ntmode == 2) WFAE_DX(1, 2); else if (ntmode == 1) WFAE_DX(1, 1); else WFAE_DX(1, 0); }
-    else if (act == 2) WFAE_DX(2, 0);
-    else WFAE_DX(0, 0);
-#undef WFAE_DX
-    rc = check_launch("bn_act_bwd_dx");
-  }
-  return rc;
+  return bn_act_bwd_impl(dy, x, gamma, scale, shift, save_mean, save_invstd, res, dx, dgamma, dbeta, NB, C, HW, act, training,
+                         accumulate, phases, ws, ws_bytes, stream);
+}
+int wfae_bn_act_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* gamma, const float* scale,
+                         const float* shift, const float* save_mean, const float* save_invstd,
+                         const uint16_t* res, uint16_t* dx, float* dgamma, float* dbeta, int NB, int C, int HW,
+                         int act, int training, int accumulate, int phases, void* ws, size_t ws_bytes,
+                         wfae_stream_t stream) {
+  return bn_act_bwd_impl(dy, x, gamma, scale, shift, save_mean, save_invstd, res, dx, dgamma, dbeta, NB, C, HW, act, training,
+                         accumulate, phases, ws, ws_bytes, stream);
+}
+
+int wfae_convert_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, wfae_stream_t stream) {
+  WFAE_REQUIRE(src && dst, WFAE_ERR_NULL_POINTER, "convert_f32_to_bf16: null pointer");
+  WFAE_REQUIRE(n > 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0, WFAE_ERR_BAD_SHAPE,
+               "convert_f32_to_bf16: bad size / alignment");
+  hipLaunchKernelGGL((convert_kernel<true>), dim3(grid_1d(n, 8)), dim3(256), 0, (hipStream_t)stream, (const void*)src, (void*)dst,
+                     (long)n);
+  return check_launch("convert_f32_to_bf16");
+}
+int wfae_convert_bf16_to_f32(const uint16_t* src, float* dst, int64_t n, wfae_stream_t stream) {
+  WFAE_REQUIRE(src && dst, WFAE_ERR_NULL_POINTER, "convert_bf16_to_f32: null pointer");
+  WFAE_REQUIRE(n > 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0, WFAE_ERR_BAD_SHAPE,
+               "convert_bf16_to_f32: bad size / alignment");
+  hipLaunchKernelGGL((convert_kernel<false>), dim3(grid_1d(n, 8)), dim3(256), 0, (hipStream_t)stream, (const void*)src, (void*)dst,
+                     (long)n);
+  return check_launch("convert_bf16_to_f32");
 }
 
 int wfae_gelu_fwd(const float* x, float* y, int64_t n, wfae_stream_t s) {

@@ -104,8 +104,8 @@ __device__ __forceinline__ bool tile_of_thread(int C, int Timg, long T, int& c, 
 }
 
 // hi (N,Chi,2Hlo,2Wlo) -> V[N*N][4Chi][T]
-template <typename WV, bool SPLIT = false>
-__global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ hi, void* __restrict__ V, int Chi,
+template <typename WV, bool SPLIT = false, typename ET = float>
+__global__ __launch_bounds__(256) void wino_in_kernel(const ET* __restrict__ hi, void* __restrict__ V, int Chi,
                                                       int Hlo, int Wlo, long T, int planes = 3) {
   constexpr int N = WV::N, M = WV::M, PSZ = 2 * N;
   const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
   if (!tile_of_thread(Chi, Timg, T, h, n, tl)) return;
   const int ty = tl / TW, tx = tl - ty * TW;
   const int H = 2 * Hlo, W = 2 * Wlo;
-  const float* __restrict__ src = hi + (long)(n * Chi + h) * H * W;
+  const ET* __restrict__ src = hi + (long)(n * Chi + h) * H * W;
   const long t = (long)n * Timg + tl;
   const long xi_stride = 4L * Chi * T;
   const int Y0 = 2 * M * ty - 1, X0 = 2 * M * tx - 1;
@@ -125,23 +125,23 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
     for (int i = 0; i < N; ++i) {
       const int Y = Y0 + 2 * i + p;
       const bool rok = Y >= 0 && Y < H;
-      const float* __restrict__ row = src + (long)(rok ? Y : 0) * W;
+      const ET* __restrict__ row = src + (long)(rok ? Y : 0) * W;
       // the patch row is hi[X0 .. X0 + 2M + 1] with X0 = 2M tx - 1: one halo element, 2M elements that start on a
       // 16-byte boundary (W % 4 == 0, the tiles cover the row exactly), one halo element -> 2 + M/2 loads instead of
       // 2M + 2 (the kernel was bound by load instructions: lanes are 8 M bytes apart, every dword load of a wave
       // touches 16 cache lines)
-      const float v0 = row[X0 >= 0 ? X0 : 0];
+      const float v0 = ld1(row + (X0 >= 0 ? X0 : 0));
       rowbuf[i][0] = (rok && X0 >= 0) ? v0 : 0.f;
 #pragma unroll
       for (int c4 = 0; c4 < 2 * M; c4 += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(row + X0 + 1 + c4);
+        const float4 v = ld4(row + X0 + 1 + c4);
         rowbuf[i][1 + c4] = rok ? v.x : 0.f;
         rowbuf[i][2 + c4] = rok ? v.y : 0.f;
         rowbuf[i][3 + c4] = rok ? v.z : 0.f;
         rowbuf[i][4 + c4] = rok ? v.w : 0.f;
       }
       const int XL = X0 + PSZ - 1;
-      const float vl = row[XL < W ? XL : 0];
+      const float vl = ld1(row + (XL < W ? XL : 0));
       rowbuf[i][PSZ - 1] = (rok && XL < W) ? vl : 0.f;
     }
 #pragma unroll
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 // STATS: the block also leaves the sum / sum of squares of the values it writes (one channel of one image, <= 256 blocks
 // of 2M x 2M) in part[(split * Chi + h) * 2 + {0,1}], split = n * gridDim.x + blockIdx.x — for the BatchNorm that follows
 // a ConvTranspose2d (DecBlock.up)
-template <typename WV, bool STATS = false>
-__global__ __launch_bounds__(256) void wino_in_t_kernel(const float* __restrict__ dV, float* __restrict__ hi, int Chi,
+template <typename WV, bool STATS = false, typename ET = float>
+__global__ __launch_bounds__(256) void wino_in_t_kernel(const float* __restrict__ dV, ET* __restrict__ hi, int Chi,
                                                         int Hlo, int Wlo, long T, double* __restrict__ part = nullptr) {
   constexpr int N = WV::N, M = WV::M, BS = 2 * M;
   const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
@@ -307,13 +307,17 @@ __global__ __launch_bounds__(256) void wino_in_t_kernel(const float* __restrict_
       }
       o[r][c] += a;
     }
-  float* __restrict__ out = hi + ((long)(n * Chi + h) * (2 * Hlo) + BS * ty) * W + BS * tx;
+  ET* __restrict__ out = hi + ((long)(n * Chi + h) * (2 * Hlo) + BS * ty) * W + BS * tx;
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
   for (int r = 0; r < BS; ++r)
 #pragma unroll
     for (int c4 = 0; c4 < BS; c4 += 4) {
-      if (active) *reinterpret_cast<float4*>(out + (long)r * W + c4) = make_float4(o[r][c4], o[r][c4 + 1], o[r][c4 + 2], o[r][c4 + 3]);
+      if constexpr (STATS && sizeof(ET) == 2) {   // the sums are those of the rounded values the BatchNorm will read
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[r][c4 + q] = rounded_as(out, o[r][c4 + q]);
+      }
+      if (active) st4(out + (long)r * W + c4, make_float4(o[r][c4], o[r][c4 + 1], o[r][c4 + 2], o[r][c4 + 3]));
       if (STATS && active) {
         s1 += (double)((o[r][c4] + o[r][c4 + 1]) + (o[r][c4 + 2] + o[r][c4 + 3]));
         s2 += (double)(fmaf(o[r][c4], o[r][c4], o[r][c4 + 1] * o[r][c4 + 1]) + fmaf(o[r][c4 + 2], o[r][c4 + 2], o[r][c4 + 3] * o[r][c4 + 3]));
@@ -334,8 +338,8 @@ __global__ __launch_bounds__(256) void wino_in_t_kernel(const float* __restrict_
 // M[N*N][Clo][T] -> lo (N,Clo,Hlo,Wlo):  Y = A^T M A
 // STATS: the block also leaves the sum / sum of squares of the values it writes (one channel, <= 256 tiles) in
 // part[(split * Clo + l) * 2 + {0,1}], split = n * gridDim.x + blockIdx.x, for the BatchNorm that follows the convolution
-template <typename WV, bool STATS = false>
-__global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ Mx, float* __restrict__ lo, int Clo,
+template <typename WV, bool STATS = false, typename ET = float>
+__global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ Mx, ET* __restrict__ lo, int Clo,
                                                        int Hlo, int Wlo, long T, double* __restrict__ part = nullptr) {
   constexpr int N = WV::N, M = WV::M;
   const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
@@ -353,15 +357,19 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 #pragma unroll
         for (int v = 0; v < N; ++v) m[u][v] = src[(long)(u * N + v) * xi_stride];
       sandwich<M, N>(m, y, [](int a, int i) { return WV::AT[a][i]; });
-      float* __restrict__ dst = lo + ((long)(n * Clo + l) * Hlo + M * ty) * Wlo + M * tx;
+      ET* __restrict__ dst = lo + ((long)(n * Clo + l) * Hlo + M * ty) * Wlo + M * tx;
 #pragma unroll
       for (int a = 0; a < M; ++a) {
+        if constexpr (sizeof(ET) == 2) {   // the sums are those of the rounded values the BatchNorm will read
+#pragma unroll
+          for (int q = 0; q < M; ++q) y[a][q] = rounded_as(dst, y[a][q]);
+        }
         if constexpr (M == 2) {
-          *reinterpret_cast<float2*>(dst + (long)a * Wlo) = make_float2(y[a][0], y[a][1]);
+          st2(dst + (long)a * Wlo, make_float2(y[a][0], y[a][1]));
           s1 += (double)(y[a][0] + y[a][1]);
           s2 += (double)fmaf(y[a][0], y[a][0], y[a][1] * y[a][1]);
         } else {
-          *reinterpret_cast<float4*>(dst + (long)a * Wlo) = make_float4(y[a][0], y[a][1], y[a][2], y[a][3]);
+          st4(dst + (long)a * Wlo, make_float4(y[a][0], y[a][1], y[a][2], y[a][3]));
           s1 += (double)((y[a][0] + y[a][1]) + (y[a][2] + y[a][3]));
           s2 += (double)(fmaf(y[a][0], y[a][0], y[a][1] * y[a][1]) + fmaf(y[a][2], y[a][2], y[a][3] * y[a][3]));
         }
@@ -386,32 +394,32 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 #pragma unroll
     for (int v = 0; v < N; ++v) m[u][v] = src[(long)(u * N + v) * xi_stride];
   sandwich<M, N>(m, y, [](int a, int i) { return WV::AT[a][i]; });
-  float* __restrict__ dst = lo + ((long)(n * Clo + l) * Hlo + M * ty) * Wlo + M * tx;
+  ET* __restrict__ dst = lo + ((long)(n * Clo + l) * Hlo + M * ty) * Wlo + M * tx;
 #pragma unroll
   for (int a = 0; a < M; ++a) {
-    if constexpr (M == 2) *reinterpret_cast<float2*>(dst + (long)a * Wlo) = make_float2(y[a][0], y[a][1]);
-    else *reinterpret_cast<float4*>(dst + (long)a * Wlo) = make_float4(y[a][0], y[a][1], y[a][2], y[a][3]);
+    if constexpr (M == 2) st2(dst + (long)a * Wlo, make_float2(y[a][0], y[a][1]));
+    else st4(dst + (long)a * Wlo, make_float4(y[a][0], y[a][1], y[a][2], y[a][3]));
   }
 }
 
 // adjoint of wino_out: lo (N,Clo,Hlo,Wlo) -> Mt[N*N][Clo][T]:  Mt = A Y A^T
-template <typename WV, bool SPLIT = false>
-__global__ __launch_bounds__(256) void wino_out_t_kernel(const float* __restrict__ lo, void* __restrict__ Mt, int Clo,
+template <typename WV, bool SPLIT = false, typename ET = float>
+__global__ __launch_bounds__(256) void wino_out_t_kernel(const ET* __restrict__ lo, void* __restrict__ Mt, int Clo,
                                                          int Hlo, int Wlo, long T, int planes = 3) {
   constexpr int N = WV::N, M = WV::M;
   const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
   int l, n, tl;
   if (!tile_of_thread(Clo, Timg, T, l, n, tl)) return;
   const int ty = tl / TW, tx = tl - ty * TW;
-  const float* __restrict__ src = lo + ((long)(n * Clo + l) * Hlo + M * ty) * Wlo + M * tx;
+  const ET* __restrict__ src = lo + ((long)(n * Clo + l) * Hlo + M * ty) * Wlo + M * tx;
   float y[M][M], m[N][N];
 #pragma unroll
   for (int a = 0; a < M; ++a) {
     if constexpr (M == 2) {
-      const float2 v = *reinterpret_cast<const float2*>(src + (long)a * Wlo);
+      const float2 v = ld2(src + (long)a * Wlo);
       y[a][0] = v.x; y[a][1] = v.y;
     } else {
-      const float4 v = *reinterpret_cast<const float4*>(src + (long)a * Wlo);
+      const float4 v = ld4(src + (long)a * Wlo);
       y[a][0] = v.x; y[a][1] = v.y; y[a][2] = v.z; y[a][3] = v.w;
     }
   }
@@ -524,22 +532,37 @@ int wino_in(int variant, const float* hi, float* V, int NB, int Chi, int Hlo, in
   WFAE_WINO_DISPATCH(wino_in_kernel, flat_grid(NB, Chi, Hlo, Wlo, M), hi, (void*)V, Chi, Hlo, Wlo, T);
   return check_launch("wino_in");
 }
-// the *_split forms write the three bf16 planes of splitgemm.hip (plane stride = the operand's element count)
-int wino_in_split(int variant, const float* hi, unsigned short* V3, int planes, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
+// the *_split forms write the three bf16 planes of splitgemm.hip (plane stride = the operand's element count); the tensor
+// they read is fp32 or, in the bf16-storage mode, bf16
+template <typename T>
+static int wino_in_split_t(int variant, const T* hi, unsigned short* V3, int planes, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
   const int M = variant ? 4 : 2;
-  const long T = (long)NB * (Hlo / M) * (Wlo / M);
+  const long T_ = (long)NB * (Hlo / M) * (Wlo / M);
   const dim3 grid = flat_grid(NB, Chi, Hlo, Wlo, M);
-  if (variant == 0) hipLaunchKernelGGL((wino_in_kernel<W22, true>), grid, dim3(256), 0, st, hi, (void*)V3, Chi, Hlo, Wlo, T, planes);
-  else hipLaunchKernelGGL((wino_in_kernel<W42, true>), grid, dim3(256), 0, st, hi, (void*)V3, Chi, Hlo, Wlo, T, planes);
+  if (variant == 0) hipLaunchKernelGGL((wino_in_kernel<W22, true, T>), grid, dim3(256), 0, st, hi, (void*)V3, Chi, Hlo, Wlo, T_, planes);
+  else hipLaunchKernelGGL((wino_in_kernel<W42, true, T>), grid, dim3(256), 0, st, hi, (void*)V3, Chi, Hlo, Wlo, T_, planes);
   return check_launch("wino_in_split");
 }
-int wino_out_t_split(int variant, const float* lo, unsigned short* Mt3, int planes, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
+int wino_in_split(int variant, const float* hi, unsigned short* V3, int planes, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
+  return wino_in_split_t(variant, hi, V3, planes, NB, Chi, Hlo, Wlo, st);
+}
+int wino_in_split(int variant, const unsigned short* hi, unsigned short* V3, int planes, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
+  return wino_in_split_t(variant, hi, V3, planes, NB, Chi, Hlo, Wlo, st);
+}
+template <typename T>
+static int wino_out_t_split_t(int variant, const T* lo, unsigned short* Mt3, int planes, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
   const int M = variant ? 4 : 2;
-  const long T = (long)NB * (Hlo / M) * (Wlo / M);
+  const long T_ = (long)NB * (Hlo / M) * (Wlo / M);
   const dim3 grid = flat_grid(NB, Clo, Hlo, Wlo, M);
-  if (variant == 0) hipLaunchKernelGGL((wino_out_t_kernel<W22, true>), grid, dim3(256), 0, st, lo, (void*)Mt3, Clo, Hlo, Wlo, T, planes);
-  else hipLaunchKernelGGL((wino_out_t_kernel<W42, true>), grid, dim3(256), 0, st, lo, (void*)Mt3, Clo, Hlo, Wlo, T, planes);
+  if (variant == 0) hipLaunchKernelGGL((wino_out_t_kernel<W22, true, T>), grid, dim3(256), 0, st, lo, (void*)Mt3, Clo, Hlo, Wlo, T_, planes);
+  else hipLaunchKernelGGL((wino_out_t_kernel<W42, true, T>), grid, dim3(256), 0, st, lo, (void*)Mt3, Clo, Hlo, Wlo, T_, planes);
   return check_launch("wino_out_t_split");
+}
+int wino_out_t_split(int variant, const float* lo, unsigned short* Mt3, int planes, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
+  return wino_out_t_split_t(variant, lo, Mt3, planes, NB, Clo, Hlo, Wlo, st);
+}
+int wino_out_t_split(int variant, const unsigned short* lo, unsigned short* Mt3, int planes, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
+  return wino_out_t_split_t(variant, lo, Mt3, planes, NB, Clo, Hlo, Wlo, st);
 }
 // U3 [3][N*N][Clo][4Chi] and its transpose Ut3 [3][N*N][4Chi][Clo]
 int wino_weights_split(int variant, const float* w, unsigned short* U3, unsigned short* Ut3, int planes, int Clo, int Chi,
@@ -554,33 +577,59 @@ int wino_weights_split(int variant, const float* w, unsigned short* U3, unsigned
   }
   return check_launch("wino_weights_split");
 }
-int wino_in_t(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
+template <typename T>
+static int wino_in_t_t(int variant, const float* dV, T* hi, int NB, int Chi, int Hlo, int Wlo, double* part, hipStream_t st) {
   const int M = variant ? 4 : 2;
-  const long T = (long)NB * (Hlo / M) * (Wlo / M);
-  WFAE_WINO_DISPATCH(wino_in_t_kernel, flat_grid(NB, Chi, Hlo, Wlo, M), dV, hi, Chi, Hlo, Wlo, T, (double*)nullptr);
+  const long T_ = (long)NB * (Hlo / M) * (Wlo / M);
+  if (part) {
+    const dim3 grid = tile_grid(NB, Chi, Hlo, Wlo, M);
+    if (variant == 0) hipLaunchKernelGGL((wino_in_t_kernel<W22, true, T>), grid, dim3(256), 0, st, dV, hi, Chi, Hlo, Wlo, T_, part);
+    else hipLaunchKernelGGL((wino_in_t_kernel<W42, true, T>), grid, dim3(256), 0, st, dV, hi, Chi, Hlo, Wlo, T_, part);
+    return check_launch("wino_in_t_stats");
+  }
+  const dim3 grid = flat_grid(NB, Chi, Hlo, Wlo, M);
+  if (variant == 0) hipLaunchKernelGGL((wino_in_t_kernel<W22, false, T>), grid, dim3(256), 0, st, dV, hi, Chi, Hlo, Wlo, T_, (double*)nullptr);
+  else hipLaunchKernelGGL((wino_in_t_kernel<W42, false, T>), grid, dim3(256), 0, st, dV, hi, Chi, Hlo, Wlo, T_, (double*)nullptr);
   return check_launch("wino_in_t");
 }
-int wino_in_t_stats(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, double* part, hipStream_t st) {
-  const int M = variant ? 4 : 2;
-  const long T = (long)NB * (Hlo / M) * (Wlo / M);
-  const dim3 grid = tile_grid(NB, Chi, Hlo, Wlo, M);
-  if (variant == 0) hipLaunchKernelGGL((wino_in_t_kernel<W22, true>), grid, dim3(256), 0, st, dV, hi, Chi, Hlo, Wlo, T, part);
-  else hipLaunchKernelGGL((wino_in_t_kernel<W42, true>), grid, dim3(256), 0, st, dV, hi, Chi, Hlo, Wlo, T, part);
-  return check_launch("wino_in_t_stats");
+int wino_in_t(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
+  return wino_in_t_t(variant, dV, hi, NB, Chi, Hlo, Wlo, nullptr, st);
 }
-int wino_out(int variant, const float* Mx, float* lo, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
+int wino_in_t(int variant, const float* dV, unsigned short* hi, int NB, int Chi, int Hlo, int Wlo, hipStream_t st) {
+  return wino_in_t_t(variant, dV, hi, NB, Chi, Hlo, Wlo, nullptr, st);
+}
+int wino_in_t_stats(int variant, const float* dV, float* hi, int NB, int Chi, int Hlo, int Wlo, double* part, hipStream_t st) {
+  return wino_in_t_t(variant, dV, hi, NB, Chi, Hlo, Wlo, part, st);
+}
+int wino_in_t_stats(int variant, const float* dV, unsigned short* hi, int NB, int Chi, int Hlo, int Wlo, double* part, hipStream_t st) {
+  return wino_in_t_t(variant, dV, hi, NB, Chi, Hlo, Wlo, part, st);
+}
+template <typename T>
+static int wino_out_tt(int variant, const float* Mx, T* lo, int NB, int Clo, int Hlo, int Wlo, double* part, hipStream_t st) {
   const int M = variant ? 4 : 2;
-  const long T = (long)NB * (Hlo / M) * (Wlo / M);
-  WFAE_WINO_DISPATCH(wino_out_kernel, flat_grid(NB, Clo, Hlo, Wlo, M), Mx, lo, Clo, Hlo, Wlo, T, (double*)nullptr);
+  const long T_ = (long)NB * (Hlo / M) * (Wlo / M);
+  if (part) {
+    const dim3 grid = tile_grid(NB, Clo, Hlo, Wlo, M);
+    if (variant == 0) hipLaunchKernelGGL((wino_out_kernel<W22, true, T>), grid, dim3(256), 0, st, Mx, lo, Clo, Hlo, Wlo, T_, part);
+    else hipLaunchKernelGGL((wino_out_kernel<W42, true, T>), grid, dim3(256), 0, st, Mx, lo, Clo, Hlo, Wlo, T_, part);
+    return check_launch("wino_out_stats");
+  }
+  const dim3 grid = flat_grid(NB, Clo, Hlo, Wlo, M);
+  if (variant == 0) hipLaunchKernelGGL((wino_out_kernel<W22, false, T>), grid, dim3(256), 0, st, Mx, lo, Clo, Hlo, Wlo, T_, (double*)nullptr);
+  else hipLaunchKernelGGL((wino_out_kernel<W42, false, T>), grid, dim3(256), 0, st, Mx, lo, Clo, Hlo, Wlo, T_, (double*)nullptr);
   return check_launch("wino_out");
 }
+int wino_out(int variant, const float* Mx, float* lo, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
+  return wino_out_tt(variant, Mx, lo, NB, Clo, Hlo, Wlo, nullptr, st);
+}
+int wino_out(int variant, const float* Mx, unsigned short* lo, int NB, int Clo, int Hlo, int Wlo, hipStream_t st) {
+  return wino_out_tt(variant, Mx, lo, NB, Clo, Hlo, Wlo, nullptr, st);
+}
 int wino_out_stats(int variant, const float* Mx, float* lo, int NB, int Clo, int Hlo, int Wlo, double* part, hipStream_t st) {
-  const int M = variant ? 4 : 2;
-  const long T = (long)NB * (Hlo / M) * (Wlo / M);
-  const dim3 grid = tile_grid(NB, Clo, Hlo, Wlo, M);
-  if (variant == 0) hipLaunchKernelGGL((wino_out_kernel<W22, true>), grid, dim3(256), 0, st, Mx, lo, Clo, Hlo, Wlo, T, part);
-  else hipLaunchKernelGGL((wino_out_kernel<W42, true>), grid, dim3(256), 0, st, Mx, lo, Clo, Hlo, Wlo, T, part);
-  return check_launch("wino_out_stats");
+  return wino_out_tt(variant, Mx, lo, NB, Clo, Hlo, Wlo, part, st);
+}
+int wino_out_stats(int variant, const float* Mx, unsigned short* lo, int NB, int Clo, int Hlo, int Wlo, double* part, hipStream_t st) {
+  return wino_out_tt(variant, Mx, lo, NB, Clo, Hlo, Wlo, part, st);
 }
 int wino_out_stat_splits(int variant, int NB, int Hlo, int Wlo) {
   const int M = variant ? 4 : 2;

@@ -134,7 +134,7 @@ def _wgrad(fn, *tensors):
     with torch.cuda.stream(side):
         fn()
     _keep.extend(tensors)
-    _keep_bytes[0] += sum(t.numel() * 4 for t in tensors)
+    _keep_bytes[0] += sum(t.numel() * t.element_size() for t in tensors)
     if _keep_bytes[0] > _KEEP_LIMIT:
         join_side_stream()
 
@@ -216,7 +216,9 @@ def _c(t):
 # ----------------------------------------------------------- 4x4 s2 units --
 def _down_fwd(x, w):
     if w.shape[1] < 16:
-        return ops.dconv_fwd(x, w, None, 4, 2, 1, 1)
+        # the one-channel first layer reads the fp32 frame and writes the stack's activation storage type
+        out = ops.activation_dtype() if (x.dtype == torch.float32 and w.shape[1] == 1) else torch.float32
+        return ops.dconv_fwd(x, w, None, 4, 2, 1, 1, out_dtype=out)
     return ops.conv4x4s2_down(x, w)
 
 
@@ -244,9 +246,9 @@ def _down_forward(x, w, stats=False):
         return (_down_fwd(x, w), None, None, None) + ((None,) if stats else ())
     U, V = ops.wino_weights(w, pl), ops.wino_in(x, pl)
     if stats:
-        t, sp = ops.wino_down(U, V, pl, stats=True)
+        t, sp = ops.wino_down(U, V, pl, stats=True, out_dtype=x.dtype)
         return t, pl, U, V, sp
-    return ops.wino_down(U, V, pl), pl, U, V
+    return ops.wino_down(U, V, pl, out_dtype=x.dtype), pl, U, V
 
 
 def _down_backward(dt, x, w, pl, U, V, need_dx, need_dw):
@@ -264,7 +266,7 @@ def _down_backward(dt, x, w, pl, U, V, need_dx, need_dw):
         dw = grad_buffer(w)
         _wgrad(lambda: ops.wino_wgrad(Mt, V, dw, pl), Mt, V)
     if need_dx:
-        dx = ops.wino_up(U, Mt, pl)
+        dx = ops.wino_up(U, Mt, pl, out_dtype=x.dtype)
     return dx, dw
 
 
@@ -307,14 +309,15 @@ class UpUnitFn(Function):
         pl = ops.wino_plan(x.shape[0], w.shape[1], w.shape[0], x.shape[2], x.shape[3])
         U = Mt = None
         sp = None
+        act_dt = ops.activation_dtype() if x.dtype == torch.float32 else x.dtype   # dec[1] reads the fp32 latent projection
         if pl is not None:
             U, Mt = ops.wino_weights(w, pl), ops.wino_out_t(x, pl)
             if training and PRODUCER_STATS:
-                t, sp = ops.wino_up(U, Mt, pl, stats=True)
+                t, sp = ops.wino_up(U, Mt, pl, stats=True, out_dtype=act_dt)
             else:
-                t = ops.wino_up(U, Mt, pl)
+                t = ops.wino_up(U, Mt, pl, out_dtype=act_dt)
         else:
-            t = ops.conv4x4s2_up(x, w)
+            t = ops.to_dtype(ops.conv4x4s2_up(x, w), act_dt)
         st = _bn_stats_rows(sp, t, bn, training)
         if training and PRODUCER_STATS:
             a, bn._out_stats = ops.bn_act_fwd_stats(t, st, 1)
@@ -335,10 +338,10 @@ class UpUnitFn(Function):
         if pl is not None:
             V = ops.wino_in(dt, pl)                                  # the hi-side tensor of this layer is dt
             _wgrad(lambda: ops.wino_wgrad(Mt, V, dw, pl), Mt, V)     # lo = x (Mt kept from forward), hi = dt
-            dx = ops.wino_down(U, V, pl) if ctx.needs_input_grad[0] else None
+            dx = ops.wino_down(U, V, pl, out_dtype=x.dtype) if ctx.needs_input_grad[0] else None
         else:
             _wgrad(lambda: ops.conv4x4s2_wgrad(x, dt, dw), x, dt)    # lo = x, hi = dt
-            dx = ops.conv4x4s2_down(dt, w) if ctx.needs_input_grad[0] else None
+            dx = ops.to_dtype(ops.conv4x4s2_down(dt, w), x.dtype) if ctx.needs_input_grad[0] else None
         return dx, dw, dg, db, None
 
 
@@ -679,7 +682,10 @@ class Conv1x1Fn(Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, pos):
-        x = _c(x)
+        # the latent projections (enc[4], dec[0]) are fp32 layers: in the bf16-storage mode the (small) neighbouring
+        # activation is converted at this boundary, the result is fp32
+        ctx.x_dtype = x.dtype
+        x = ops.to_f32(_c(x))
         y = ops.conv1x1_fwd(x, w, bias, None if pos is None else _c(pos), pos is not None)
         ctx.save_for_backward(x, w)
         ctx.bias, ctx.pos = bias, pos
@@ -688,11 +694,11 @@ class Conv1x1Fn(Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        dy = _c(dy)
+        dy = ops.to_f32(_c(dy))
         nb, cout, h, wd = dy.shape
         dw = grad_buffer(w)
         ops.conv1x1_bwd_weight(dy, x, dw)
-        dx = ops.conv1x1_bwd_data(dy, w) if ctx.needs_input_grad[0] else None
+        dx = ops.to_dtype(ops.conv1x1_bwd_data(dy, w), ctx.x_dtype) if ctx.needs_input_grad[0] else None
         dbias = dpos = None
         if ctx.bias is not None:
             dbias = grad_buffer(ctx.bias)
@@ -748,7 +754,7 @@ class DConvFn(Function):
         dy = _c(dy)
         dw = grad_buffer(w)
         ops.dconv_bwd_weight(dy, x, dw, 3, 1, 1, ctx.groups)
-        dx = ops.dconv_bwd_data(dy, w, x.shape[1], 3, 1, ctx.groups) if ctx.needs_input_grad[0] else None
+        dx = ops.dconv_bwd_data(dy, w, x.shape[1], 3, 1, ctx.groups, out_dtype=x.dtype) if ctx.needs_input_grad[0] else None
         dbias = None
         if ctx.bias is not None:
             nb, cout, h, wd = dy.shape

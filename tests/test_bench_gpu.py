@@ -40,7 +40,13 @@ def test_bench_json_contract(dev):
     ts = ro["traffic_source"]
     assert ts is None or (ts["stale"] == (ro["traffic"] is None) or ro["traffic"] is None)
     sr = d["step_roofline"]
-    assert 0 < sr["executed_flops_fraction"] < sr["fp32_fraction"] * 1.0001
+    # ideal_ms = sum over launches of max(bytes / HBM peak, FLOPs / peak of that launch's matrix instruction): a lower
+    # bound of the step, recomputable from the per-entry-point rows
+    assert 0 < sr["ideal_ms"] < d["ms_per_step"] and abs(sr["achieved"] - sr["ideal_ms"] / d["ms_per_step"]) < 1e-9
+    assert sr["ideal_ms"] >= sum(k["ideal_ms_per_step"] for k in d["kernel_breakdown"]) * 0.999
+    assert 0 < sr["hbm_fraction"] < 1 and "compute_path" in d
+    assert "hbm_bytes_source" not in sr or (sr["hbm_bytes_source"]["stale"] == (sr["hbm_bytes_per_step_measured"] is None)
+                                             or sr["hbm_bytes_per_step_measured"] is None)
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "warm" in cb["sample"]
 

@@ -93,6 +93,16 @@ for key, e in (("bn_act_bwd_dx_kernel", "wfae_bn_act_bwd[dx]"), ("bn_act_bwd_red
                   "launches": n, "source": f"profiles/{tag}_pmc_hbm_traffic_per_kernel.csv"}
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (kernel_source_tag)
+# whole-step HBM bytes (bench.py step_roofline.hbm_bytes_per_step_measured): all launches of the PMC run, which times
+# `steps` steps after `warmup` untimed ones (2 in total); the 2 x FETCH bound and the raw counters side by side
+nsteps = 2
+out["_step_total"] = {"bytes_2xfetch_plus_write": (2 * sum(v[1] for v in F.values()) + sum(v[1] for v in W.values())) * 1024 / nsteps,
+                      "bytes_raw_fetch_plus_write": (sum(v[1] for v in F.values()) + sum(v[1] for v in W.values())) * 1024 / nsteps,
+                      "steps_in_run": nsteps}
+if os.path.exists("profiles/pmc_traffic.json"):   # keep the bf16-storage total measured by tools/make_profiles_medium.py
+    old = json.load(open("profiles/pmc_traffic.json"))
+    if "_step_total_bf16" in old and old.get("_kernel_source_tag") == bench.kernel_source_tag():
+        out["_step_total_bf16"] = old["_step_total_bf16"]
 out["_kernel_source_tag"] = bench.kernel_source_tag()
 out["_source"] = f"{tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 1"
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)

@@ -180,7 +180,6 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
 }
 
 // Conv2d(C, 1, 3, padding=1): the decoder's full-resolution output convolution (c1conv.hip)
-int c1conv3_fwd(const float* x, const float* w, const float* bias, float* y, int NB, int C, int H, int W, hipStream_t st);
 int c1_wgrad_mfma(int flip, const float* big, const float* small, float* dw, int NB, int C, int H, int W, int accumulate,
                   void* ws, size_t ws_bytes, hipStream_t st);   // dconv.hip: weight gradients with one channel count = 1
 int c1_wgrad_mfma(int flip, const unsigned short* big, const float* small, float* dw, int NB, int C, int H, int W, int accumulate,

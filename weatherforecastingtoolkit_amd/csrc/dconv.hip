@@ -360,14 +360,6 @@ int wfae_dconv_fwd(const float* x, const float* w, const float* bias, float* y, 
                    Cout % groups == 0,
                WFAE_ERR_BAD_SHAPE, "dconv_fwd: bad shape");
   WFAE_REQUIRE(NB <= 65535, WFAE_ERR_BAD_SHAPE, "dconv_fwd: batch > 65535");
-  {
-    // A/B: the dedicated one-output-channel forward kernel (c1conv.hip) measured 2.4 ms against 1.3 ms for the
-    // generic LDS-patch kernel at 128 -> 1 @ 384^2, B = 32; it stays opt-in.  Its weight-gradient sibling is the
-    // default (1.4 ms against 3.9 ms).
-    static const int use_c1 = getenv("WFAE_C1_FWD") ? atoi(getenv("WFAE_C1_FWD")) : 0;
-    if (use_c1 && KS == 3 && stride == 1 && pad == 1 && groups == 1 && Cout == 1 && Cin >= 16)
-      return c1conv3_fwd(x, w, bias, y, NB, Cin, H, W, (hipStream_t)stream);
-  }
   if (Cin == 1 && groups == 1 && KS == 4 && stride == 2 && pad == 1 && !(H & 1) && !(W & 1)) {
     const int rc = launch_c1in_conv<4, 2, false, float>(x, w, bias, y, NB, Cout, H, W, H / 2, W / 2, 1, (hipStream_t)stream);
     if (rc != WFAE_ERR_UNSUPPORTED) return rc;

@@ -56,12 +56,9 @@ __device__ __forceinline__ unsigned off_tr(int k, int ch) {
   return (unsigned)(k * 256 + ((ch ^ (((k & 3) << 2) | ((k >> 2) & 3))) << 4));
 }
 
-// DMA: operand tiles go from global memory straight into the LDS stage (global_load_lds_dwordx4: no staging registers, no
-// ds_write instructions); a wave-instruction fills 1 KiB of LDS lane-linearly, so every lane loads the 16-byte chunk that
-// the swizzled image keeps at its position.
-template <int BKIND, int DBG = 0, bool DMA = false, int NP = 3>
+template <int BKIND, int NP = 3>
 __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
-  static_assert(NP == 3 || (NP == 1 && !DMA && DBG == 0), "one plane: register-staged loader only");
+  static_assert(NP == 3 || NP == 1, "three exact planes or the h plane alone");
   constexpr int A_STAGE_B = NP * A_PLANE_B;
   constexpr int STAGE_B = NP * (A_PLANE_B + B_PLANE_B);
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B];
@@ -210,97 +207,6 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
       for (int j = 0; j < 2; ++j) mfma_tile(f, i, j);
   };
 
-  if constexpr (DMA) {
-    // this wave's share of a stage: A row groups 2w, 2w+1 (16 rows each), B k-rows 4w..4w+3 (or rows 16w..16w+15)
-    const int rl = lane >> 2, cl = lane & 3;
-    const unsigned short* d_a[2];
-#pragma unroll
-    for (int g2 = 0; g2 < 2; ++g2) {
-      const int row = (2 * wave + g2) * 16 + rl;
-      d_a[g2] = Ab + (long)min(m0 + row, p.M - 1) * p.lda + k_begin + (cl ^ ((row >> 2) & 3)) * 8;
-    }
-    const unsigned short* d_b;
-    long d_bstep;
-    if constexpr (BKIND == 0) {
-      const int k = 4 * wave + (lane >> 4);
-      int n = n0 + (((lane & 15) ^ (((k & 3) << 2) | ((k >> 2) & 3))) << 3);
-      if (n >= p.N) n = p.N - 8;
-      d_b = Bb + (long)(k_begin + k) * p.ldb + n;
-      d_bstep = (long)SBK * p.ldb;
-    } else {
-      const int row = 16 * wave + rl;
-      d_b = Bb + (long)min(n0 + row, p.N - 1) * p.ldb + k_begin + (cl ^ ((row >> 2) & 3)) * 8;
-      d_bstep = SBK;
-    }
-    // The instruction is issued through inline assembly on purpose: behind __builtin_amdgcn_global_load_lds the compiler
-    // cannot tell which LDS bytes the transfer writes and puts s_waitcnt vmcnt(0) in front of the next ds_read — a full
-    // memory latency per K-step in the issuing wave.  The waits that ARE needed stand in the loop below, by hand.
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
-    auto dma16 = [&](const unsigned short* g, unsigned lds_addr) {
-      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(g) : "memory");
-    };
-    auto dma_plane = [&](int buf, int pl) {   // one plane of this wave's share: 2 A pieces + 1 B piece of 1 KiB
-      const unsigned s = lds0 + (unsigned)buf * STAGE_B;
-      dma16(d_a[0] + pl * p.a_plane, s + pl * A_PLANE_B + (2 * wave_u) * 1024);
-      dma16(d_a[1] + pl * p.a_plane, s + pl * A_PLANE_B + (2 * wave_u + 1) * 1024);
-      dma16(d_b + pl * p.b_plane, s + A_STAGE_B + pl * B_PLANE_B + wave_u * 1024);
-    };
-    auto dma_stage = [&](int buf) {
-#pragma unroll
-      for (int pl = 0; pl < NP; ++pl) dma_plane(buf, pl);
-    };
-    auto dma_advance = [&](bool more) {
-      d_a[0] += more ? SBK : 0;
-      d_a[1] += more ? SBK : 0;
-      d_b += more ? d_bstep : 0;
-    };
-    if (nsteps > 0) {
-      Frag f0, f1;
-      dma_stage(0);
-      dma_advance(nsteps > 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      dma_stage(1);   // K-step 1 (K-step 0 again when there is only one: lands in the stage nobody reads)
-      dma_advance(nsteps > 2);
-      read_frag(f0, 0, 0);
-      for (int st = 0; st < nsteps; ++st) {
-        const int cur = st & 1;
-        read_frag(f1, cur, 1);
-        mfma_frag(f0);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of K-step st + 1 has landed
-        __syncthreads();                                    // ... everybody's has, and nobody reads stage cur any more
-        __builtin_amdgcn_sched_barrier(0);
-        // K-step st + 2 (a repeat of the last one past the end) goes into the stage just vacated, one plane (3 KiB per
-        // wave) after each of the first three MFMA tiles: issued as one burst the nine transfers of all eight waves sit
-        // in the texture unit's queue while the matrix pipe idles (a wave issues in order)
-        read_frag(f0, cur ^ 1, 0);
-        mfma_tile(f1, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        dma_plane(cur, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_tile(f1, 0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        dma_plane(cur, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_tile(f1, 1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        dma_plane(cur, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_tile(f1, 1, 1);
-        dma_advance(st + 3 < nsteps);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the block ends
-    }
-  } else
   // Software pipeline, one barrier per K-step in the MIDDLE of the iteration:
   //   first half : MFMAs of k-slab 0 (fragments F0, read during the previous iteration) while this wave reads the
   //                fragments of k-slab 1 (F1), moves the staged K-step st+1 into the idle LDS stage and issues the global
@@ -321,8 +227,8 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
     for (int st = 0; st < nsteps; ++st) {
       const int cur = st & 1;
       read_frag(f1, cur, 1);
-      if constexpr (!(DBG & 2)) store_lds(cur ^ 1);   // K-step st + 1; in the last iteration a stale copy nobody reads
-      if constexpr (!(DBG & 1)) load_global();        // K-step st + 2
+      store_lds(cur ^ 1);   // K-step st + 1; in the last iteration a stale copy nobody reads
+      load_global();        // K-step st + 2
       advance(st + 3 < nsteps);
       mfma_frag(f0);
 #pragma unroll
@@ -335,7 +241,7 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the k-slab-1 MFMAs behind the barrier: they are what hides the F0 reads
-      if constexpr (!(DBG & 4)) __syncthreads();
+      __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
       read_frag(f0, cur ^ 1, 0);
       mfma_frag(f1);
@@ -380,22 +286,10 @@ int launch_sgemm3(SgP& p, int planes, int batches, int splits, hipStream_t st, c
   p.mtiles = cdiv(p.M, SBM);
   const long tiles = (long)p.mtiles * cdiv(p.N, SBN);
   WFAE_REQUIRE(tiles < (1l << 31) && batches <= 65535 && splits <= 65535, WFAE_ERR_BAD_SHAPE, "%s: grid too large", what);
-  // WFAE_SPLIT_DMA=1: operand tiles by LDS-DMA instead of register staging.  Measured equal on the Winograd shapes (28.96
-  // vs 28.57 ms over tools/kbench.py --only wino): with the loads spread between the MFMAs neither the staging registers
-  // nor the ds_write instructions are what the kernel waits for — PMC: matrix pipe busy 0.59 at a clock of 1.67 GHz
-  // (the fp32 MFMA GEMM: 0.75 at 2.11 GHz; the chip gives clock back under bf16 MFMA load).
-  static const int dma = getenv("WFAE_SPLIT_DMA") ? atoi(getenv("WFAE_SPLIT_DMA")) : 0;
-  if (planes == 1) {
-    hipLaunchKernelGGL((sgemm3_kernel<BKIND, 0, false, 1>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
-    return check_launch(what);
-  }
-  static const int dbg = getenv("WFAE_SPLIT_DBG") ? atoi(getenv("WFAE_SPLIT_DBG")) : 0;   // timing probes, wrong results
-  if (dbg == 1) hipLaunchKernelGGL((sgemm3_kernel<BKIND, 1>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
-  else if (dbg == 3) hipLaunchKernelGGL((sgemm3_kernel<BKIND, 3>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
-  else if (dbg == 7) hipLaunchKernelGGL((sgemm3_kernel<BKIND, 7>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
-  else if (dma) hipLaunchKernelGGL((sgemm3_kernel<BKIND, 0, true>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
-  else
-  hipLaunchKernelGGL((sgemm3_kernel<BKIND>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
+  // (An LDS-DMA form of the loaders — global_load_lds_dwordx4, no staging registers or ds_write — measured equal on the
+  // Winograd shapes in round 2, 28.96 vs 28.57 ms, and was removed: the operand path is not what the waves wait for.)
+  if (planes == 1) hipLaunchKernelGGL((sgemm3_kernel<BKIND, 1>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
+  else hipLaunchKernelGGL((sgemm3_kernel<BKIND, 3>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
   return check_launch(what);
 }
 

@@ -57,14 +57,14 @@ STAT_FUSION = os.environ.get("WFAE_STAT_FUSION", "1") == "1"
 # WFAE_FUSE_A1=0 restores the materialised form, WFAE_FUSE_A1_MAXC limits the fused form to that many input channels (A/B:
 # 256 -> 250.1 ms, 512 -> 249.6 ms, all -> 249.7 ms).
 FUSE_A1 = os.environ.get("WFAE_FUSE_A1", "1") == "1"
-FUSE_A1_MAXC = int(os.environ.get("WFAE_FUSE_A1_MAXC", str(1 << 30)))
+FUSE_A1_MAXC = 1 << 30
 # The same for the THIRD BatchNorm of a Bottleneck (C/4 channels -> the C/4 -> C convolution and its weight gradient; the
 # roles of that weight gradient are swapped when C/4 < 128, so the prologue sits on its A operand there).  The forward
 # GEMM re-loads (and re-activates) every element once per M tile, 1 - 8 times: measured for the whole step, fusing it
 # at every width costs 3 ms (247.4 -> 250.5 ms), at C <= 256 0.5 ms, at C <= 128 nothing — so it is limited to
 # WFAE_FUSE_A3_MAXC = 128 output channels (one M tile; -1.1 GiB).  WFAE_FUSE_A3=0: off.
 FUSE_A3 = os.environ.get("WFAE_FUSE_A3", "1") == "1"
-FUSE_A3_MAXC = int(os.environ.get("WFAE_FUSE_A3_MAXC", "128"))
+FUSE_A3_MAXC = 128
 
 
 # BatchNorm sums produced by the kernel that WRITES the tensor when that kernel is a streaming one (the Winograd output

@@ -30,26 +30,92 @@ def profile_start():
     _prof = {}
 
 
+PEAK_HBM = 8.0e12          # MI355X_MICROARCH.md
+PEAK_FP32_MFMA = 157.3e12  # v_mfma_f32_32x32x2_f32 = the fp32 vector rate
+PEAK_BF16_MFMA = 2500.0e12 # dense bf16
+
+
 def profile_stop():
-    """-> {name: (calls, total_ms, flops, bytes)}; synchronises the device."""
+    """-> {name: (calls, total_ms, flops, bytes, ideal_ms)}; synchronises the device.  ideal_ms = sum over the launches
+    of max(algorithmic bytes / HBM peak, algorithmic FLOPs / peak of the matrix instruction that launch runs on)"""
     global _prof
     rec, _prof = _prof, None
     torch.cuda.synchronize()
     out = {}
     for k, lst in (rec or {}).items():
-        ms = sum(a.elapsed_time(b) for a, b, _, _ in lst)
-        out[k] = (len(lst), ms, sum(f for _, _, f, _ in lst), sum(b for _, _, _, b in lst))
+        ms = sum(a.elapsed_time(b) for a, b, _, _, _ in lst)
+        out[k] = (len(lst), ms, sum(f for _, _, f, _, _ in lst), sum(b for _, _, _, b, _ in lst),
+                  1e3 * sum(max(b / PEAK_HBM, f / pk) for _, _, f, b, pk in lst))
     return out
 
 
-def _call(name, flops, nbytes, *args, label=None):
+def _default_peak():
+    return PEAK_BF16_MFMA if _lib.load().wfae_get_matmul_precision() == 1 else PEAK_FP32_MFMA
+
+
+def _gemm_peak(m, k):
+    """FLOP/s ceiling of the instruction a plain GEMM-family launch (1x1 / linear) runs on: bf16 operands at 'medium'; at
+    fp32 precision the exact three-plane split (six bf16 products per fp32 product) for K >= 128, M >= 64 (gemm.hip
+    launch_gemm_v), else v_mfma_f32_32x32x2_f32.  Work is counted in fp32-equivalent FLOPs."""
+    if _lib.load().wfae_get_matmul_precision() == 1:
+        return PEAK_BF16_MFMA
+    if _SPLIT_GEMM and k >= 128 and m >= 64:
+        return PEAK_BF16_MFMA / 6
+    return PEAK_FP32_MFMA
+
+
+def _call(name, flops, nbytes, *args, label=None, peak=None):
     if _prof is None:
         return _lib.call(name, *args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     _lib.call(name, *args)
     e1.record()
-    _prof.setdefault(label or name, []).append((e0, e1, flops, nbytes))
+    if peak is None:
+        fn = _PEAK_OF.get(name)
+        peak = fn(args) if fn is not None else PEAK_FP32_MFMA
+    _prof.setdefault(label or name, []).append((e0, e1, flops, nbytes, peak))
+
+
+def _planes_peak(planes):
+    return PEAK_BF16_MFMA / 6 if planes == 3 else PEAK_BF16_MFMA
+
+
+# matrix-instruction ceiling per GEMM-family entry point, from its C argument list (positions as in include/wfae.h)
+_PEAK_OF = {
+    "wfae_conv1x1_fwd": lambda a: _gemm_peak(a[8], a[7]),                 # (.., NB, Cin, Cout, HW): M = Cout, K = Cin
+    "wfae_conv1x1_fwd_stats": lambda a: _gemm_peak(a[8], a[7]),
+    "wfae_conv1x1_fwd_bnact": lambda a: _gemm_peak(a[10], a[9]),
+    "wfae_conv1x1_fwd_bf16": lambda a: PEAK_BF16_MFMA,
+    "wfae_conv1x1_bwd_data": lambda a: _gemm_peak(a[4], a[5]),            # M = Cin, K = Cout
+    "wfae_conv1x1_bwd_data_bf16": lambda a: PEAK_BF16_MFMA,
+    "wfae_conv1x1_bwd_data_bnred": lambda a: _gemm_peak(a[9], a[10]),
+    "wfae_conv1x1_bwd_data_bndx": lambda a: _gemm_peak(a[12], a[13]),
+    # weight gradients: M = Cout, or Cin when the roles are swapped (Cin < Cout and Cin < 128); K = the pixels
+    "wfae_conv1x1_bwd_weight": lambda a: _gemm_peak(a[4] if (a[4] < a[5] and a[4] < 128) else a[5], 1 << 20),
+    "wfae_conv1x1_bwd_weight_bnact": lambda a: _gemm_peak(a[6] if (a[6] < a[7] and a[6] < 128) else a[7], 1 << 20),
+    "wfae_conv1x1_bwd_weight_bf16": lambda a: PEAK_BF16_MFMA,
+    "wfae_linear_fwd": lambda a: _gemm_peak(a[6], a[5]),
+    "wfae_linear_bwd_data": lambda a: _gemm_peak(a[4], a[5]),
+    "wfae_linear_bwd_data_splitk": lambda a: _gemm_peak(a[4], a[5]),
+    "wfae_linear_bwd_weight": lambda a: _gemm_peak(a[5], a[3]),
+    "wfae_linear_bwd_weight_splitk": lambda a: _gemm_peak(a[5], a[3]),
+    "wfae_wino_gemm_down_split": lambda a: _planes_peak(a[4]),
+    "wfae_wino_gemm_up_split": lambda a: _planes_peak(a[4]),
+    "wfae_wino_gemm_wgrad_split": lambda a: _planes_peak(a[4]),
+    "wfae_wino_gemm_down": lambda a: _default_peak(),
+    "wfae_wino_gemm_up": lambda a: _default_peak(),
+    "wfae_wino_gemm_wgrad": lambda a: _default_peak(),
+    "wfae_split_gemm": lambda a: _planes_peak(a[1]),
+    "wfae_c1gemm_fwd": lambda a: PEAK_BF16_MFMA / 6,
+    "wfae_c1gemm_bnred": lambda a: PEAK_BF16_MFMA / 6,
+    "wfae_c1gemm_bndx": lambda a: PEAK_BF16_MFMA / 6,
+    "wfae_conv4x4s2_down": lambda a: _default_peak(),
+    "wfae_conv4x4s2_up": lambda a: _default_peak(),
+    "wfae_conv4x4s2_wgrad": lambda a: _default_peak(),
+    "wfae_conv4x4s1_fwd": lambda a: _gemm_peak(a[5], 16 * a[4]),
+    "wfae_conv4x4s1_bwd_weight": lambda a: _gemm_peak(a[5], 1 << 20),
+}
 
 
 def workspace(min_bytes: int = 0):

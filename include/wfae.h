@@ -337,6 +337,18 @@ int wfae_wino_out_bf16(int variant, const float* M, uint16_t* lo, int NB, int Cl
                        int64_t part_capacity, int* splits_out, wfae_stream_t stream);
 int wfae_wino_in_t_bf16(int variant, const float* dV, uint16_t* hi, int NB, int Chi, int Hlo, int Wlo, double* part,
                         int64_t part_capacity, int* splits_out, wfae_stream_t stream);
+/* The Bottleneck's 1x1 convolutions on bf16-stored activations without a format change between HBM and the matrix core
+ * (csrc/c1b.hip): y (bf16) = W f(x) (+ res), W one bf16 plane.  c1b_weights: w (Cout,Cin) fp32 -> Wb [Cout][Cin] and Wtb
+ * [Cin][Cout] bf16 (the forward passes Wb with (M, K) = (Cout, Cin), the data gradient Wtb with (M, K) = (Cin, Cout)).
+ * c1b_fwd: pro_scale / pro_shift [K] non-null = the BatchNorm + GELU prologue; stat_part non-null = BatchNorm sums of the
+ * rounded y as *stat_rows rows, sum[rows][M] then sumsq[rows][M], rows = wfae_c1b_stat_rows(M, K, NB, HW), finish with
+ * wfae_bn_stats_from_rows.  Served: M % 32 == 0, K % 32 == 0, HW % 8 == 0 (wfae_c1b_supported), WFAE_PRECISION_BF16 arithmetic. */
+int wfae_c1b_supported(int M, int K, int HW);
+int wfae_c1b_stat_rows(int M, int K, int NB, int HW);
+int wfae_c1b_weights(const float* w, uint16_t* Wb, uint16_t* Wtb, int Cout, int Cin, wfae_stream_t stream);
+int wfae_c1b_fwd(const uint16_t* Wb, const uint16_t* x, const float* pro_scale, const float* pro_shift, const uint16_t* res,
+                 uint16_t* y, int NB, int K, int M, int HW, double* stat_part, int64_t stat_capacity, int* stat_rows,
+                 wfae_stream_t stream);
 int wfae_bn_act_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* gamma, const float* scale, const float* shift,
                          const float* save_mean, const float* save_invstd, const uint16_t* res, uint16_t* dx, float* dgamma,
                          float* dbeta, int NB, int C, int HW, int act, int training, int accumulate, int phases, void* ws,

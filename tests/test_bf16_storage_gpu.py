@@ -243,3 +243,38 @@ def test_full_step_runs_in_bf16_storage_and_tracks_fp32_tensors(ops_medium, dev)
     assert all(v == torch.float32 for v in seen32.values())
     assert abs(l16[0] - l32[0]) < 5e-3 * l32[0], (l16[0], l32[0])
     assert l16[-1] < 0.9 * l16[0] and abs(l16[-1] - l32[-1]) < 0.05 * l32[-1], (l16, l32)
+
+
+@pytest.mark.parametrize("nb,k,m,h,w", [(2, 64, 256, 16, 16), (3, 128, 128, 8, 8), (2, 256, 64, 16, 16), (2, 128, 32, 8, 16),
+                                        (1, 32, 128, 8, 8), (5, 32, 64, 4, 6), (2, 1024, 256, 8, 8), (1, 64, 160, 12, 12)])
+@pytest.mark.parametrize("mode", ["plain", "res", "pro", "res+stats", "pro+res+stats"])
+def test_c1b_matches_the_fp32_image_kernels(ops_medium, dev, nb, k, m, h, w, mode):
+    """csrc/c1b.hip (bf16 values go from HBM to the matrix core without a format change) against gemm.hip's bf16-storage
+    kernels of the same arithmetic (bf16 operands, fp32 accumulation, one rounding of the result): all three tiles, one
+    K-step and many, tiles across image boundaries, column tails, M tails"""
+    ops = ops_medium
+    assert ops.c1b_supported(m, k, h * w)
+    x = rnd((nb, k, h, w), 1, -2, 2).bfloat16().to(dev)
+    res = rnd((nb, m, h, w), 2).bfloat16().to(dev) if "res" in mode else None
+    wt = (rnd((m, k, 1, 1), 3) * k ** -0.5).to(dev)
+    st = None
+    if "pro" in mode:
+        st = ops.BnStats(k, dev)
+        st.scale.copy_(rnd((k,), 5) + 1.5)
+        st.shift.copy_(rnd((k,), 6))
+    Wb, Wtb = ops.c1b_weights(wt)
+    assert torch.equal(Wb, wt.view(m, k).bfloat16()) and torch.equal(Wtb, wt.view(m, k).t().contiguous().bfloat16())
+    out = ops.c1b_fwd(Wb, x, st, res, "stats" in mode)
+    y, sr = out if "stats" in mode else (out, None)
+    ref = ops.conv1x1_fwd_bnact(x, st, wt, None, res) if st is not None else ops.conv1x1_fwd(x, wt, None, res)
+    assert y.dtype == BF and ulp_close(y, ref.float(), 5e-3)
+    if sr is not None:
+        g, b = torch.ones(m, device=dev), torch.zeros(m, device=dev)
+        s_a = ops.bn_stats_from_rows(sr, tuple(y.shape), g, b, None, None)
+        s_b = ops.bn_stats_train(y, g, b, torch.zeros(m, device=dev), torch.ones(m, device=dev))
+        assert relerr(s_a.mean, s_b.mean) < 2e-6 and relerr(s_a.invstd, s_b.invstd) < 2e-6
+    # the data gradient is the same product with the transposed plane
+    dy = rnd((nb, m, h, w), 7).bfloat16().to(dev)
+    if ops.c1b_supported(k, m, h * w):
+        dx = ops.c1b_fwd(Wtb, dy)
+        assert ulp_close(dx, ops.conv1x1_bwd_data(dy, wt).float(), 5e-3)

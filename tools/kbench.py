@@ -183,6 +183,36 @@ def main():
                 report(f"c1 @{h} {tag}", ms, f_, b2)
                 acc(key, ms, mult)
             del x, t2, w1, w3, W1, W1t, W3, W3t
+    if "c1b" in only:
+        # bf16 storage ('medium'): csrc/c1b.hip against gemm.hip's bf16-storage kernels, per Bottleneck stage
+        ops.set_float32_matmul_precision("medium")
+        bf = torch.bfloat16
+        for c, h in stages[:4] + stages[7:]:
+            mult = 4 if c == 128 or h == S // 16 else 8
+            mid = c // 4
+            n = B * h * h
+            x, t2 = rnd(B, c, h, h).to(bf), rnd(B, mid, h, h).to(bf)
+            w1, w3 = rnd(mid, c, 1, 1) * c ** -0.5, rnd(c, mid, 1, 1) * mid ** -0.5
+            g, b_, rm, rv = torch.ones(c, device=dev), torch.zeros(c, device=dev), torch.zeros(c, device=dev), torch.ones(c, device=dev)
+            st = ops.bn_stats_train(x, g, b_, rm, rv)
+            W1, W1t = ops.c1b_weights(w1)
+            W3, W3t = ops.c1b_weights(w3)
+            fl = 2 * n * c * mid
+            by1, by3 = 2 * n * (c + mid), 2 * n * (c + mid) + 2 * n * c
+            rows = [(f"fwd  {c}->{mid} bnact gemm.hip", lambda: ops.conv1x1_fwd_bnact(x, st, w1), fl, by1, "fwd1_gemm"),
+                    (f"fwd  {c}->{mid} bnact c1b", lambda: ops.c1b_fwd(W1, x, st), fl, by1, "fwd1_c1b"),
+                    (f"dgrad {c}->{mid} (da3) gemm.hip", lambda: ops.conv1x1_bwd_data(x, w3), fl, by1, "dgrad3_gemm"),
+                    (f"dgrad {c}->{mid} (da3) c1b", lambda: ops.c1b_fwd(W3t, x), fl, by1, "dgrad3_c1b"),
+                    (f"fwd  {mid}->{c} +res gemm.hip", lambda: ops.conv1x1_fwd(t2, w3, None, x), fl, by3, "fwd3_gemm"),
+                    (f"fwd  {mid}->{c} +res c1b", lambda: ops.c1b_fwd(W3, t2, None, x), fl, by3, "fwd3_c1b"),
+                    (f"dgrad {mid}->{c} (da1) gemm.hip", lambda: ops.conv1x1_bwd_data(t2, w1), fl, by1, "dgrad1_gemm"),
+                    (f"dgrad {mid}->{c} (da1) c1b", lambda: ops.c1b_fwd(W1t, t2), fl, by1, "dgrad1_c1b")]
+            for tag, fn, f_, b2, key in rows:
+                ms = timeit(fn, R)
+                report(f"c1b @{h} {tag}", ms, f_, b2)
+                acc(key, ms, mult)
+            del x, t2, w1, w3, W1, W1t, W3, W3t
+        ops.set_float32_matmul_precision(a.precision)
     if "fuse" in only:
         # BatchNorm-apply + GELU in the GEMM loaders vs the materialised form, first BatchNorm of a Bottleneck (C -> C/4)
         for c, h in stages:

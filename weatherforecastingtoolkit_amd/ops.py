@@ -383,6 +383,49 @@ def c1gemm_supported(m, k, hw):
             and bool(_lib.load().wfae_c1gemm_supported(int(m), int(k), int(hw))))
 
 
+# ---- bf16 storage: csrc/c1b.hip (no format change between HBM and the matrix core)
+_C1B = os.environ.get("WFAE_C1B", "1") != "0"
+
+
+def c1b_supported(m, k, hw):
+    return _C1B and _lib.load().wfae_get_matmul_precision() == 1 and bool(_lib.load().wfae_c1b_supported(int(m), int(k), int(hw)))
+
+
+def c1b_weights(w):
+    """w (Cout, Cin[,1,1]) fp32 -> (Wb (Cout, Cin), Wtb (Cin, Cout)) bf16"""
+    _chk(w)
+    cout, cin = w.shape[0], w.shape[1]
+    Wb = torch.empty((cout, cin), dtype=BF16, device=w.device)
+    Wtb = torch.empty((cin, cout), dtype=BF16, device=w.device)
+    _call("wfae_c1b_weights", 0, 8 * w.numel(), _p(w), _p(Wb), _p(Wtb), cout, cin, _stream())
+    return Wb, Wtb
+
+
+def c1b_fwd(Wb, x, st=None, res=None, stats=False, label="wfae_c1b_fwd"):
+    """y (bf16) = W f(x) (+ res) on bf16-stored activations; Wb (M, K) from c1b_weights; st: BnStats folded into the
+    operand loader (BatchNorm + GELU in front of the convolution); stats=True: -> (y, StatRows of y)"""
+    import ctypes
+    sfx, _ = _chka(x, res)
+    if not sfx or Wb.dtype != BF16 or not Wb.is_contiguous() or Wb.shape[1] != x.shape[1]:
+        raise _lib.WfaeError("c1b_fwd: bf16 activations and the contiguous (M, K) bf16 weight plane of c1b_weights")
+    nb, k, h, wd = x.shape
+    m = Wb.shape[0]
+    y = torch.empty((nb, m, h, wd), dtype=BF16, device=x.device)
+    fl = 2 * nb * h * wd * k * m
+    by = 2 * nb * h * wd * (k + m) + 2 * k * m + (0 if res is None else 2 * nb * h * wd * m)
+    ps, ph = (None, None) if st is None else (_p(st.scale), _p(st.shift))
+    if not stats:
+        _call("wfae_c1b_fwd", fl, by, _p(Wb), _p(x), ps, ph, _p(res), _p(y), nb, k, m, h * wd, None, 0, None, _stream(), label=label,
+              peak=PEAK_BF16_MFMA)
+        return y
+    rows_n = int(_lib.load().wfae_c1b_stat_rows(m, k, nb, h * wd))
+    part = torch.empty(2 * rows_n * m, dtype=torch.float64, device=x.device)
+    rows = ctypes.c_int(0)
+    _call("wfae_c1b_fwd", fl, by, _p(Wb), _p(x), ps, ph, _p(res), _p(y), nb, k, m, h * wd, part.data_ptr(), part.numel(),
+          ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream(), label=label, peak=PEAK_BF16_MFMA)
+    return y, StatRows(part, rows.value)
+
+
 # c1gemm is taken for reductions K >= WFAE_C1_MIN_K.  Measured (profiles/r03_kbench_c1_fused_bn_backward.txt, tools/kbench.py
 # --only c1): in isolation it beats the round-2 kernels on the K >= 512 shapes (1024 -> 256 @48: fused-prologue forward
 # 0.376 -> 0.273 ms, data gradient 0.272 -> 0.237 ms = 163 TF fp32-equivalent; @24: 0.154 -> 0.086 ms) and loses on the short

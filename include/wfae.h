@@ -168,6 +168,17 @@ int wfae_conv1x1_bwd_data_bndx(const float* dy, const float* w, const float* x, 
                                const float* bn_shift, const float* save_mean, const float* save_invstd, const float* coef,
                                const float* res, float* dx, int NB, int Cin, int Cout, int HW, int training,
                                wfae_stream_t stream);
+/* Weight gradients of the Bottleneck's 1x1 convolutions with both operands read as K-contiguous rows (csrc/c1w.hip, ABI
+ * 102): dw (Cout,Cin) (+)= dy (NB,Cout,HW) . x'^T, x' = x or (bn_scale / bn_shift non-null) gelu(x * bn_scale[c] +
+ * bn_shift[c]) rebuilt in the loader (wfae_conv1x1_bwd_weight_bnact's prologue).  fp32 tensors: exact three-plane bf16
+ * split at the LDS store, six bf16 MFMA products per fp32 product (needs the split GEMMs on); _bf16: bf16-stored tensors,
+ * one product (needs WFAE_PRECISION_BF16).  HW % 32 == 0, channel counts % 32 == 0 (wfae_c1w_supported); ws holds the
+ * split-K slabs: up to NB * ceil(HW / 256) slabs of Cout * Cin floats (fewer when they would not fit). */
+int wfae_c1w_supported(int Cin, int Cout, int HW);
+int wfae_c1w_bwd_weight(const float* dy, const float* x, const float* bn_scale, const float* bn_shift, float* dw, int NB, int Cin,
+                        int Cout, int HW, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
+int wfae_c1w_bwd_weight_bf16(const uint16_t* dy, const uint16_t* x, const float* bn_scale, const float* bn_shift, float* dw, int NB,
+                             int Cin, int Cout, int HW, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
 /* wfae_bn_act_bwd phase 1 from partial rows a producer left (wfae_c1gemm_bnred): dgamma / dbeta and the coefficients at
  * the head of ws, exactly as phase 1 leaves them — follow with wfae_bn_act_bwd(phases = 2, same ws) or wfae_c1gemm_bndx
  * (coef = (const float*)ws). */

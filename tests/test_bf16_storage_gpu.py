@@ -278,3 +278,27 @@ def test_c1b_matches_the_fp32_image_kernels(ops_medium, dev, nb, k, m, h, w, mod
     if ops.c1b_supported(k, m, h * w):
         dx = ops.c1b_fwd(Wtb, dy)
         assert ulp_close(dx, ops.conv1x1_bwd_data(dy, wt).float(), 5e-3)
+
+
+@pytest.mark.parametrize("nb,cin,cout,h,w", [(2, 256, 64, 16, 16), (3, 64, 256, 8, 8), (2, 512, 128, 8, 8), (1, 128, 32, 16, 32),
+                                             (2, 32, 128, 8, 8)])
+@pytest.mark.parametrize("pro", [False, True])
+def test_c1w_weight_gradient_bf16(ops_medium, dev, nb, cin, cout, h, w, pro):
+    """csrc/c1w.hip on bf16-stored tensors (16-byte pieces straight into the MFMA row image) against gemm.hip's bf16-storage
+    weight gradient of the same arithmetic (bf16 operands, fp32 accumulation)"""
+    ops = ops_medium
+    dy, x = rnd((nb, cout, h, w), 1).bfloat16().to(dev), rnd((nb, cin, h, w), 2, -2, 2).bfloat16().to(dev)
+    st = None
+    if pro:
+        st = ops.BnStats(cin, dev)
+        st.scale.copy_(rnd((cin,), 5) + 1.5)
+        st.shift.copy_(rnd((cin,), 6))
+    assert ops._c1w_route(dy, x, "_bf16")
+    dw, old = torch.empty((cout, cin, 1, 1), device=dev), torch.empty((cout, cin, 1, 1), device=dev)
+    (ops.conv1x1_bwd_weight_bnact(dy, x, st, dw) if pro else ops.conv1x1_bwd_weight(dy, x, dw))
+    ops.set_c1w(False)
+    try:
+        (ops.conv1x1_bwd_weight_bnact(dy, x, st, old) if pro else ops.conv1x1_bwd_weight(dy, x, old))
+    finally:
+        ops.set_c1w(True)
+    assert relerr(dw, old) < 2e-5

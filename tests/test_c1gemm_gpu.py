@@ -190,3 +190,45 @@ def test_bottleneck_paths_agree(dev):
     for name in cfgs:
         for a, b in zip(outs[name], outs["round2"]):
             assert relerr(a, b) < 5e-5, name
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 64, 16, 16), (3, 64, 256, 8, 8), (2, 512, 128, 8, 8), (1, 128, 32, 16, 32),
+                                   (2, 32, 128, 8, 8), (4, 1024, 256, 8, 4), (2, 160, 96, 8, 8), (1, 64, 64, 40, 40)])
+@pytest.mark.parametrize("pro", [False, True])
+def test_c1w_weight_gradient_fp32(dev, shape, pro):
+    """csrc/c1w.hip (fp32 tensors, exact bf16x3 split at the LDS store, both operands as K-contiguous rows) against fp64 and
+    against gemm.hip's weight gradient: every tile shape, either operand as the wide side (transposed slab reduce), the
+    BatchNorm + GELU prologue on either side, split-K over images and pixel chunks, accumulate"""
+    from weatherforecastingtoolkit_amd import ops
+    nb, cin, cout, h, w = shape
+    gen = torch.Generator().manual_seed(11 + hash(shape) % (2 ** 31))
+    dy, x = _rnd(gen, nb, cout, h, w).to(dev), _rnd(gen, nb, cin, h, w, scale=2.0).to(dev)
+    st = None
+    xin = x.double().cpu()
+    if pro:
+        st = ops.BnStats(cin, dev)
+        st.scale.copy_(_rnd(gen, cin) + 1.5)
+        st.shift.copy_(_rnd(gen, cin))
+        xin = torch.nn.functional.gelu(xin * st.scale.double().cpu().view(1, cin, 1, 1) + st.shift.double().cpu().view(1, cin, 1, 1))
+    want = torch.einsum("nohw,nihw->oi", dy.double().cpu(), xin)
+    mag = torch.einsum("nohw,nihw->oi", dy.double().cpu().abs(), xin.abs()).max().item()
+    assert ops._c1w_route(dy, x, "")
+    dw = torch.full((cout, cin, 1, 1), 7.0, device=dev)
+    (ops.conv1x1_bwd_weight_bnact(dy, x, st, dw) if pro else ops.conv1x1_bwd_weight(dy, x, dw))
+    err = (dw.view(cout, cin).double().cpu() - want).abs().max().item() / mag
+    assert err < 3e-7, err
+    ops.set_c1w(False)
+    try:
+        old = torch.empty_like(dw)
+        (ops.conv1x1_bwd_weight_bnact(dy, x, st, old) if pro else ops.conv1x1_bwd_weight(dy, x, old))
+    finally:
+        ops.set_c1w(True)
+    assert relerr(dw, old) < 2e-5
+    # accumulate
+    acc = dw.clone()
+    (ops.conv1x1_bwd_weight_bnact(dy, x, st, acc, True) if pro else ops.conv1x1_bwd_weight(dy, x, acc, True))
+    assert relerr(acc, 2 * dw) < 1e-6
+    # bit-identical repeat (fixed-order slab reduce)
+    again = torch.empty_like(dw)
+    (ops.conv1x1_bwd_weight_bnact(dy, x, st, again) if pro else ops.conv1x1_bwd_weight(dy, x, again))
+    assert torch.equal(again, dw)

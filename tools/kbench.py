@@ -213,6 +213,33 @@ def main():
                 acc(key, ms, mult)
             del x, t2, w1, w3, W1, W1t, W3, W3t
         ops.set_float32_matmul_precision(a.precision)
+    if "c1w" in only:
+        # weight gradients of the 1x1 convolutions: csrc/c1w.hip against gemm.hip, fp32 tensors and bf16 storage
+        for prec, dt in (("highest", torch.float32), ("medium", torch.bfloat16)):
+            ops.set_float32_matmul_precision(prec)
+            tag = "fp32" if prec == "highest" else "bf16"
+            es = 4 if prec == "highest" else 2
+            for c, h in stages[:4] + stages[7:]:
+                mult = 4 if c == 128 or h == S // 16 else 8
+                mid = c // 4
+                n = B * h * h
+                x, dt1 = rnd(B, c, h, h).to(dt), rnd(B, mid, h, h).to(dt)
+                g, b_, rm, rv = torch.ones(c, device=dev), torch.zeros(c, device=dev), torch.zeros(c, device=dev), torch.ones(c, device=dev)
+                st = ops.bn_stats_train(x, g, b_, rm, rv)
+                dw1, dw3 = torch.empty(mid, c, 1, 1, device=dev), torch.empty(c, mid, 1, 1, device=dev)
+                fl, by = 2 * n * c * mid, es * n * (c + mid)
+                for on in (False, True):
+                    ops.set_c1w(on)
+                    nm = "c1w" if on else "gemm.hip"
+                    ms = timeit(lambda: ops.conv1x1_bwd_weight_bnact(dt1, x, st, dw1), R)
+                    report(f"{tag} @{h} wgrad {c}->{mid} bnact {nm}", ms, fl, by)
+                    acc(f"wgrad1_{tag}_{'c1w' if on else 'gemm'}", ms, mult)
+                    ms = timeit(lambda: ops.conv1x1_bwd_weight(x, dt1, dw3), R)
+                    report(f"{tag} @{h} wgrad {mid}->{c} {nm}", ms, fl, by)
+                    acc(f"wgrad3_{tag}_{'c1w' if on else 'gemm'}", ms, mult)
+                ops.set_c1w(True)
+                del x, dt1
+        ops.set_float32_matmul_precision(a.precision)
     if "fuse" in only:
         # BatchNorm-apply + GELU in the GEMM loaders vs the materialised form, first BatchNorm of a Bottleneck (C -> C/4)
         for c, h in stages:

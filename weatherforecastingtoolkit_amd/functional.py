@@ -614,14 +614,14 @@ class BottleneckFn(Function):
         W1p = ops.c1_split_weights(w1) if (use1 or use3) else (None, None)
         W3p = ops.c1_split_weights(w3) if (use1 or use3) else (None, None)
         # bf16 storage: csrc/c1b.hip for the same four products (one bf16 weight plane each way)
-        b1 = x.dtype == ops.BF16 and ops.c1b_supported(mid, C, hw)
-        b3 = x.dtype == ops.BF16 and ops.c1b_supported(C, mid, hw)
-        if b1 or b3:
+        cb1 = x.dtype == ops.BF16 and ops.c1b_supported(mid, C, hw)
+        cb3 = x.dtype == ops.BF16 and ops.c1b_supported(C, mid, hw)
+        if cb1 or cb3:
             W1p, W3p = ops.c1b_weights(w1), ops.c1b_weights(w3)
         st1 = _bn_stats_rows(x_stats if (fuse or isinstance(x_stats, ops.StatParts)) else None, x, bn1, training)
         fused1 = FUSE_A1 and x.shape[1] <= FUSE_A1_MAXC and ops.conv1x1_bnact_supported(x, w1.shape[0])
         a1 = None if fused1 else ops.bn_act_fwd(x, st1, 1)
-        if b1:
+        if cb1:
             src, pro = (x, st1) if fused1 else (a1, None)
             t1, sr2 = ops.c1b_fwd(W1p[0], src, pro, None, True) if fuse else (ops.c1b_fwd(W1p[0], src, pro), None)
         elif use1:
@@ -637,14 +637,14 @@ class BottleneckFn(Function):
         st3 = _bn_stats(t2, bn3, training)
         if FUSE_A3 and w3.shape[0] <= FUSE_A3_MAXC and ops.conv1x1_bnact_supported(t2, w3.shape[0]):
             a3 = None
-            if b3:
+            if cb3:
                 y, mod._out_stats = ops.c1b_fwd(W3p[0], t2, st3, x, True) if emit else (ops.c1b_fwd(W3p[0], t2, st3, x), None)
             else:
                 y, mod._out_stats = ops.conv1x1_fwd_bnact(t2, st3, w3, None, x, stats=True) if emit else \
                     (ops.conv1x1_fwd_bnact(t2, st3, w3, None, x), None)
         else:
             a3 = ops.bn_act_fwd(t2, st3, 1)
-            if b3:
+            if cb3:
                 y, mod._out_stats = ops.c1b_fwd(W3p[0], a3, None, x, True) if emit else (ops.c1b_fwd(W3p[0], a3, None, x), None)
             elif use3:
                 y, mod._out_stats = ops.c1gemm_fwd(W3p[0], a3, None, x, True) if emit else (ops.c1gemm_fwd(W3p[0], a3, None, x), None)
@@ -654,7 +654,7 @@ class BottleneckFn(Function):
                               st1.mean, st1.invstd, st1.scale, st1.shift,
                               st2.mean, st2.invstd, st2.scale, st2.shift,
                               st3.mean, st3.invstd, st3.scale, st3.shift,
-                              _opt(W1p[1] if (use3 or b3) else None), _opt(W3p[1] if (use1 or b1) else None))
+                              _opt(W1p[1] if (use3 or cb3) else None), _opt(W3p[1] if (use1 or cb1) else None))
         ctx.training = training
         ctx.groups = groups
         ctx.betas = (b1, b2, b3)

@@ -320,10 +320,41 @@ def conv1x1_fwd_bnact(x, st, w, bias=None, res=None, stats=False):
     return y, (StatRows(part, rows.value) if rows.value > 0 else None)
 
 
+# weight gradients on csrc/c1w.hip (both operands as K-contiguous rows, no LDS transpose): fp32 tensors at fp32 precision with
+# the split GEMMs on, bf16-stored tensors at 'medium'
+_C1W = os.environ.get("WFAE_C1W", "1") != "0"
+
+
+def set_c1w(on):
+    global _C1W
+    _C1W = bool(on)
+
+
+def _c1w_route(dy, x, sfx):
+    nb, cout, h, wd = dy.shape
+    if not (_C1W and _lib.load().wfae_c1w_supported(x.shape[1], cout, h * wd)):
+        return False
+    prec = _lib.load().wfae_get_matmul_precision()
+    return prec == 1 if sfx else (prec == 0 and _SPLIT_GEMM)
+
+
+def _c1w(dy, x, st, dw, accumulate, sfx, es, label):
+    nb, cout, h, wd = dy.shape
+    cin = x.shape[1]
+    ws = workspace()
+    ps, ph = (None, None) if st is None else (_p(st.scale), _p(st.shift))
+    _call("wfae_c1w_bwd_weight" + sfx, 2 * nb * h * wd * cin * cout, es * nb * h * wd * (cin + cout) + 4 * cin * cout, _p(dy), _p(x),
+          ps, ph, _p(dw), nb, cin, cout, h * wd, int(accumulate), ws.data_ptr(), ws.numel(), _stream(), label=label,
+          peak=PEAK_BF16_MFMA / (1 if sfx else 6))
+    return dw
+
+
 def conv1x1_bwd_weight_bnact(dy, x, st, dw, accumulate=False):
     """conv1x1_bwd_weight(dy, bn_act_fwd(x, st, GELU), dw) without the activated tensor in HBM"""
     sfx, es = _chka(dy, x)
     _chk(dw)
+    if _c1w_route(dy, x, sfx):
+        return _c1w(dy, x, st, dw, accumulate, sfx, es, "wfae_conv1x1_bwd_weight_bnact")
     nb, cout, h, wd = dy.shape
     cin = x.shape[1]
     ws = workspace()
@@ -352,6 +383,8 @@ def conv1x1_bwd_data(dy, w):
 def conv1x1_bwd_weight(dy, x, dw, accumulate=False):
     sfx, es = _chka(dy, x)
     _chk(dw)
+    if _c1w_route(dy, x, sfx):
+        return _c1w(dy, x, None, dw, accumulate, sfx, es, "wfae_conv1x1_bwd_weight")
     nb, cout, h, wd = dy.shape
     cin = x.shape[1]
     ws = workspace()

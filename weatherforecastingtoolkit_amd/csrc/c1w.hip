@@ -123,8 +123,9 @@ __global__ __launch_bounds__(WNT, 2) void c1w_kernel(C1WP p) {
   // one loaded 16-byte piece -> LDS: fp32: 4 values -> (optional activation) -> three planes of 8 bytes; bf16: as it is
   auto put = [&](unsigned char* base, int plane_b, unsigned dst, u32x4 r, bool act, float s, float h) {
     if constexpr (F32) {
-      float v0 = __builtin_bit_cast(float, r.x), v1 = __builtin_bit_cast(float, r.y);
-      float v2 = __builtin_bit_cast(float, r.z), v3 = __builtin_bit_cast(float, r.w);
+      // (copied to scalars first: __builtin_bit_cast applied to an ext-vector ELEMENT expression read element 0 for all four)
+      const unsigned u0 = r[0], u1 = r[1], u2 = r[2], u3 = r[3];
+      float v0 = __uint_as_float(u0), v1 = __uint_as_float(u1), v2 = __uint_as_float(u2), v3 = __uint_as_float(u3);
       if (act) {   // bn_act_fwd_kernel<GELU>'s arithmetic
         v0 = gelu_f(fmaf(v0, s, h)); v1 = gelu_f(fmaf(v1, s, h));
         v2 = gelu_f(fmaf(v2, s, h)); v3 = gelu_f(fmaf(v3, s, h));

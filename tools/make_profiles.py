@@ -99,10 +99,22 @@ nsteps = 2
 out["_step_total"] = {"bytes_2xfetch_plus_write": (2 * sum(v[1] for v in F.values()) + sum(v[1] for v in W.values())) * 1024 / nsteps,
                       "bytes_raw_fetch_plus_write": (sum(v[1] for v in F.values()) + sum(v[1] for v in W.values())) * 1024 / nsteps,
                       "steps_in_run": nsteps}
-if os.path.exists("profiles/pmc_traffic.json"):   # keep the bf16-storage total measured by tools/make_profiles_medium.py
-    old = json.load(open("profiles/pmc_traffic.json"))
-    if "_step_total_bf16" in old and old.get("_kernel_source_tag") == bench.kernel_source_tag():
-        out["_step_total_bf16"] = old["_step_total_bf16"]
+# the same for --precision medium (bf16 activation storage) when tools/gpu_profile.sh collected it
+if glob.glob("gpurun_out/pmc_fetch_medium/*/*counter_collection.csv") and glob.glob("gpurun_out/pmc_write_medium/*/*counter_collection.csv"):
+    Fm = agg(one("gpurun_out/pmc_fetch_medium/*/*counter_collection.csv"), "FETCH_SIZE")
+    Wm = agg(one("gpurun_out/pmc_write_medium/*/*counter_collection.csv"), "WRITE_SIZE")
+    out["_step_total_bf16"] = {"bytes_2xfetch_plus_write": (2 * sum(v[1] for v in Fm.values()) + sum(v[1] for v in Wm.values())) * 1024 / nsteps,
+                               "bytes_raw_fetch_plus_write": (sum(v[1] for v in Fm.values()) + sum(v[1] for v in Wm.values())) * 1024 / nsteps,
+                               "steps_in_run": nsteps}
+    with open(f"profiles/{tag}_medium_pmc_hbm_traffic_per_kernel.csv", "w") as fo:
+        fo.write("# bench.py --precision medium (bf16 activation storage): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KiB\n")
+        fo.write("kernel,launches,fetch_KiB_per_launch_raw,write_KiB_per_launch,hbm_bytes_per_launch_corrected\n")
+        for k in sorted(Fm, key=lambda k: -Fm[k][1]):
+            n, fs = Fm[k]
+            ws = Wm.get(k, [n, 0])[1]
+            fo.write(f"\"{k}\",{n},{fs / n:.1f},{ws / n:.1f},{(2 * fs + ws) / n * 1024:.0f}\n")
+    shutil.copy(one("gpurun_out/prof_medium/*/*kernel_stats.csv"), f"profiles/{tag}_medium_bench_b32_384_kernel_stats.csv")
+    shutil.copy("gpurun_out/bench_medium.log", f"profiles/{tag}_medium_bench_b32_384.json")
 out["_kernel_source_tag"] = bench.kernel_source_tag()
 out["_source"] = f"{tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 1"
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)

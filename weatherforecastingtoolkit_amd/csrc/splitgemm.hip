@@ -1,6 +1,6 @@
 // splitgemm.hip — fp32-accurate batched GEMMs on the bf16 matrix pipe for the Winograd-domain products.
 //
-// v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (64 FLOP/clk/SIMD); v_mfma_f32_32x32x16_bf16 at 16x that.  An fp32
+// v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (64 FLOP/clk/SIMD); the bf16 MFMA instructions at 16x that.  An fp32
 // value is EXACTLY the sum of three bf16 values  x = h + m + l  (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): 3 x 8
 // significand bits, every subtraction exact), and a product of two bf16 values is exact in fp32, so
 //     a b = ah bh + (ah bm + am bh) + (ah bl + al bh + am bm) + [am bl + al bm + al bl]
@@ -14,11 +14,10 @@
 //   A: K-contiguous rows [M][K] (three planes `a_plane` elements apart),
 //   B: BKIND 0 — [K][N], N contiguous (down: V, up: Mt), read from LDS through ds_read_b64_tr_b16;
 //      BKIND 1 — [N][K], K contiguous (weight gradient: the contraction runs over the tiles), read like A.
-// Block tile 256 x 128 x 32, 8 waves as 4 (M) x 2 (N), wave tile 64 x 64 = 2 x 2 MFMA tiles, two LDS stages of 72 KiB,
-// register-staged global loads one K-step ahead, one barrier per K-step.  Per K-step and wave: 48 MFMAs (1536 cycles of
-// the SIMD's matrix pipe) against 24 LDS fragment reads, 9 global loads and 9 LDS stores.
-// LDS images (bank rule of MI355X_MICROARCH.md, LDS): rows of 64 B with the 16-byte chunk XOR-swizzled by (row >> 2) & 3
-// for the ds_read_b128 row reads; 256-byte k-rows with the chunk XOR ((k & 3) << 2 | (k >> 2) & 3) for the transposed reads.
+// Block tile 256 x 128 x 32, 8 waves as 4 (M) x 2 (N), wave tile 64 x 64 = 4 x 4 MFMA tiles of 16 x 16 x 32, two LDS stages
+// of 72 KiB, register-staged global loads one K-step ahead, one barrier per K-step.  Per K-step and wave: 96 MFMAs (1536
+// cycles of the SIMD's matrix pipe) against 24 (36 with the transposed reads) LDS fragment reads, 9 global loads and 9 LDS
+// stores.  LDS images (bank rule of MI355X_MICROARCH.md, LDS): off_row16 / off_tr16 below.
 #include "common.h"
 #include <stdlib.h>
 
@@ -26,7 +25,6 @@ using namespace wfae;
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -51,228 +49,13 @@ constexpr int B_PLANE_B = SBN * 64;   // either image: 128 rows x 64 B or 32 k-r
 // NP planes per operand: 3 = the exact fp32 split (six products per tile), 1 = the h plane alone = bf16-rounded operands
 // with fp32 accumulation (torch's 'medium' matmul precision; one product per tile, operands 2 bytes per element)
 
-__device__ __forceinline__ unsigned off_row(int r, int c) { return (unsigned)(r * 64 + ((c ^ ((r >> 2) & 3)) << 4)); }
-__device__ __forceinline__ unsigned off_tr(int k, int ch) {
-  return (unsigned)(k * 256 + ((ch ^ (((k & 3) << 2) | ((k >> 2) & 3))) << 4));
-}
-
-template <int BKIND, int NP = 3>
-__global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
-  static_assert(NP == 3 || NP == 1, "three exact planes or the h plane alone");
-  constexpr int A_STAGE_B = NP * A_PLANE_B;
-  constexpr int STAGE_B = NP * (A_PLANE_B + B_PLANE_B);
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  // XCD-aware placement.  Workgroups go round-robin over the 8 XCDs in launch order (x fastest, then y, z), each XCD
-  // with its own L2.  gridDim.x % 8 == 0: every XCD gets a contiguous run of the tiles of one batch.  Otherwise (few
-  // tiles per batch / K-split: the weight gradients) whole (y, z) groups are dealt to the XCDs, so that the tiles which
-  // share the group's operands run side by side under ONE L2 instead of fetching them from HBM once per XCD.
-  int bid = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if ((gridDim.x & 7) == 0) {
-    bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
-  } else {
-    const unsigned nxt = gridDim.x, ngroups = gridDim.y * gridDim.z;
-    const unsigned L = blockIdx.x + nxt * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (L < (ngroups & ~7u) * nxt) {
-      const unsigned slot = L >> 3, G = (L & 7) + 8 * (slot / nxt);
-      bid = (int)(slot % nxt);
-      by = (int)(G % gridDim.y);
-      bz = (int)(G / gridDim.y);
-    }
-  }
-  const int m0 = (bid % p.mtiles) * SBM, n0 = (bid / p.mtiles) * SBN;
-  const int k_begin = bz * p.k_per_split;
-  const int k_end = min(p.K, k_begin + p.k_per_split);
-  const int nsteps = (k_end - k_begin) / SBK;
-
-  // ---- loaders: every thread moves 2 (A) + 1 (B) 16-byte chunks per plane and K-step; rows / chunks beyond the matrix
-  // are clamped to valid ones (their products land in rows / columns the epilogue does not store)
-  const unsigned short* __restrict__ Ab = p.A + (long)by * p.a_y;
-  const unsigned short* __restrict__ Bb = p.B + (long)by * p.b_y;
-  const int ac = t & 3, ar = t >> 2;
-  const unsigned short* a_src0 = Ab + (long)min(m0 + ar, p.M - 1) * p.lda + k_begin + ac * 8;
-  const unsigned short* a_src1 = Ab + (long)min(m0 + ar + 128, p.M - 1) * p.lda + k_begin + ac * 8;
-  const unsigned a_dst = off_row(ar, ac);   // second row: + 128 * 64 (same swizzle: 128 / 4 = 0 mod 4)
-  const unsigned short* b_src;
-  unsigned b_dst;
-  long b_step;
-  if constexpr (BKIND == 0) {
-    const int bk = t >> 4, bch = t & 15;
-    int n = n0 + bch * 8;
-    if (n >= p.N) n = p.N - 8;
-    b_src = Bb + (long)(k_begin + bk) * p.ldb + n;
-    b_dst = off_tr(bk, bch);
-    b_step = (long)SBK * p.ldb;
-  } else {
-    b_src = Bb + (long)min(n0 + ar, p.N - 1) * p.ldb + k_begin + ac * 8;
-    b_dst = a_dst;
-    b_step = SBK;
-  }
-  u32x4 ra[NP][2], rb[NP];
-  auto load_global = [&]() {
-#pragma unroll
-    for (int pl = 0; pl < NP; ++pl) {
-      ra[pl][0] = *reinterpret_cast<const u32x4*>(a_src0 + pl * p.a_plane);
-      ra[pl][1] = *reinterpret_cast<const u32x4*>(a_src1 + pl * p.a_plane);
-      rb[pl] = *reinterpret_cast<const u32x4*>(b_src + pl * p.b_plane);
-    }
-  };
-  // pointer bumps are separate (and zero past the last K-step) so that the loop body has no conditional loads or stores:
-  // with them the compiler kept the staging registers in scratch memory and waited for every load at its issue point
-  auto advance = [&](bool more) {
-    a_src0 += more ? SBK : 0;
-    a_src1 += more ? SBK : 0;
-    b_src += more ? b_step : 0;
-  };
-  auto store_lds = [&](int buf) {
-    unsigned char* s = smem + buf * STAGE_B;
-#pragma unroll
-    for (int pl = 0; pl < NP; ++pl) {
-      *reinterpret_cast<u32x4*>(s + pl * A_PLANE_B + a_dst) = ra[pl][0];
-      *reinterpret_cast<u32x4*>(s + pl * A_PLANE_B + a_dst + 128 * 64) = ra[pl][1];
-      *reinterpret_cast<u32x4*>(s + A_STAGE_B + pl * B_PLANE_B + b_dst) = rb[pl];
-    }
-  };
-
-  // ---- fragment addresses
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-  const int r31 = lane & 31, lh = lane >> 5;
-  const unsigned a_rd = (unsigned)((wm0 + r31) * 64);
-  const int a_x = (r31 >> 2) & 3;
-  // BKIND 0 (transposed reads): lane 4q+pp of a 16-lane group g addresses row q, columns 4pp..4pp+3 of its 4 x 16 block
-  const int i16 = lane & 15, g = lane >> 4, tq = i16 >> 2, tp = i16 & 3;
-  const unsigned b_rd_row = (unsigned)((wn0 + r31) * 64);   // BKIND 1
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-
-  // fragments of one 16-deep k-slab: 2 x 3 A rows-of-planes and 2 x 3 B ones (48 registers)
-  struct Frag {
-    bf16x8 a[2][NP], b[2][NP];
-  };
-  auto read_frag = [&](Frag& f, int buf, int ks) {
-    const unsigned char* s = smem + buf * STAGE_B;
-    const unsigned a_c = (unsigned)(((2 * ks + lh) ^ a_x) << 4);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int pl = 0; pl < NP; ++pl)
-        f.a[i][pl] = *reinterpret_cast<const bf16x8*>(s + pl * A_PLANE_B + a_rd + i * (32 * 64) + a_c);
-    if constexpr (BKIND == 0) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
-          s16x4 part[2];
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            const int row = 16 * ks + 8 * (g >> 1) + 4 * hf + tq;
-            const int ch = ((wn0 + 32 * j) >> 3) + 2 * (g & 1) + (tp >> 1);
-            const unsigned off = off_tr(row, ch) + 8u * (tp & 1);
-            part[hf] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3)))*)(s + A_STAGE_B + pl * B_PLANE_B + off));
-          }
-          const s16x8 v = __builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7);
-          f.b[j][pl] = __builtin_bit_cast(bf16x8, v);
-        }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
-          f.b[j][pl] = *reinterpret_cast<const bf16x8*>(s + A_STAGE_B + pl * B_PLANE_B + b_rd_row + j * (32 * 64) + a_c);
-    }
-  };
-  auto mfma_tile = [&](const Frag& f, int i, int j) {
-    f32x16 c = acc[i][j];   // smallest terms first
-    if constexpr (NP == 3) {
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][2], f.b[j][0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][2], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][1], c, 0, 0, 0);
-    }
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][0], c, 0, 0, 0);
-    acc[i][j] = c;
-  };
-  auto mfma_frag = [&](const Frag& f) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) mfma_tile(f, i, j);
-  };
-
-  // Software pipeline, one barrier per K-step in the MIDDLE of the iteration:
-  //   first half : MFMAs of k-slab 0 (fragments F0, read during the previous iteration) while this wave reads the
-  //                fragments of k-slab 1 (F1), moves the staged K-step st+1 into the idle LDS stage and issues the global
-  //                loads of K-step st+2 — the memory instructions are spread between the MFMAs (sched_group_barrier): a wave
-  //                issues in order, and a burst of nine dwordx4 loads per wave, by all eight waves at once, kept every wave
-  //                in the texture unit's queue (and the matrix pipe idle) for ~1100 cycles per K-step;
-  //   barrier    : stage cur^1 complete, nobody reads stage cur any more (its k-slab-1 fragments are in registers);
-  //   second half: MFMAs of k-slab 1 (F1) while F0 is refilled from k-slab 0 of the NEXT stage.
-  if (nsteps > 0) {
-    Frag f0, f1;
-    load_global();
-    advance(nsteps > 1);
-    store_lds(0);
-    load_global();   // K-step 1 (or 0 again when there is only one: stored to the idle stage, never read)
-    advance(nsteps > 2);
-    __syncthreads();
-    read_frag(f0, 0, 0);
-    for (int st = 0; st < nsteps; ++st) {
-      const int cur = st & 1;
-      read_frag(f1, cur, 1);
-      store_lds(cur ^ 1);   // K-step st + 1; in the last iteration a stale copy nobody reads
-      load_global();        // K-step st + 2
-      advance(st + 3 < nsteps);
-      mfma_frag(f0);
-#pragma unroll
-      for (int q = 0; q < 9; ++q) {   // 24 MFMAs, 12 or 18 LDS reads, 9 LDS writes, 9 global loads
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);   // keep the k-slab-1 MFMAs behind the barrier: they are what hides the F0 reads
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);
-      read_frag(f0, cur ^ 1, 0);
-      mfma_frag(f1);
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-
-  // ---- epilogue: accumulator register q of lane (r31, lh) is C[(q & 3) + 8 (q >> 2) + 4 lh][r31] of its 32 x 32 tile
-  float* __restrict__ Cb = p.C + (long)by * p.c_y + (long)bz * p.c_split;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn0 + 32 * j + r31;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = m0 + wm0 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * lh;
-        if (row < p.M && col < p.N) Cb[(long)row * p.ldc + col] = acc[i][j][q];
-      }
-    }
-}
-
-// ---- the same GEMM on v_mfma_f32_16x16x32_bf16 (round 3).  Under bf16 MFMA load the chip holds its clock by power, and
-// the 16x16x32 shape needs less of it per FLOP (MI355X_MICROARCH.md, DVFS give-back (7)): same block tile, LDS stages,
-// loaders and wave tile (64 x 64 = 4 x 4 MFMA tiles of 16 x 16, 64 accumulator registers); a fragment now spans the whole
-// 32-deep K-step, so the two halves of an iteration are quadrants of the wave tile instead of k-slabs:
+// ---- the kernel, on v_mfma_f32_16x16x32_bf16.  Rounds 2's form of it ran v_mfma_f32_32x32x16_bf16 (two 16-deep k-slabs per
+// K-step, same tiles and stages).  Under bf16 MFMA load the chip holds its clock by power, and the 16x16x32 shape needs
+// less of it per FLOP (MI355X_MICROARCH.md, DVFS give-back (7)): measured on the four layer shapes of the model, same
+// run, 28.03 -> 25.53 ms for the three products at an unchanged matrix-pipe share (0.59 -> 0.61) and a clock of 1.88
+// instead of 1.74 GHz (profiles/r03_v7_pmc_split_gemm_mfma_shape.txt); step 213.4 -> 208.4 ms on that box.
+// Wave tile 64 x 64 = 4 x 4 MFMA tiles of 16 x 16 (64 accumulator registers); a fragment spans the whole 32-deep
+// K-step, so the two halves of an iteration are quadrants of the wave tile:
 //     (A_lo, B_lo) -> (A_lo, B_hi) -> barrier -> (A_hi, B_hi) -> (A_hi, B_lo)
 // and every quadrant shares one operand group (2 tiles x NP planes, 24 registers) with the one before it while the other
 // group is read from LDS during the previous quadrant's MFMAs: 24 fragment reads per K-step as before, at most four
@@ -294,13 +77,17 @@ __device__ __forceinline__ unsigned off_tr16(int k, int ch) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int BKIND, int NP = 3>
-__global__ __launch_bounds__(SNT, 2) void sgemm3_k16_kernel(SgP p) {
+__global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
   static_assert(NP == 3 || NP == 1, "three exact planes or the h plane alone");
   constexpr int A_STAGE_B = NP * A_PLANE_B;
   constexpr int STAGE_B = NP * (A_PLANE_B + B_PLANE_B);
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  int bid = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;   // XCD placement: see sgemm3_kernel
+  // XCD-aware placement.  Workgroups go round-robin over the 8 XCDs in launch order (x fastest, then y, z), each XCD
+  // with its own L2.  gridDim.x % 8 == 0: every XCD gets a contiguous run of the tiles of one batch.  Otherwise (few
+  // tiles per batch / K-split: the weight gradients) whole (y, z) groups are dealt to the XCDs, so that the tiles which
+  // share the group's operands run side by side under ONE L2 instead of fetching them from HBM once per XCD.
+  int bid = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if ((gridDim.x & 7) == 0) {
     bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
   } else {
@@ -532,12 +319,6 @@ int launch_sgemm3(SgP& p, int planes, int batches, int splits, hipStream_t st, c
   WFAE_REQUIRE(tiles < (1l << 31) && batches <= 65535 && splits <= 65535, WFAE_ERR_BAD_SHAPE, "%s: grid too large", what);
   // (An LDS-DMA form of the loaders — global_load_lds_dwordx4, no staging registers or ds_write — measured equal on the
   // Winograd shapes in round 2, 28.96 vs 28.57 ms, and was removed: the operand path is not what the waves wait for.)
-  static const int shape = getenv("WFAE_SGEMM_MFMA") ? atoi(getenv("WFAE_SGEMM_MFMA")) : 32;   // A/B (round 3)
-  if (shape == 16) {
-    if (planes == 1) hipLaunchKernelGGL((sgemm3_k16_kernel<BKIND, 1>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
-    else hipLaunchKernelGGL((sgemm3_k16_kernel<BKIND, 3>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
-    return check_launch(what);
-  }
   if (planes == 1) hipLaunchKernelGGL((sgemm3_kernel<BKIND, 1>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
   else hipLaunchKernelGGL((sgemm3_kernel<BKIND, 3>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
   return check_launch(what);

@@ -61,7 +61,7 @@ def main():
     rows = sorted(prof.items(), key=lambda kv: -kv[1][1])
     tot = sum(v[1] for v in prof.values()) / 2
     print(f"serialised kernel time {tot:.1f} ms/step")
-    for k, (calls, tms, fl, by) in rows[:24]:
+    for k, (calls, tms, fl, by, *_) in rows[:24]:
         print(f"  {k:32s} {calls // 2:5d} calls {tms / 2:9.2f} ms  {fl / tms / 1e9 if tms else 0:7.1f} TF/s {by / tms / 1e6 if tms else 0:8.0f} GB/s")
 
 

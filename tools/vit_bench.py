@@ -38,7 +38,7 @@ print(f"AE_ViT_2048 train step B={a.batch}: {ms:.1f} ms  ({a.batch / ms * 1e3:.0
 ops.profile_start()
 step()
 prof = ops.profile_stop()
-for k, (calls, tms, fl, by) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:8]:
+for k, (calls, tms, fl, by, *_) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:8]:
     print(f"   {k:26s} {calls:4d} calls {tms:8.2f} ms  {fl / tms / 1e9 if tms else 0:7.1f} TF/s")
 # forecaster on the [64, 512] token latent: 13 -> 12 frames, B sequences
 from weatherforecastingtoolkit_amd import nn as wnn  # noqa: E402

@@ -1351,15 +1351,10 @@ __global__ void unpack_taps_kernel(const float* __restrict__ dwp, float* __restr
   dw[i] = v;
 }
 
-inline int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
 // Tile selection: BM x 128 x 16 with 4 waves.  BM = 256 (wave tile 128 x 64, 128 accumulator
 // registers) halves the loads / LDS traffic / address arithmetic per MFMA — the SIMD issues VALU, LDS
 // and MFMA instructions from one port, so non-MFMA instructions per MFMA set the achieved rate
-// (PMC: SQ_VALU_MFMA_BUSY_CYCLES vs SQ_INSTS_VALU).  WFAE_BM256=0 disables it (A/B testing).
+// (PMC: SQ_VALU_MFMA_BUSY_CYCLES vs SQ_INSTS_VALU).
 // tile height: the tallest of 128 / 64 / 32 rows that M fills, stepped down while the grid would leave most of the
 // chip's 1024 resident-block slots empty (small batches, the 24x24 stage: 288 blocks of 128 rows ran 0.157 ms,
 // 576 of 64 rows 0.132 ms).  Large grids are unaffected.
@@ -1371,7 +1366,7 @@ inline int pick_bm(int M, long col_blocks) {
 
 template <int AK, int BKD, int EK, bool VEC, int PRO = 0, typename AT = float, typename BT = float, typename CT = float>
 int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what, int ydim = 1) {
-  static const int use256 = env_int("WFAE_BM256", 1);
+  constexpr bool use256 = true;
   GemmP p = p_in;
   const int ntiles = cdiv(p.N, BN);
   dim3 block(NT);
@@ -1403,8 +1398,7 @@ int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what,
     if constexpr (VEC) {
       if constexpr (BKD == B_NCONTIG || BKD == B_KCONTIG || BKD == B_TAPN || BKD == B_TAPK) {
         // fp32 products on the bf16 matrix pipe, operands split in registers (PREC 2): for the MFMA-bound shapes
-        static const int split_min_k = env_int("WFAE_SPLIT_MIN_K", 128);
-        static const int split_min_m = env_int("WFAE_SPLIT_MIN_M", 64);
+        constexpr int split_min_k = 128, split_min_m = 64;   // (K >= 32..128, M >= 32..64 all within 1 % in round 2)
         if (wfae::split_gemm_enabled() && p.K >= split_min_k && p.M >= split_min_m) {
           int bm = pick_bm(p.M, (long)ntiles * ydim * zdim);
           if (p.bn_mode && bm == 32) bm = 64;

@@ -52,7 +52,8 @@ typedef enum {
  *        double* and `stat_capacity` counts DOUBLES (the epilogue sums are reduced in fp64).  A caller built against 100
  *        would hand over a buffer of half the byte size: check wfae_version() >= 101 before using them.
  *   102  round 3: wfae_c1gemm_* (1x1 convolutions on the bf16 matrix pipe with exact split operands, fused BatchNorm
- *        backward epilogues) added; nothing removed. */
+ *        backward epilogues), the bf16 ACTIVATION STORAGE entry points (*_bf16, *_bf16in, *_bf16out, wfae_convert_*),
+ *        wfae_c1b_*, wfae_c1w_*, wfae_g3b_* added; nothing removed. */
 int wfae_version(void);
 const char* wfae_last_error_string(void);
 /* upper bound of scratch bytes any single call needs for a problem whose
@@ -360,6 +361,14 @@ int wfae_c1b_weights(const float* w, uint16_t* Wb, uint16_t* Wtb, int Cout, int 
 int wfae_c1b_fwd(const uint16_t* Wb, const uint16_t* x, const float* pro_scale, const float* pro_shift, const uint16_t* res,
                  uint16_t* y, int NB, int K, int M, int HW, double* stat_part, int64_t stat_capacity, int* stat_rows,
                  wfae_stream_t stream);
+/* The Bottleneck's grouped 3x3 convolution on bf16-stored activations as an implicit GEMM on the bf16 matrix pipe
+ * (csrc/g3b.hip; reference pipeline/models/ae_64x8x8_lin.py:17): same arguments and result as wfae_gconv3x3_fwd_bf16 (which
+ * routes here when wfae_g3b_supported says 1), transposed = 1 gives the data gradient.  Served: (channels per group, W) =
+ * (4,384), (8,192), (16,96), (32,48), (32,24) with H a multiple of the strip height; workspace >= C/16 * 3 * 2 * 1024 bytes
+ * (C/32 * 3 * 3 * 2 * 1024 at 32 channels per group) for the weight fragments.  WFAE_PRECISION_BF16 arithmetic. */
+int wfae_g3b_supported(int C, int H, int W, int groups);
+int wfae_g3b_fwd_bf16(const uint16_t* x, const float* w, uint16_t* y, int NB, int C, int H, int W, int groups, int transposed,
+                      void* ws, size_t ws_bytes, wfae_stream_t stream);
 int wfae_bn_act_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* gamma, const float* scale, const float* shift,
                          const float* save_mean, const float* save_invstd, const uint16_t* res, uint16_t* dx, float* dgamma,
                          float* dbeta, int NB, int C, int HW, int act, int training, int accumulate, int phases, void* ws,

@@ -30,11 +30,12 @@ def ops_medium(dev):
         assert ops.activation_dtype() == torch.float32
 
 
-def ulp_close(a_bf16, ref_f32, frac=2e-3):
-    """a (bf16) == round_bf16(ref) except where the fp32 value sits at a rounding boundary: then one bf16 ulp (2^-8 rel)"""
+def ulp_close(a_bf16, ref_f32, frac=2e-3, atol=0.0):
+    """a (bf16) == round_bf16(ref) except where the fp32 value sits at a rounding boundary: then one bf16 ulp (2^-8 rel);
+    atol: the fp32 accumulation-order noise of a sum whose terms cancel (a result near zero has an ulp below that noise)"""
     a, r = a_bf16.float(), ref_f32.bfloat16().float()
     exact = (a == r)
-    close = (a - r).abs() <= 2.0 ** -7 * r.abs().clamp_min(1e-30)
+    close = (a - r).abs() <= 2.0 ** -7 * r.abs().clamp_min(1e-30) + atol
     return bool(close.all()) and float((~exact).float().mean()) <= frac
 
 
@@ -142,6 +143,41 @@ def test_gconv3_bf16_storage(ops_medium, dev, nb, c, groups, h, w):
     ops.gconv3x3_bwd_weight(dy, x, dw, groups)
     ops.gconv3x3_bwd_weight(dy.float(), x.float(), dw32, groups)
     assert relerr(dw, dw32) < 2e-5
+
+
+@pytest.mark.parametrize("nb,c,h,w", [(2, 32, 48, 384), (1, 32, 24, 384), (2, 64, 48, 192), (1, 64, 72, 192), (2, 128, 48, 96),
+                                      (3, 256, 48, 48), (2, 256, 16, 48), (2, 256, 24, 24), (1, 256, 12, 24)])
+def test_g3b_implicit_gemm_matches_the_direct_kernels(ops_medium, dev, nb, c, h, w):
+    """csrc/g3b.hip (bf16 MFMA, row ring, output-side tap shifts) against the dconv.hip kernels on the same bf16 tensors and
+    bf16-rounded weights, forward and data gradient; several strips per image (halo rows, zero rows at the image border),
+    several slabs, all five (channels per group, width) pairs of the model; and against torch's conv2d on the CPU."""
+    ops = ops_medium
+    groups = 8
+    assert ops.g3b_supported(c, h, w, groups)
+    x = rnd((nb, c, h, w), 11).bfloat16().to(dev)
+    wt = (rnd((c, c // groups, 3, 3), 12) * 0.3).bfloat16().float().to(dev)   # bf16-representable: both paths multiply the same values
+    for tr in (False, True):
+        y = ops.gconv3x3_fwd(x, wt, groups, tr)
+        ops.set_g3b(False)
+        try:
+            y0 = ops.gconv3x3_fwd(x.float(), wt, groups, tr)
+        finally:
+            ops.set_g3b(True)
+        assert y.dtype == BF and y.shape == x.shape
+        assert ulp_close(y, y0, frac=5e-4, atol=2e-6), (tr, float((y.float() - y0).abs().max()))
+    ref = torch.nn.functional.conv2d(x.float().cpu(), wt.cpu(), padding=1, groups=groups)
+    assert relerr(ops.gconv3x3_fwd(x, wt, groups).float().cpu(), ref) < 4e-3   # bf16 rounding of the result
+
+
+def test_g3b_refuses_other_shapes(ops_medium, dev):
+    from weatherforecastingtoolkit_amd import _lib
+    ops = ops_medium
+    assert not ops.g3b_supported(32, 20, 36, 8) and not ops.g3b_supported(64, 25, 192, 8)
+    x = torch.zeros((1, 32, 20, 36), dtype=BF, device=dev)
+    wt = torch.zeros((32, 4, 3, 3), device=dev)
+    with pytest.raises(_lib.WfaeError):
+        _lib.call("wfae_g3b_fwd_bf16", x.data_ptr(), wt.data_ptr(), x.data_ptr(), 1, 32, 20, 36, 8, 0, ops.workspace().data_ptr(),
+                  ops.workspace().numel(), 0)
 
 
 @pytest.mark.parametrize("nb,chi,clo,hlo,wlo", [(2, 32, 64, 8, 8), (1, 64, 32, 16, 16), (2, 128, 256, 8, 8), (1, 32, 32, 64, 64)])

@@ -274,6 +274,26 @@ def main():
                 report(f"gconv3x3 {nm:5s} {mid}ch g8 @{h}", ms, fl, by)
                 acc("dconv_" + nm, ms, 4)
             del x, w, dy, dw
+    if "g3b" in only:   # grouped 3x3 on bf16 tensors: dconv.hip kernels vs the implicit-GEMM kernel (csrc/g3b.hip)
+        ops.set_float32_matmul_precision("medium")
+        for c, h in stages:
+            mid = c // 4
+            x, w, dy = rnd(B, mid, h, h).bfloat16(), rnd(mid, mid // 8, 3, 3), rnd(B, mid, h, h).bfloat16()
+            dw = torch.empty_like(w)
+            fl = 2 * B * h * h * mid * (mid // 8) * 9
+            by = 2 * 2 * B * h * h * mid
+            for kern in ("dconv", "g3b"):
+                ops.set_g3b(kern == "g3b")
+                for nm, fn in [("fwd", lambda: ops.gconv3x3_fwd(x, w, 8, False)), ("dgrad", lambda: ops.gconv3x3_fwd(dy, w, 8, True))]:
+                    ms = timeit(fn, R)
+                    report(f"bf16 gconv3x3 {nm:5s} {mid}ch g8 @{h} {kern}", ms, fl, by)
+                    acc(f"{kern}_{nm}", ms, 4)
+            ms = timeit(lambda: ops.gconv3x3_bwd_weight(dy, x, dw, 8), R)
+            report(f"bf16 gconv3x3 wgrad {mid}ch g8 @{h}", ms, fl, by)
+            acc("wgrad", ms, 4)
+            del x, w, dy, dw
+        ops.set_g3b(True)
+        ops.set_float32_matmul_precision(a.precision)
     if "bn" in only:
         for c, h in stages:
             for ch in (c, c // 4):

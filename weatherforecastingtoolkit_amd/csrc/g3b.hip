@@ -1,0 +1,328 @@
+// g3b.hip — the Bottleneck's grouped 3x3 'same' convolution (pipeline/models/ae_64x8x8_lin.py:17), forward and data
+// gradient, in the bf16-STORAGE mode ('medium' precision, BASELINE config 5) as an implicit GEMM on the bf16 matrix pipe.
+//
+// dconv.hip serves these shapes through fp32 LDS patches: a VALU kernel at 4 / 8 channels per group (36 / 72 FMAs per output
+// element) and v_mfma_f32_*_f32 tiles at 16 / 32 — with bf16 tensors both stay bound by fp32 arithmetic and by a patch staging
+// that moves one 2-byte element per lane (1.0 - 1.4 TB/s, profiles/r03_v6_medium_*).  Here a bf16 value never changes format
+// between HBM and the matrix core:
+//   y[oc][p] = sum_{kx} P_kx[oc][p + kx - 1],     P_kx[oc][q] = sum_{ky, ci} w[oc][ci][ky][kx] x[ci][q + (ky - 1) W]
+//   * the x shift of a tap is taken on the OUTPUT side: each P_kx is accumulated over 16-pixel blocks q that are ALIGNED in
+//     the input row, so the B operand (k = (ky, ci), n = 16 pixels) is read from an LDS image that is laid out exactly like
+//     the tensor ([channel][row][x], 16-byte global loads stored as they are) through ds_read_b64_tr_b16, whose 4 x 16
+//     blocks must start on a multiple of four columns; the ky shift is a whole LDS row.  The three partial tiles are combined
+//     with two DPP row shifts (the MFMA's C layout puts the 16 pixels of a tile in the 16 lanes of a DPP row); the lane that
+//     falls off a tile takes the neighbour tile's value, which the same wave computes next (or, at the two ends of a wave's
+//     run of tiles, with the one partial product it needs of the neighbour tile);
+//   * a block owns a slab of 16 (32 at 32 channels per group) channels of one image over the FULL image width — no column
+//     halo — and walks down a strip of rows with a ring of rows in LDS: every input row is loaded once per strip, row
+//     r + 2 travels HBM -> registers while row r is multiplied, one barrier per step;
+//   * A operand: the weights of the slab as ready-made MFMA fragments (bf16, block-diagonal over the groups that share a
+//     16-channel tile: 4 / 8 channels per group use a quarter / half of it, which is still far from binding — the kernel is
+//     HBM-bound), written once per call by g3b_pack_kernel, held in registers for the whole strip;
+//   * results leave through wave-private LDS slices as 16-byte pieces of 8 bf16.
+// MFMA k order inside a 32-deep step (it only has to be the same for both operands): k = 8 g + 4 h + q with g the lane
+// group, h the transposed read, q the row of its 4 x 16 block  ->  channel 8 h + 4 (g & 1) + q of tap row 2 s + (g >> 1)
+// (16-channel slabs: two tap rows per step, the fourth is a zero weight) or channel 16 (g >> 1) + 8 h + 4 (g & 1) + q of tap
+// row s (32-channel slabs): the two lane groups of a 32-lane LDS access then read 8 CONSECUTIVE channels, and a channel stride
+// of an odd multiple of 32 bytes spreads them over all 64 banks.
+#include "common.h"
+
+using namespace wfae;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int CPG, int TPR, int W_>
+struct G3B {
+  static constexpr int SC = CPG == 32 ? 32 : 16;   // channels of a slab
+  static constexpr int MT = SC / 16;               // 16-row tiles of output channels
+  static constexpr int KS = CPG == 32 ? 3 : 2;     // 32-deep K-steps per kx
+  static constexpr int RI = 24 / TPR;              // rows per step: 24 tiles of 16 pixels, 6 per wave
+  static constexpr int P = 16 * TPR;               // LDS row pitch in pixels (>= W_; the rest stays zero)
+  static constexpr int R = 2 * RI + 2;             // ring rows
+  static constexpr int RS = P * 2;                 // bytes
+  static constexpr int CS0 = R * RS;
+  static constexpr int CS = (CS0 / 32) % 2 ? CS0 : CS0 + 32;   // odd multiple of 32 bytes
+  static constexpr int RING_B = SC * CS;
+  static constexpr int OB_RS = 208;                // 96 pixels x 2 bytes + 16: the four lane groups write different bank octets
+  static constexpr int OB_B = MT * 16 * OB_RS;     // per wave
+  static constexpr int XC = W_ / 8;                // 16-byte pieces per channel row
+  static constexpr int CH_ROW = SC * XC;
+  static constexpr int NLD = (RI * CH_ROW + 255) / 256;
+  static constexpr int SEG = TPR < 6 ? TPR : 6;    // tiles of one row in a wave's run
+  static constexpr int NSEG = 6 / SEG;
+  static_assert(24 % TPR == 0 && W_ % 8 == 0 && W_ <= P && P - W_ < 16, "geometry");
+};
+
+__device__ __forceinline__ float dpp_shr1(float cur, float prev) {   // lane i <- cur[i - 1], lane 0 <- prev[15] (16-lane rows)
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(prev), 0x121, 0xf, 0xf, false);          // row_ror:1
+  return __int_as_float(__builtin_amdgcn_update_dpp(t, __float_as_int(cur), 0x111, 0xf, 0xf, false));  // row_shr:1
+}
+__device__ __forceinline__ float dpp_shl1(float cur, float next) {   // lane i <- cur[i + 1], lane 15 <- next[0]
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(next), 0x12f, 0xf, 0xf, false);          // row_ror:15
+  return __int_as_float(__builtin_amdgcn_update_dpp(t, __float_as_int(cur), 0x101, 0xf, 0xf, false));  // row_shl:1
+}
+
+template <int CPG, int TPR, int W_>
+__global__ __launch_bounds__(256) void g3b_kernel(const bf16_t* __restrict__ x, const bf16x8* __restrict__ wpk,
+                                                  bf16_t* __restrict__ y, int C, int H, int RH) {
+  using G = G3B<CPG, TPR, W_>;
+  constexpr int SC = G::SC, MT = G::MT, KS = G::KS, RI = G::RI, R = G::R, RS = G::RS, CS = G::CS;
+  __shared__ __attribute__((aligned(16))) unsigned char ring[G::RING_B];
+  __shared__ __attribute__((aligned(16))) unsigned char obuf[4 * G::OB_B];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int strip = blockIdx.x, vg = blockIdx.y, n = blockIdx.z;
+  const int y0 = strip * RH;
+  const long HW = (long)H * W_;
+  const bf16_t* __restrict__ xg = x + ((long)n * C + (long)vg * SC) * HW;
+  bf16_t* __restrict__ yg = y + ((long)n * C + (long)vg * SC) * HW;
+
+  if constexpr (G::P != W_) {   // pad columns are never written again
+    for (int i = t * 16; i < G::RING_B; i += 256 * 16) *reinterpret_cast<u32x4*>(ring + i) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+  }
+
+  // ---- weights: MFMA A fragments of this slab, in registers for the whole strip
+  bf16x8 afr[3][KS][MT];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) afr[kx][s][mt] = wpk[((((long)vg * 3 + kx) * KS + s) * MT + mt) * 64 + lane];
+
+  // ---- staging: rows [first, first + nrows) of the slab, 16-byte pieces, as they lie in memory; rows outside the image are zero
+  u32x4 rg[G::NLD];
+  auto load_rows = [&](int first, int nrows) {
+#pragma unroll
+    for (int j = 0; j < G::NLD; ++j) {
+      const int id = t + 256 * j;
+      const int ri = id / G::CH_ROW, rem = id - ri * G::CH_ROW;
+      const int ci = rem / G::XC, xc = rem - ci * G::XC;
+      const int row = first + ri;
+      const bool ok = id < nrows * G::CH_ROW && row >= 0 && row < H;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(xg + (ok ? (long)ci * HW + (long)row * W_ + xc * 8 : 0));
+      rg[j] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto store_rows = [&](int first, int nrows) {
+#pragma unroll
+    for (int j = 0; j < G::NLD; ++j) {
+      const int id = t + 256 * j;
+      const int ri = id / G::CH_ROW, rem = id - ri * G::CH_ROW;
+      const int ci = rem / G::XC, xc = rem - ci * G::XC;
+      const int slot = (first + ri - y0 + 1) % R;
+      if (id < nrows * G::CH_ROW) *reinterpret_cast<u32x4*>(ring + ci * CS + slot * RS + xc * 16) = rg[j];
+    }
+  };
+
+  // ---- per-lane pieces of the transposed-read addresses
+  const int g4 = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+  const int ci0 = (CPG == 32 ? 16 * (g4 >> 1) : 0) + 4 * (g4 & 1) + tq;   // h = 0; h = 1 is 8 channels on
+  const unsigned lane_off = (unsigned)(ci0 * CS + 8 * tp);
+  const bool ky_hi = (g4 >> 1) != 0;   // 16-channel slabs: this lane group takes the second tap row of a step
+
+  // B fragments of the tile (row index `ridx` into the ring = row - y0 + 1 of tap row 0, column block xb)
+  auto read_b = [&](bf16x8 (&b)[KS], int ridx, int xb) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      int ky_lo = CPG == 32 ? s : 2 * s, ky_up = CPG == 32 ? s : (2 * s + 1 > 2 ? 2 : 2 * s + 1);
+      const unsigned rlo = (unsigned)(((ridx + ky_lo) % R) * RS), rup = (unsigned)(((ridx + ky_up) % R) * RS);
+      const unsigned roff = CPG == 32 ? rlo : (ky_hi ? rup : rlo);
+      const unsigned char* a = ring + lane_off + roff + xb * 32;
+      const s16x4 p0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a));
+      const s16x4 p1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a + 8 * CS));
+      b[s] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+  };
+  auto partial = [&](f32x4 (&acc)[MT], const bf16x8 (&b)[KS], int kx) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kx][s][mt], b[s], c, 0, 0, 0);
+      acc[mt] = c;
+    }
+  };
+
+  // ---- prologue: rows y0 - 1 .. y0 + RI
+  for (int r = y0 - 1; r <= y0 + RI; r += RI) {
+    const int nr = min(RI, y0 + RI - r + 1);
+    load_rows(r, nr);
+    store_rows(r, nr);
+  }
+  __syncthreads();
+
+  unsigned char* ob = obuf + wave * G::OB_B;
+  const int iters = RH / RI;
+  for (int it = 0; it < iters; ++it) {
+    const int r0 = y0 + it * RI;
+    const bool more = it + 1 < iters;
+    if (more) load_rows(r0 + RI + 1, RI);
+
+#pragma unroll
+    for (int sg = 0; sg < G::NSEG; ++sg) {
+      const int idx0 = 6 * wave + sg * G::SEG;
+      const int rowi = idx0 / TPR, xa = idx0 - rowi * TPR;   // row inside the step, first column block
+      const int ridx = it * RI + rowi;                        // ring index of tap row 0 (input row r0 + rowi - 1)
+      f32x4 prev0[MT], pend[MT], pend2[MT];
+      bf16x8 b[KS];
+      // the P_0 of the block left of the run feeds pixel 0 of the first tile (zero at the image border)
+      if (xa > 0) {
+        read_b(b, ridx, xa - 1);
+        partial(prev0, b, 0);
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) prev0[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i <= G::SEG; ++i) {
+        f32x4 p0[MT], p1[MT], p2[MT];
+        const bool inside = i < G::SEG;
+        if (inside || xa + G::SEG < TPR) {
+          read_b(b, ridx, xa + i);
+          partial(p2, b, 2);
+          if (inside) {
+            partial(p0, b, 0);
+            partial(p1, b, 1);
+          }
+        } else {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) p2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (i > 0) {   // tile i - 1 is complete: its P_2 shifted left takes pixel 0 of this tile's P_2
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float v = pend[mt][q] + dpp_shl1(pend2[mt][q], p2[mt][q]);
+              const int oc = mt * 16 + 4 * g4 + q;
+              *reinterpret_cast<bf16_t*>(ob + oc * G::OB_RS + ((sg * G::SEG + i - 1) * 16 + i16) * 2) =
+                  (bf16_t)(pack_bf16(v, 0.f) & 0xffffu);
+            }
+        }
+        if (inside) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pend[mt][q] = p1[mt][q] + dpp_shr1(p0[mt][q], prev0[mt][q]);
+            prev0[mt] = p0[mt];
+            pend2[mt] = p2[mt];
+          }
+        }
+      }
+    }
+
+    // ---- the wave's 6 tiles leave as 16-byte pieces: MT x 16 channel rows x 12 pieces
+#pragma unroll
+    for (int j = 0; j < 3 * MT; ++j) {
+      const int id = lane + 64 * j;
+      const int orow = id / 12, ch = id - orow * 12;
+      const int idx = 6 * wave + (ch >> 1);
+      const int rowi = idx / TPR, xb = idx - rowi * TPR;
+      const int px = xb * 16 + 8 * (ch & 1);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(ob + orow * G::OB_RS + ch * 16);
+      if (px < W_) *reinterpret_cast<u32x4*>(yg + (long)orow * HW + (long)(r0 + rowi) * W_ + px) = v;
+    }
+
+    if (more) store_rows(r0 + RI + 1, RI);
+    __syncthreads();
+  }
+}
+
+// wpk[((((vg * 3 + kx) * KS + s) * MT + mt) * 64 + lane) * 8 + j]: A[m = lane & 15][k = 8 (lane >> 4) + j] of the MFMA
+//   forward:    out channel co, in channel ci:  w[co][ci - group base][ky][kx]
+//   transposed: (data gradient) the kernel's "out" channel is the convolution's input channel: w[ci][co - group base][2 - ky][2 - kx]
+template <int CPG>
+__global__ void g3b_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ wpk, int C, int transposed) {
+  constexpr int SC = CPG == 32 ? 32 : 16, MT = SC / 16, KS = CPG == 32 ? 3 : 2;
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)(C / SC) * 3 * KS * MT * 64 * 8;
+  if (i0 >= total) return;
+  const int j = (int)(i0 & 7), lane = (int)((i0 >> 3) & 63);
+  long r = i0 >> 9;
+  const int mt = (int)(r % MT); r /= MT;
+  const int s = (int)(r % KS); r /= KS;
+  const int kx = (int)(r % 3);
+  const int vg = (int)(r / 3);
+  const int m = lane & 15, g4 = lane >> 4, h = j >> 2, q = j & 3;
+  const int oc = mt * 16 + m;
+  const int ci = CPG == 32 ? 16 * (g4 >> 1) + 8 * h + 4 * (g4 & 1) + q : 8 * h + 4 * (g4 & 1) + q;
+  const int ky = CPG == 32 ? s : 2 * s + (g4 >> 1);
+  float v = 0.f;
+  if (ky <= 2 && oc / CPG == ci / CPG) {
+    const int co = vg * SC + oc, cin = vg * SC + ci, gb = (co / CPG) * CPG;
+    v = transposed ? w[((long)cin * CPG + (co - gb)) * 9 + (2 - ky) * 3 + (2 - kx)]
+                   : w[((long)co * CPG + (cin - gb)) * 9 + ky * 3 + kx];
+  }
+  wpk[i0] = (bf16_t)(pack_bf16(v, 0.f) & 0xffffu);
+}
+
+template <int CPG, int TPR, int W_>
+int g3b_launch(const bf16_t* x, const float* w, bf16_t* y, int NB, int C, int H, int RH, int transposed, void* ws,
+               size_t ws_bytes, hipStream_t st) {
+  using G = G3B<CPG, TPR, W_>;
+  const int slabs = C / G::SC;
+  const long frag_elems = (long)slabs * 3 * G::KS * G::MT * 64 * 8;
+  WFAE_REQUIRE(ws && ws_bytes >= (size_t)frag_elems * 2, WFAE_ERR_WORKSPACE, "g3b_fwd: workspace %zu < %zu", ws_bytes,
+               (size_t)frag_elems * 2);
+  hipLaunchKernelGGL((g3b_pack_kernel<CPG>), dim3((unsigned)cdiv(frag_elems, 256)), dim3(256), 0, st, w, (bf16_t*)ws, C,
+                     transposed);
+  int rc = check_launch("g3b_pack");
+  if (rc) return rc;
+  hipLaunchKernelGGL((g3b_kernel<CPG, TPR, W_>), dim3(H / RH, slabs, NB), dim3(256), 0, st, x, (const bf16x8*)ws, y, C, H, RH);
+  return check_launch("g3b");
+}
+
+// the (channels per group, width) pairs of the model; rows per strip: a multiple of the rows per step that divides H
+int g3b_strip(int cpg, int H, int W) {
+  int ri;
+  if (cpg == 4 && W == 384) ri = 1;
+  else if (cpg == 8 && W == 192) ri = 2;
+  else if (cpg == 16 && W == 96) ri = 4;
+  else if (cpg == 32 && W == 48) ri = 8;
+  else if (cpg == 32 && W == 24) ri = 12;
+  else return 0;
+  for (int rh = 24; rh >= ri; rh -= ri)
+    if (rh % ri == 0 && H % rh == 0) return rh;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wfae_g3b_supported(int C, int H, int W, int groups) {
+  if (C <= 0 || groups <= 0 || C % groups != 0 || H <= 0) return 0;
+  const int cpg = C / groups;
+  if (C % (cpg == 32 ? 32 : 16) != 0 || C / (cpg == 32 ? 32 : 16) > 65535) return 0;
+  return g3b_strip(cpg, H, W) > 0 ? 1 : 0;
+}
+
+int wfae_g3b_fwd_bf16(const uint16_t* x, const float* w, uint16_t* y, int NB, int C, int H, int W, int groups, int transposed,
+                      void* ws, size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(x && w && y, WFAE_ERR_NULL_POINTER, "g3b_fwd: null pointer");
+  WFAE_REQUIRE(NB > 0 && NB <= 65535 && C > 0 && H > 0 && W > 0 && groups > 0 && C % groups == 0, WFAE_ERR_BAD_SHAPE,
+               "g3b_fwd: bad shape");
+  WFAE_REQUIRE(wfae_g3b_supported(C, H, W, groups), WFAE_ERR_UNSUPPORTED,
+               "g3b_fwd: (channels per group, width) must be (4,384), (8,192), (16,96), (32,48) or (32,24) with H a multiple of "
+               "the strip height (ask wfae_g3b_supported; wfae_gconv3x3_fwd_bf16 serves every shape)");
+  WFAE_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0,
+               WFAE_ERR_BAD_SHAPE, "g3b_fwd: tensors and workspace must be 16-byte aligned");
+  WFAE_REQUIRE(wfae::matmul_precision() == WFAE_PRECISION_BF16, WFAE_ERR_UNSUPPORTED,
+               "g3b_fwd: bf16 activation storage needs wfae_set_matmul_precision(WFAE_PRECISION_BF16)");
+  const int cpg = C / groups, rh = g3b_strip(cpg, H, W);
+  hipStream_t st = (hipStream_t)stream;
+  if (cpg == 4) return g3b_launch<4, 24, 384>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
+  if (cpg == 8) return g3b_launch<8, 12, 192>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
+  if (cpg == 16) return g3b_launch<16, 6, 96>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
+  if (W == 48) return g3b_launch<32, 3, 48>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
+  return g3b_launch<32, 2, 24>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
+}
+
+}  // extern "C"

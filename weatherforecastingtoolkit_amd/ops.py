@@ -1067,6 +1067,20 @@ def gconv3x3_supported(c, groups):
     return c % groups == 0 and (c // groups) in (4, 8, 16, 32)
 
 
+_G3B = os.environ.get("WFAE_G3B", "1") != "0"
+
+
+def set_g3b(on):
+    """A/B switch: bf16 grouped 3x3 convolutions on the implicit-GEMM kernel (csrc/g3b.hip) or on the dconv.hip kernels"""
+    global _G3B
+    _G3B = bool(on)
+
+
+def g3b_supported(c, h, wd, groups):
+    return _G3B and _lib.load().wfae_get_matmul_precision() == 1 and bool(
+        _lib.load().wfae_g3b_supported(int(c), int(h), int(wd), int(groups)))
+
+
 def gconv3x3_fwd(x, w, groups, transposed=False):
     """grouped 3x3 'same' conv with Cin == Cout (Bottleneck middle conv); transposed=True gives the data gradient."""
     sfx, es = _chka(x)
@@ -1075,6 +1089,10 @@ def gconv3x3_fwd(x, w, groups, transposed=False):
     y = torch.empty_like(x)
     ws = workspace()
     cpg = c // groups
+    if sfx == "_bf16" and g3b_supported(c, h, wd, groups):
+        _call("wfae_g3b_fwd_bf16", 2 * x.numel() * cpg * 9, 2 * es * x.numel(), _p(x), _p(w), _p(y), nb, c, h, wd, groups,
+              int(transposed), ws.data_ptr(), ws.numel(), _stream(), label="wfae_gconv3x3_fwd", peak=PEAK_BF16_MFMA)
+        return y
     _call("wfae_gconv3x3_fwd" + sfx, 2 * x.numel() * cpg * 9, 2 * es * x.numel(), _p(x), _p(w), _p(y), nb, c, h, wd, groups,
           int(transposed), ws.data_ptr(), ws.numel(), _stream(), label="wfae_gconv3x3_fwd")
     return y

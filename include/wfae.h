@@ -369,6 +369,11 @@ int wfae_c1b_fwd(const uint16_t* Wb, const uint16_t* x, const float* pro_scale, 
 int wfae_g3b_supported(int C, int H, int W, int groups);
 int wfae_g3b_fwd_bf16(const uint16_t* x, const float* w, uint16_t* y, int NB, int C, int H, int W, int groups, int transposed,
                       void* ws, size_t ws_bytes, wfae_stream_t stream);
+/* weight gradient of the same convolution on the same kernel family (both tensors staged as they lie in memory, the kx shift
+ * of a tap taken on the dy fragment in registers): dw (C, C/groups, 3, 3) fp32, += when accumulate; workspace >=
+ * NB * (H / strip height) * C * (C/groups) * 9 * 4 bytes (one partial per block, added in fixed order) */
+int wfae_g3b_bwd_weight_bf16(const uint16_t* dy, const uint16_t* x, float* dw, int NB, int C, int H, int W, int groups,
+                             int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
 int wfae_bn_act_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* gamma, const float* scale, const float* shift,
                          const float* save_mean, const float* save_invstd, const uint16_t* res, uint16_t* dx, float* dgamma,
                          float* dbeta, int NB, int C, int HW, int act, int training, int accumulate, int phases, void* ws,

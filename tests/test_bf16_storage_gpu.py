@@ -167,6 +167,23 @@ def test_g3b_implicit_gemm_matches_the_direct_kernels(ops_medium, dev, nb, c, h,
         assert ulp_close(y, y0, frac=5e-4, atol=2e-6), (tr, float((y.float() - y0).abs().max()))
     ref = torch.nn.functional.conv2d(x.float().cpu(), wt.cpu(), padding=1, groups=groups)
     assert relerr(ops.gconv3x3_fwd(x, wt, groups).float().cpu(), ref) < 4e-3   # bf16 rounding of the result
+    # weight gradient (csrc/g3b.hip g3bw_kernel): fp32 sums of exact bf16 products on both paths
+    dy = rnd((nb, c, h, w), 13).bfloat16().to(dev)
+    dw, dw0 = torch.empty_like(wt), torch.empty_like(wt)
+    ops.gconv3x3_bwd_weight(dy, x, dw, groups)
+    ops.set_g3b(False)
+    try:
+        ops.gconv3x3_bwd_weight(dy.float(), x.float(), dw0, groups)
+    finally:
+        ops.set_g3b(True)
+    assert relerr(dw, dw0) < 2e-5, relerr(dw, dw0)
+    xc = x.float().cpu().requires_grad_(False)
+    wc = wt.cpu().clone().requires_grad_(True)
+    torch.nn.functional.conv2d(xc, wc, padding=1, groups=groups).backward(dy.float().cpu())
+    assert relerr(dw.cpu(), wc.grad) < 2e-5
+    dw2 = dw.clone()
+    ops.gconv3x3_bwd_weight(dy, x, dw2, groups, accumulate=True)
+    assert relerr(dw2, 2 * dw) < 1e-6
 
 
 def test_g3b_refuses_other_shapes(ops_medium, dev):

@@ -288,9 +288,9 @@ def main():
                     ms = timeit(fn, R)
                     report(f"bf16 gconv3x3 {nm:5s} {mid}ch g8 @{h} {kern}", ms, fl, by)
                     acc(f"{kern}_{nm}", ms, 4)
-            ms = timeit(lambda: ops.gconv3x3_bwd_weight(dy, x, dw, 8), R)
-            report(f"bf16 gconv3x3 wgrad {mid}ch g8 @{h}", ms, fl, by)
-            acc("wgrad", ms, 4)
+                ms = timeit(lambda: ops.gconv3x3_bwd_weight(dy, x, dw, 8), R)
+                report(f"bf16 gconv3x3 wgrad {mid}ch g8 @{h} {kern}", ms, fl, by)
+                acc(f"{kern}_wgrad", ms, 4)
             del x, w, dy, dw
         ops.set_g3b(True)
         ops.set_float32_matmul_precision(a.precision)

@@ -293,6 +293,203 @@ int g3b_strip(int cpg, int H, int W) {
   return 0;
 }
 
+
+// =====================================================================================================================
+// Weight gradient of the same convolution on bf16 tensors:
+//   dW[oc][ci][ky][kx] = sum_q dy[oc][q - (kx - 1)] x[ci][q + (ky - 1) P]        (q over the padded pixel slots of a strip)
+// The contraction runs over pixels, which are the contiguous index of BOTH tensors: both are staged as they lie in memory
+// (16-byte pieces) into chunk-major LDS images  [32-pixel chunk][channel][64 bytes]  — per chunk exactly the A / B row image
+// of splitgemm.hip (16-byte unit XOR g(channel >> 2): conflict-free ds_read_b128 fragments) — with a row pitch P that is a
+// multiple of 32 pixels and >= W + 8, the pad columns zero in both images:
+//   * the ky shift of a tap is then a whole number of chunks of the x image;
+//   * the kx shift is taken on the dy fragment in registers: one 16-byte read plus the two neighbouring dwords, two funnel
+//     shifts of four dwords (v_alignbit) give dy[q + 1 ..] and dy[q - 1 ..] — one fragment read serves all nine taps;
+//     the zero pad between two rows is what the shifted fragment reads at a row end (the 'same' padding of the convolution).
+// One v_mfma_f32_16x16x32_bf16 per tap and 32 pixels.  A block owns a 16- (32-) channel slab of one image and a strip of
+// rows, rows travel through LDS once (x with one halo row either side), next rows HBM -> registers during the products.
+// 4 / 8 / 16 channels per group: the four waves split the chunks and their nine accumulator tiles are added through LDS at
+// the end (fixed order); 32 per group: wave = (oc tile, ci tile).  The block's partial goes to a slab, slab_reduce adds the
+// slabs in fixed order (deterministic).
+// =====================================================================================================================
+template <int CPG, int W_>
+struct G3W {
+  static constexpr int SC = CPG == 32 ? 32 : 16;
+  static constexpr int P = (W_ + 8 + 31) / 32 * 32;
+  static constexpr int CPRW = P / 32;                                   // chunks per row
+  static constexpr int RI = W_ >= 384 ? 1 : W_ >= 192 ? 2 : W_ >= 96 ? 4 : W_ >= 48 ? 8 : 12;
+  static constexpr int RX = RI + 2, RD = RI;
+  static constexpr int CHB = SC * 64;                                   // bytes of a chunk
+  static constexpr int XB = RX * CPRW * CHB, DB = (RD * CPRW + 2) * CHB;  // dy image with a zero guard chunk at either end
+  static constexpr int XC = W_ / 8;
+  static constexpr int NLD = (RI * SC * XC + 255) / 256;
+  static constexpr int NCH = RI * CPRW;                                 // dy chunks per step
+  static_assert(XB >= 2 * 9 * 256 * 4, "the x image doubles as the cross-wave reduction buffer");
+};
+
+__device__ __forceinline__ unsigned g3w_sw(int ch) { return (unsigned)((0x78 >> (((ch >> 2) & 3) << 1)) & 3); }
+
+template <int CPG, int W_>
+__global__ __launch_bounds__(256) void g3bw_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                   float* __restrict__ part, int C, int H, int RH, long out_elems) {
+  using G = G3W<CPG, W_>;
+  constexpr int SC = G::SC, RI = G::RI, RX = G::RX, CPRW = G::CPRW, CHB = G::CHB;
+  __shared__ __attribute__((aligned(16))) unsigned char xl[G::XB];
+  __shared__ __attribute__((aligned(16))) unsigned char dl[G::DB];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int strip = blockIdx.x, vg = blockIdx.y, n = blockIdx.z;
+  const int y0 = strip * RH;
+  const long HW = (long)H * W_;
+  const bf16_t* __restrict__ xg = x + ((long)n * C + (long)vg * SC) * HW;
+  const bf16_t* __restrict__ dg = dy + ((long)n * C + (long)vg * SC) * HW;
+
+  for (int i = t * 16; i < G::XB; i += 256 * 16) *reinterpret_cast<u32x4*>(xl + i) = u32x4{0u, 0u, 0u, 0u};
+  for (int i = t * 16; i < G::DB; i += 256 * 16) *reinterpret_cast<u32x4*>(dl + i) = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+
+  u32x4 rgx[G::NLD], rgd[G::NLD];
+  auto load_rows = [&](u32x4 (&rg)[G::NLD], const bf16_t* __restrict__ src, int first, int nrows) {
+#pragma unroll
+    for (int j = 0; j < G::NLD; ++j) {
+      const int id = t + 256 * j;
+      const int ri = id / (SC * G::XC), rem = id - ri * (SC * G::XC);
+      const int ch = rem / G::XC, xc = rem - ch * G::XC;
+      const int row = first + ri;
+      const bool ok = id < nrows * SC * G::XC && row >= 0 && row < H;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(src + (ok ? (long)ch * HW + (long)row * W_ + xc * 8 : 0));
+      rg[j] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  // slot0: ring index of row `first` (x: (row - y0 + 1) % RX, dy: (row - y0) % RD); img: the image past its guard chunk
+  auto store_rows = [&](const u32x4 (&rg)[G::NLD], unsigned char* img, int slot0, int nslots, int nrows) {
+#pragma unroll
+    for (int j = 0; j < G::NLD; ++j) {
+      const int id = t + 256 * j;
+      const int ri = id / (SC * G::XC), rem = id - ri * (SC * G::XC);
+      const int ch = rem / G::XC, xc = rem - ch * G::XC;
+      const int slot = (slot0 + ri) % nslots;
+      if (id < nrows * SC * G::XC)
+        *reinterpret_cast<u32x4*>(img + (slot * CPRW + (xc >> 2)) * CHB + ch * 64 + ((((unsigned)xc & 3u) ^ g3w_sw(ch)) << 4)) = rg[j];
+    }
+  };
+  unsigned char* dimg = dl + CHB;
+
+  // ---- fragment addresses inside a chunk
+  const int g4 = lane >> 4, c16 = lane & 15;
+  const int cha = (CPG == 32 ? 16 * (wave >> 1) : 0) + c16;   // dy row (oc) of this lane
+  const int chb = (CPG == 32 ? 16 * (wave & 1) : 0) + c16;    // x row (ci)
+  const unsigned swa = g3w_sw(cha), swb = g3w_sw(chb);
+  const int a_cur = cha * 64 + (int)(((unsigned)g4 ^ swa) << 4);
+  const int a_prev = (g4 > 0 ? cha * 64 + (int)(((unsigned)(g4 - 1) ^ swa) << 4) : -CHB + cha * 64 + (int)((3u ^ swa) << 4)) + 12;
+  const int a_next = g4 < 3 ? cha * 64 + (int)(((unsigned)(g4 + 1) ^ swa) << 4) : CHB + cha * 64 + (int)((0u ^ swa) << 4);
+  const int b_cur = chb * 64 + (int)(((unsigned)g4 ^ swb) << 4);
+
+  f32x4 acc[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: x rows y0 - 1 .. y0 + RI, dy rows y0 .. y0 + RI - 1
+  for (int r = y0 - 1; r <= y0 + RI; r += RI) {
+    const int nr = min(RI, y0 + RI - r + 1);
+    load_rows(rgx, xg, r, nr);
+    store_rows(rgx, xl, r - y0 + 1, RX, nr);
+  }
+  load_rows(rgd, dg, y0, RI);
+  store_rows(rgd, dimg, 0, G::RD, RI);
+  __syncthreads();
+
+  const int iters = RH / RI;
+  for (int it = 0; it < iters; ++it) {
+    const int r0 = y0 + it * RI;
+    const bool more = it + 1 < iters;
+    if (more) {
+      load_rows(rgx, xg, r0 + RI + 1, RI);
+      load_rows(rgd, dg, r0 + RI, RI);
+    }
+    for (int c = (CPG == 32 ? 0 : wave); c < G::NCH; c += (CPG == 32 ? 1 : 4)) {
+      const int rowi = c / CPRW, cr = c - rowi * CPRW;
+      const unsigned char* dc = dimg + c * CHB;
+      const u32x4 d = *reinterpret_cast<const u32x4*>(dc + a_cur);
+      const unsigned dm = *reinterpret_cast<const unsigned*>(dc + a_prev);
+      const unsigned dn = *reinterpret_cast<const unsigned*>(dc + a_next);
+      bf16x8 af[3];
+      af[1] = __builtin_bit_cast(bf16x8, d);
+      // kx = 0 multiplies dy[q + 1], kx = 2 dy[q - 1]
+      af[0] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(d[1], d[0], 16), __builtin_amdgcn_alignbit(d[2], d[1], 16),
+                                               __builtin_amdgcn_alignbit(d[3], d[2], 16), __builtin_amdgcn_alignbit(dn, d[3], 16)});
+      af[2] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(d[0], dm, 16), __builtin_amdgcn_alignbit(d[1], d[0], 16),
+                                               __builtin_amdgcn_alignbit(d[2], d[1], 16), __builtin_amdgcn_alignbit(d[3], d[2], 16)});
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int sx = (it * RI + rowi + ky) % RX;
+        const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(xl + (sx * CPRW + cr) * CHB + b_cur);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc[ky][kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kx], bfr, acc[ky][kx], 0, 0, 0);
+      }
+    }
+    __syncthreads();   // every wave is done with the rows that the incoming ones replace
+    if (more) {
+      store_rows(rgx, xl, (r0 + RI + 1 - y0 + 1) % RX, RX, RI);
+      store_rows(rgd, dimg, 0, G::RD, RI);
+    }
+    __syncthreads();
+  }
+
+  // ---- 16-channel slabs: add the four waves' tiles (3 + 2 -> 1 + 0, then 1 -> 0), fixed order
+  if constexpr (CPG != 32) {
+    float* red = reinterpret_cast<float*>(xl);
+    auto put = [&](int slotw) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) *reinterpret_cast<f32x4*>(red + ((slotw * 9 + a * 3 + b) * 64 + lane) * 4) = acc[a][b];
+    };
+    auto add = [&](int slotw) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[a][b] += *reinterpret_cast<const f32x4*>(red + ((slotw * 9 + a * 3 + b) * 64 + lane) * 4);
+    };
+    if (wave >= 2) put(wave - 2);
+    __syncthreads();
+    if (wave < 2) add(wave);
+    __syncthreads();
+    if (wave == 1) put(0);
+    __syncthreads();
+    if (wave == 0) add(0);
+  }
+  // ---- D[oc = 4 g4 + q][ci = c16] of tap (ky, kx): only the products inside a group are weights
+  if (CPG == 32 || wave == 0) {
+    float* __restrict__ dst = part + ((long)n * gridDim.x + strip) * out_elems;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int oc = (CPG == 32 ? 16 * (wave >> 1) : 0) + 4 * g4 + q, ci = chb;
+      if (oc / CPG == ci / CPG) {
+        const long co = (long)vg * SC + oc;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) dst[(co * CPG + (ci % CPG)) * 9 + ky * 3 + kx] = acc[ky][kx][q];
+      }
+    }
+  }
+}
+
+template <int CPG, int W_>
+int g3bw_launch(const bf16_t* dy, const bf16_t* x, float* dw, int NB, int C, int H, int RH, int accumulate, void* ws,
+                size_t ws_bytes, hipStream_t st) {
+  using G = G3W<CPG, W_>;
+  const int slabs = C / G::SC, strips = H / RH;
+  const long out_elems = (long)C * CPG * 9, parts = (long)NB * strips;
+  WFAE_REQUIRE(ws && ws_bytes >= (size_t)parts * out_elems * sizeof(float), WFAE_ERR_WORKSPACE,
+               "g3b_bwd_weight: workspace %zu < %zu", ws_bytes, (size_t)parts * out_elems * sizeof(float));
+  hipLaunchKernelGGL((g3bw_kernel<CPG, W_>), dim3(strips, slabs, NB), dim3(256), 0, st, dy, x, (float*)ws, C, H, RH, out_elems);
+  int rc = check_launch("g3bw");
+  if (rc) return rc;
+  return slab_reduce((const float*)ws, dw, nullptr, out_elems, 1, (int)parts, accumulate, st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -323,6 +520,26 @@ int wfae_g3b_fwd_bf16(const uint16_t* x, const float* w, uint16_t* y, int NB, in
   if (cpg == 16) return g3b_launch<16, 6, 96>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
   if (W == 48) return g3b_launch<32, 3, 48>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
   return g3b_launch<32, 2, 24>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
+}
+
+int wfae_g3b_bwd_weight_bf16(const uint16_t* dy, const uint16_t* x, float* dw, int NB, int C, int H, int W, int groups,
+                             int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(dy && x && dw, WFAE_ERR_NULL_POINTER, "g3b_bwd_weight: null pointer");
+  WFAE_REQUIRE(NB > 0 && NB <= 65535 && C > 0 && H > 0 && W > 0 && groups > 0 && C % groups == 0, WFAE_ERR_BAD_SHAPE,
+               "g3b_bwd_weight: bad shape");
+  WFAE_REQUIRE(wfae_g3b_supported(C, H, W, groups), WFAE_ERR_UNSUPPORTED,
+               "g3b_bwd_weight: shape not served (ask wfae_g3b_supported; wfae_gconv3x3_bwd_weight_bf16 serves every shape)");
+  WFAE_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0, WFAE_ERR_BAD_SHAPE,
+               "g3b_bwd_weight: tensors must be 16-byte aligned");
+  WFAE_REQUIRE(wfae::matmul_precision() == WFAE_PRECISION_BF16, WFAE_ERR_UNSUPPORTED,
+               "g3b_bwd_weight: bf16 activation storage needs wfae_set_matmul_precision(WFAE_PRECISION_BF16)");
+  const int cpg = C / groups, rh = g3b_strip(cpg, H, W);
+  hipStream_t st = (hipStream_t)stream;
+  if (cpg == 4) return g3bw_launch<4, 384>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
+  if (cpg == 8) return g3bw_launch<8, 192>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
+  if (cpg == 16) return g3bw_launch<16, 96>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
+  if (W == 48) return g3bw_launch<32, 48>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
+  return g3bw_launch<32, 24>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
 }
 
 }  // extern "C"

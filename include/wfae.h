@@ -374,6 +374,13 @@ int wfae_g3b_fwd_bf16(const uint16_t* x, const float* w, uint16_t* y, int NB, in
  * NB * (H / strip height) * C * (C/groups) * 9 * 4 bytes (one partial per block, added in fixed order) */
 int wfae_g3b_bwd_weight_bf16(const uint16_t* dy, const uint16_t* x, float* dw, int NB, int C, int H, int W, int groups,
                              int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
+/* the same kernels on fp32 tensors: every value split exactly into three bf16 planes at the LDS store, six products per fp32
+ * product (the arithmetic of the split GEMMs: fp32 accuracy).  wfae_g3b_f32_supported(…, wgrad): 1 when the shape is served at
+ * the current mode (fp32 precision with the split switch on; weight gradient at W <= 96 only: three planes of full-width rows exceed
+ * the LDS at W = 384 and allow one block per CU at W = 192, which measured slower than wfae_gconv3x3_bwd_weight's kernel). */
+int wfae_g3b_f32_supported(int C, int H, int W, int groups, int wgrad);
+int wfae_g3b_bwd_weight(const float* dy, const float* x, float* dw, int NB, int C, int H, int W, int groups, int accumulate,
+                        void* ws, size_t ws_bytes, wfae_stream_t stream);
 int wfae_bn_act_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* gamma, const float* scale, const float* shift,
                          const float* save_mean, const float* save_invstd, const uint16_t* res, uint16_t* dx, float* dgamma,
                          float* dbeta, int NB, int C, int HW, int act, int training, int accumulate, int phases, void* ws,

@@ -163,3 +163,36 @@ def test_conv1x1_in_register_split_matches_fp32_accuracy(ops, dev, nb, cin, cout
         e_split = float((res[True][i].double() - r64).abs().max()) / rms
         assert e_split <= 1.5 * e_f32 + 1e-7, (i, e_split, e_f32)
         assert not torch.equal(res[False][i], res[True][i]), "the split path did not run"
+
+
+@pytest.mark.parametrize("nb,c,h,w", [(2, 128, 48, 96), (1, 128, 96, 96), (3, 256, 48, 48), (2, 256, 16, 48), (2, 256, 24, 24),
+                                      (1, 256, 12, 24)])
+def test_grouped3x3_weight_gradient_on_split_planes_matches_fp32_accuracy(ops, dev, nb, c, h, w):
+    """csrc/g3b.hip g3bw_kernel on fp32 tensors (three exact bf16 planes per value, six products per fp32 product) against
+    fp64, beside the fp32-MFMA kernel of dconv.hip on the same data: inside the spread two fp32 summation orders of these
+    10^4 .. 10^5-term sums show (3x, measured 0.5 - 2x); accumulate form; the shapes of the model that the kernel serves in
+    fp32 (W <= 96), several strips and slabs"""
+    groups = 8
+    g = torch.Generator().manual_seed(c + w)
+    x = (torch.rand(nb, c, h, w, generator=g) - 0.5).to(dev)
+    dy = (torch.rand(nb, c, h, w, generator=g) - 0.5).to(dev)
+    wr = torch.zeros(c, c // groups, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double().cpu(), wr, padding=1, groups=groups).backward(dy.double().cpu())
+    r64 = wr.grad.to(dev)
+    res = {}
+    try:
+        for on in (False, True):
+            ops.set_g3b(on)
+            dw = torch.empty(c, c // groups, 3, 3, device=dev)
+            ops.gconv3x3_bwd_weight(dy, x, dw, groups)
+            res[on] = dw
+        dw2 = res[True].clone()
+        ops.gconv3x3_bwd_weight(dy, x, dw2, groups, accumulate=True)
+    finally:
+        ops.set_g3b(True)
+    rms = float(r64.pow(2).mean().sqrt())
+    e_old = float((res[False].double() - r64).abs().max()) / rms
+    e_new = float((res[True].double() - r64).abs().max()) / rms
+    assert e_new <= max(3.0 * e_old, 3e-6), (e_new, e_old)
+    assert not torch.equal(res[False], res[True]), "the split-plane kernel did not run"
+    assert float((dw2 - 2 * res[True]).abs().max()) <= 1e-6 * float(res[True].abs().max())

@@ -311,43 +311,75 @@ int g3b_strip(int cpg, int H, int W) {
 // the end (fixed order); 32 per group: wave = (oc tile, ci tile).  The block's partial goes to a slab, slab_reduce adds the
 // slabs in fixed order (deterministic).
 // =====================================================================================================================
-template <int CPG, int W_>
+template <int CPG, int W_, int NP>
 struct G3W {
   static constexpr int SC = CPG == 32 ? 32 : 16;
   static constexpr int P = (W_ + 8 + 31) / 32 * 32;
   static constexpr int CPRW = P / 32;                                   // chunks per row
-  static constexpr int RI = W_ >= 384 ? 1 : W_ >= 192 ? 2 : W_ >= 96 ? 4 : W_ >= 48 ? 8 : 12;
+  // rows per step: bf16 tensors 12 - 16 chunks per step; fp32 tensors (three planes: 3x the LDS) as few rows as give the
+  // four waves a chunk each
+  static constexpr int RI = NP == 1 ? (W_ >= 384 ? 1 : W_ >= 192 ? 2 : W_ >= 96 ? 4 : W_ >= 48 ? 8 : 12)
+                                    : (W_ >= 192 ? 1 : W_ >= 96 ? 2 : W_ >= 48 ? 1 : 2);
   static constexpr int RX = RI + 2, RD = RI;
   static constexpr int CHB = SC * 64;                                   // bytes of a chunk
-  static constexpr int XB = RX * CPRW * CHB, DB = (RD * CPRW + 2) * CHB;  // dy image with a zero guard chunk at either end
+  static constexpr int XB = RX * CPRW * CHB, DB = (RD * CPRW + 2) * CHB;  // per plane; dy image with a zero guard chunk at either end
   static constexpr int XC = W_ / 8;
   static constexpr int NLD = (RI * SC * XC + 255) / 256;
   static constexpr int NCH = RI * CPRW;                                 // dy chunks per step
-  static_assert(XB >= 2 * 9 * 256 * 4, "the x image doubles as the cross-wave reduction buffer");
+  static_assert(NP * XB >= 2 * 9 * 256 * 4, "the x image doubles as the cross-wave reduction buffer");
+  static_assert(NP * (XB + DB) <= 160 * 1024, "LDS");
 };
 
 __device__ __forceinline__ unsigned g3w_sw(int ch) { return (unsigned)((0x78 >> (((ch >> 2) & 3) << 1)) & 3); }
 
-template <int CPG, int W_>
-__global__ __launch_bounds__(256) void g3bw_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+// eight consecutive pixels of one channel row in registers: bf16 tensors one 16-byte piece, fp32 tensors two
+template <typename T> struct G3Piece;
+template <> struct G3Piece<bf16_t> { u32x4 v; };
+template <> struct G3Piece<float> { u32x4 lo, hi; };
+__device__ __forceinline__ void g3_load(G3Piece<bf16_t>& r, const bf16_t* p, bool ok) {
+  const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+  r.v = ok ? v : u32x4{0u, 0u, 0u, 0u};
+}
+__device__ __forceinline__ void g3_load(G3Piece<float>& r, const float* p, bool ok) {
+  const u32x4 a = *reinterpret_cast<const u32x4*>(p), b = *reinterpret_cast<const u32x4*>(p + 4);
+  r.lo = ok ? a : u32x4{0u, 0u, 0u, 0u};
+  r.hi = ok ? b : u32x4{0u, 0u, 0u, 0u};
+}
+// planes of the piece as MFMA-ready 16-byte rows: bf16 tensors the value itself, fp32 tensors h + m + l == x (common.h split3)
+__device__ __forceinline__ void g3_planes(const G3Piece<bf16_t>& r, u32x4 (&pl)[1]) { pl[0] = r.v; }
+__device__ __forceinline__ void g3_planes(const G3Piece<float>& r, u32x4 (&pl)[3]) {
+  unsigned short h[8], m[8], l[8];
+  const unsigned u[8] = {r.lo[0], r.lo[1], r.lo[2], r.lo[3], r.hi[0], r.hi[1], r.hi[2], r.hi[3]};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) split3(__uint_as_float(u[i]), h[i], m[i], l[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pl[0][i] = (unsigned)h[2 * i] | ((unsigned)h[2 * i + 1] << 16);
+    pl[1][i] = (unsigned)m[2 * i] | ((unsigned)m[2 * i + 1] << 16);
+    pl[2][i] = (unsigned)l[2 * i] | ((unsigned)l[2 * i + 1] << 16);
+  }
+}
+
+template <int CPG, int W_, int NP, typename T>
+__global__ __launch_bounds__(256) void g3bw_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                    float* __restrict__ part, int C, int H, int RH, long out_elems) {
-  using G = G3W<CPG, W_>;
-  constexpr int SC = G::SC, RI = G::RI, RX = G::RX, CPRW = G::CPRW, CHB = G::CHB;
-  __shared__ __attribute__((aligned(16))) unsigned char xl[G::XB];
-  __shared__ __attribute__((aligned(16))) unsigned char dl[G::DB];
+  using G = G3W<CPG, W_, NP>;
+  constexpr int SC = G::SC, RI = G::RI, RX = G::RX, CPRW = G::CPRW, CHB = G::CHB, XB = G::XB, DB = G::DB;
+  __shared__ __attribute__((aligned(16))) unsigned char xl[NP * XB];
+  __shared__ __attribute__((aligned(16))) unsigned char dl[NP * DB];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int strip = blockIdx.x, vg = blockIdx.y, n = blockIdx.z;
   const int y0 = strip * RH;
   const long HW = (long)H * W_;
-  const bf16_t* __restrict__ xg = x + ((long)n * C + (long)vg * SC) * HW;
-  const bf16_t* __restrict__ dg = dy + ((long)n * C + (long)vg * SC) * HW;
+  const T* __restrict__ xg = x + ((long)n * C + (long)vg * SC) * HW;
+  const T* __restrict__ dg = dy + ((long)n * C + (long)vg * SC) * HW;
 
-  for (int i = t * 16; i < G::XB; i += 256 * 16) *reinterpret_cast<u32x4*>(xl + i) = u32x4{0u, 0u, 0u, 0u};
-  for (int i = t * 16; i < G::DB; i += 256 * 16) *reinterpret_cast<u32x4*>(dl + i) = u32x4{0u, 0u, 0u, 0u};
+  for (int i = t * 16; i < NP * XB; i += 256 * 16) *reinterpret_cast<u32x4*>(xl + i) = u32x4{0u, 0u, 0u, 0u};
+  for (int i = t * 16; i < NP * DB; i += 256 * 16) *reinterpret_cast<u32x4*>(dl + i) = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
 
-  u32x4 rgx[G::NLD], rgd[G::NLD];
-  auto load_rows = [&](u32x4 (&rg)[G::NLD], const bf16_t* __restrict__ src, int first, int nrows) {
+  G3Piece<T> rgx[G::NLD], rgd[G::NLD];
+  auto load_rows = [&](G3Piece<T> (&rg)[G::NLD], const T* __restrict__ src, int first, int nrows) {
 #pragma unroll
     for (int j = 0; j < G::NLD; ++j) {
       const int id = t + 256 * j;
@@ -355,20 +387,25 @@ __global__ __launch_bounds__(256) void g3bw_kernel(const bf16_t* __restrict__ dy
       const int ch = rem / G::XC, xc = rem - ch * G::XC;
       const int row = first + ri;
       const bool ok = id < nrows * SC * G::XC && row >= 0 && row < H;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(src + (ok ? (long)ch * HW + (long)row * W_ + xc * 8 : 0));
-      rg[j] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+      g3_load(rg[j], src + (ok ? (long)ch * HW + (long)row * W_ + xc * 8 : 0), ok);
     }
   };
-  // slot0: ring index of row `first` (x: (row - y0 + 1) % RX, dy: (row - y0) % RD); img: the image past its guard chunk
-  auto store_rows = [&](const u32x4 (&rg)[G::NLD], unsigned char* img, int slot0, int nslots, int nrows) {
+  // slot0: ring index of row `first` (x: (row - y0 + 1) % RX, dy: (row - y0) % RD); img: plane 0 of the image (past its guard
+  // chunk), pstride: bytes between planes
+  auto store_rows = [&](const G3Piece<T> (&rg)[G::NLD], unsigned char* img, int pstride, int slot0, int nslots, int nrows) {
 #pragma unroll
     for (int j = 0; j < G::NLD; ++j) {
       const int id = t + 256 * j;
       const int ri = id / (SC * G::XC), rem = id - ri * (SC * G::XC);
       const int ch = rem / G::XC, xc = rem - ch * G::XC;
       const int slot = (slot0 + ri) % nslots;
-      if (id < nrows * SC * G::XC)
-        *reinterpret_cast<u32x4*>(img + (slot * CPRW + (xc >> 2)) * CHB + ch * 64 + ((((unsigned)xc & 3u) ^ g3w_sw(ch)) << 4)) = rg[j];
+      if (id < nrows * SC * G::XC) {
+        u32x4 pl[NP];
+        g3_planes(rg[j], pl);
+        unsigned char* dst = img + (slot * CPRW + (xc >> 2)) * CHB + ch * 64 + ((((unsigned)xc & 3u) ^ g3w_sw(ch)) << 4);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x4*>(dst + q * pstride) = pl[q];
+      }
     }
   };
   unsigned char* dimg = dl + CHB;
@@ -393,10 +430,10 @@ __global__ __launch_bounds__(256) void g3bw_kernel(const bf16_t* __restrict__ dy
   for (int r = y0 - 1; r <= y0 + RI; r += RI) {
     const int nr = min(RI, y0 + RI - r + 1);
     load_rows(rgx, xg, r, nr);
-    store_rows(rgx, xl, r - y0 + 1, RX, nr);
+    store_rows(rgx, xl, XB, r - y0 + 1, RX, nr);
   }
   load_rows(rgd, dg, y0, RI);
-  store_rows(rgd, dimg, 0, G::RD, RI);
+  store_rows(rgd, dimg, DB, 0, G::RD, RI);
   __syncthreads();
 
   const int iters = RH / RI;
@@ -409,29 +446,44 @@ __global__ __launch_bounds__(256) void g3bw_kernel(const bf16_t* __restrict__ dy
     }
     for (int c = (CPG == 32 ? 0 : wave); c < G::NCH; c += (CPG == 32 ? 1 : 4)) {
       const int rowi = c / CPRW, cr = c - rowi * CPRW;
-      const unsigned char* dc = dimg + c * CHB;
-      const u32x4 d = *reinterpret_cast<const u32x4*>(dc + a_cur);
-      const unsigned dm = *reinterpret_cast<const unsigned*>(dc + a_prev);
-      const unsigned dn = *reinterpret_cast<const unsigned*>(dc + a_next);
-      bf16x8 af[3];
-      af[1] = __builtin_bit_cast(bf16x8, d);
-      // kx = 0 multiplies dy[q + 1], kx = 2 dy[q - 1]
-      af[0] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(d[1], d[0], 16), __builtin_amdgcn_alignbit(d[2], d[1], 16),
-                                               __builtin_amdgcn_alignbit(d[3], d[2], 16), __builtin_amdgcn_alignbit(dn, d[3], 16)});
-      af[2] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(d[0], dm, 16), __builtin_amdgcn_alignbit(d[1], d[0], 16),
-                                               __builtin_amdgcn_alignbit(d[2], d[1], 16), __builtin_amdgcn_alignbit(d[3], d[2], 16)});
+      bf16x8 af[NP][3];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const unsigned char* dc = dimg + q * DB + c * CHB;
+        const u32x4 d = *reinterpret_cast<const u32x4*>(dc + a_cur);
+        const unsigned dm = *reinterpret_cast<const unsigned*>(dc + a_prev);
+        const unsigned dn = *reinterpret_cast<const unsigned*>(dc + a_next);
+        af[q][1] = __builtin_bit_cast(bf16x8, d);
+        // kx = 0 multiplies dy[q + 1], kx = 2 dy[q - 1]
+        af[q][0] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(d[1], d[0], 16), __builtin_amdgcn_alignbit(d[2], d[1], 16),
+                                                    __builtin_amdgcn_alignbit(d[3], d[2], 16), __builtin_amdgcn_alignbit(dn, d[3], 16)});
+        af[q][2] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(d[0], dm, 16), __builtin_amdgcn_alignbit(d[1], d[0], 16),
+                                                    __builtin_amdgcn_alignbit(d[2], d[1], 16), __builtin_amdgcn_alignbit(d[3], d[2], 16)});
+      }
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int sx = (it * RI + rowi + ky) % RX;
-        const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(xl + (sx * CPRW + cr) * CHB + b_cur);
+        bf16x8 bfr[NP];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) acc[ky][kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kx], bfr, acc[ky][kx], 0, 0, 0);
+        for (int q = 0; q < NP; ++q) bfr[q] = *reinterpret_cast<const bf16x8*>(xl + q * XB + (sx * CPRW + cr) * CHB + b_cur);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          f32x4 cc = acc[ky][kx];
+          if constexpr (NP == 3) {   // the six plane products of the exact split, smallest terms first (splitgemm.hip)
+            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2][kx], bfr[0], cc, 0, 0, 0);
+            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][kx], bfr[2], cc, 0, 0, 0);
+            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][kx], bfr[1], cc, 0, 0, 0);
+            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][kx], bfr[0], cc, 0, 0, 0);
+            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][kx], bfr[1], cc, 0, 0, 0);
+          }
+          acc[ky][kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][kx], bfr[0], cc, 0, 0, 0);
+        }
       }
     }
     __syncthreads();   // every wave is done with the rows that the incoming ones replace
     if (more) {
-      store_rows(rgx, xl, (r0 + RI + 1 - y0 + 1) % RX, RX, RI);
-      store_rows(rgd, dimg, 0, G::RD, RI);
+      store_rows(rgx, xl, XB, (r0 + RI + 1 - y0 + 1) % RX, RX, RI);
+      store_rows(rgd, dimg, DB, 0, G::RD, RI);
     }
     __syncthreads();
   }
@@ -476,15 +528,16 @@ __global__ __launch_bounds__(256) void g3bw_kernel(const bf16_t* __restrict__ dy
   }
 }
 
-template <int CPG, int W_>
-int g3bw_launch(const bf16_t* dy, const bf16_t* x, float* dw, int NB, int C, int H, int RH, int accumulate, void* ws,
+template <int CPG, int W_, int NP, typename T>
+int g3bw_launch(const T* dy, const T* x, float* dw, int NB, int C, int H, int RH, int accumulate, void* ws,
                 size_t ws_bytes, hipStream_t st) {
-  using G = G3W<CPG, W_>;
+  using G = G3W<CPG, W_, NP>;
   const int slabs = C / G::SC, strips = H / RH;
   const long out_elems = (long)C * CPG * 9, parts = (long)NB * strips;
   WFAE_REQUIRE(ws && ws_bytes >= (size_t)parts * out_elems * sizeof(float), WFAE_ERR_WORKSPACE,
                "g3b_bwd_weight: workspace %zu < %zu", ws_bytes, (size_t)parts * out_elems * sizeof(float));
-  hipLaunchKernelGGL((g3bw_kernel<CPG, W_>), dim3(strips, slabs, NB), dim3(256), 0, st, dy, x, (float*)ws, C, H, RH, out_elems);
+  hipLaunchKernelGGL((g3bw_kernel<CPG, W_, NP, T>), dim3(strips, slabs, NB), dim3(256), 0, st, dy, x, (float*)ws, C, H, RH,
+                     out_elems);
   int rc = check_launch("g3bw");
   if (rc) return rc;
   return slab_reduce((const float*)ws, dw, nullptr, out_elems, 1, (int)parts, accumulate, st);
@@ -535,11 +588,38 @@ int wfae_g3b_bwd_weight_bf16(const uint16_t* dy, const uint16_t* x, float* dw, i
                "g3b_bwd_weight: bf16 activation storage needs wfae_set_matmul_precision(WFAE_PRECISION_BF16)");
   const int cpg = C / groups, rh = g3b_strip(cpg, H, W);
   hipStream_t st = (hipStream_t)stream;
-  if (cpg == 4) return g3bw_launch<4, 384>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
-  if (cpg == 8) return g3bw_launch<8, 192>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
-  if (cpg == 16) return g3bw_launch<16, 96>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
-  if (W == 48) return g3bw_launch<32, 48>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
-  return g3bw_launch<32, 24>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
+  if (cpg == 4) return g3bw_launch<4, 384, 1, bf16_t>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
+  if (cpg == 8) return g3bw_launch<8, 192, 1, bf16_t>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
+  if (cpg == 16) return g3bw_launch<16, 96, 1, bf16_t>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
+  if (W == 48) return g3bw_launch<32, 48, 1, bf16_t>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
+  return g3bw_launch<32, 24, 1, bf16_t>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
+}
+
+/* fp32 tensors: the same kernel with the exact three-plane split done once per value at the LDS store (six bf16 products
+ * per fp32 product, fp32 accuracy — csrc/splitgemm.hip).  Served for W <= 96 (16 / 32 channels per group in the model): three
+ * planes of full-width rows do not fit the LDS at W = 384, and at W = 192 they leave room for one block per CU, which measured
+ * slower than the fp32-MFMA kernel of dconv.hip (0.335 vs 0.305 ms at 64 channels; W <= 96: 0.155 -> 0.122, 0.179 -> 0.096,
+ * 0.077 -> 0.049 ms) */
+int wfae_g3b_f32_supported(int C, int H, int W, int groups, int wgrad) {
+  if (!wgrad) return 0;
+  if (!wfae_g3b_supported(C, H, W, groups) || W > 96) return 0;
+  return wfae::matmul_precision() == WFAE_PRECISION_FP32 && wfae::split_gemm_enabled() ? 1 : 0;
+}
+
+int wfae_g3b_bwd_weight(const float* dy, const float* x, float* dw, int NB, int C, int H, int W, int groups, int accumulate,
+                        void* ws, size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(dy && x && dw, WFAE_ERR_NULL_POINTER, "g3b_bwd_weight: null pointer");
+  WFAE_REQUIRE(NB > 0 && NB <= 65535 && C > 0 && H > 0 && W > 0 && groups > 0 && C % groups == 0, WFAE_ERR_BAD_SHAPE,
+               "g3b_bwd_weight: bad shape");
+  WFAE_REQUIRE(wfae_g3b_f32_supported(C, H, W, groups, 1), WFAE_ERR_UNSUPPORTED,
+               "g3b_bwd_weight: shape / mode not served (ask wfae_g3b_f32_supported; wfae_gconv3x3_bwd_weight serves every shape)");
+  WFAE_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0, WFAE_ERR_BAD_SHAPE,
+               "g3b_bwd_weight: tensors must be 16-byte aligned");
+  const int cpg = C / groups, rh = g3b_strip(cpg, H, W);
+  hipStream_t st = (hipStream_t)stream;
+  if (cpg == 16) return g3bw_launch<16, 96, 3, float>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
+  if (W == 48) return g3bw_launch<32, 48, 3, float>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
+  return g3bw_launch<32, 24, 3, float>(dy, x, dw, NB, C, H, rh, accumulate, ws, ws_bytes, st);
 }
 
 }  // extern "C"

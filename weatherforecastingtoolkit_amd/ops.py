@@ -1103,6 +1103,10 @@ def gconv3x3_bwd_weight(dy, x, dw, groups, accumulate=False):
     _chk(dw)
     nb, c, h, wd = x.shape
     ws = workspace()
+    if sfx == "" and _G3B and _lib.load().wfae_g3b_f32_supported(int(c), int(h), int(wd), int(groups), 1):
+        _call("wfae_g3b_bwd_weight", 2 * x.numel() * (c // groups) * 9, 2 * es * x.numel(), _p(dy), _p(x), _p(dw), nb, c, h, wd,
+              groups, int(accumulate), ws.data_ptr(), ws.numel(), _stream(), label="wfae_gconv3x3_bwd_weight", peak=PEAK_BF16_MFMA / 6)
+        return dw
     if sfx == "_bf16" and g3b_supported(c, h, wd, groups):
         _call("wfae_g3b_bwd_weight_bf16", 2 * x.numel() * (c // groups) * 9, 2 * es * x.numel(), _p(dy), _p(x), _p(dw), nb, c, h, wd,
               groups, int(accumulate), ws.data_ptr(), ws.numel(), _stream(), label="wfae_gconv3x3_bwd_weight", peak=PEAK_BF16_MFMA)

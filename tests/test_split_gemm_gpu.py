@@ -96,13 +96,15 @@ def test_split_gemm_refuses_unserved_shapes(ops, dev):
     assert _lib.load().wfae_wino_split_supported(1, 32, 256, 512, 96, 96) == 1
 
 
+@pytest.mark.parametrize("n", [200, 512, 600])
 @pytest.mark.parametrize("kind", [0, 1])
-def test_one_plane_gemm_is_the_bf16_operand_product(ops, dev, kind):
+def test_one_plane_gemm_is_the_bf16_operand_product(ops, dev, kind, n):
     """planes = 1: the h plane alone — the product of the bf16-rounded operands with fp32 accumulation ('medium'
-    precision with 2-byte operand storage): equal to an fp64 product of the rounded operands to fp32 accumulation error"""
+    precision with 2-byte operand storage): equal to an fp64 product of the rounded operands to fp32 accumulation error.
+    n >= 256 runs the 256-column blocks (64 x 128 wave tiles), 600 with a partial last block"""
     g = torch.Generator().manual_seed(11 + kind)
     a = torch.randn(3, 300, 96, generator=g).to(dev)
-    b = torch.randn(3, 96, 200, generator=g).to(dev)
+    b = torch.randn(3, 96, n, generator=g).to(dev)
     a1, b1 = ops.split_bf16x3(a, planes=1), ops.split_bf16x3(b if kind == 0 else b.transpose(1, 2).contiguous(), planes=1)
     assert a1.shape[0] == 1 and torch.equal(_planes_to_f32(a1)[0], a.bfloat16().float())
     c = ops.split_gemm(a1, b1, kind)

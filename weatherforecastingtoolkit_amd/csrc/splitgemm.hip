@@ -43,9 +43,12 @@ struct SgP {
   int mtiles;
 };
 
-constexpr int SBM = 256, SBN = 128, SBK = 32, SNT = 512;
+constexpr int SBM = 256, SBK = 32, SNT = 512;
 constexpr int A_PLANE_B = SBM * 64;
-constexpr int B_PLANE_B = SBN * 64;   // either image: 128 rows x 64 B or 32 k-rows x 256 B
+// block columns SBN = 64 NTB: 128 (wave tile 64 x 64, the three-plane form: registers) or 256 (wave tile 64 x 128, the
+// one-plane form: per K-step a block moves (256 + SBN) x 64 bytes from L2 into LDS for 256 x SBN x 32 MACs, and at one
+// product per tile the 128-column block needs 23 TB/s of that traffic chip-wide to keep the matrix pipe fed — 256 columns
+// need a third less)
 // NP planes per operand: 3 = the exact fp32 split (six products per tile), 1 = the h plane alone = bf16-rounded operands
 // with fp32 accumulation (torch's 'medium' matmul precision; one product per tile, operands 2 bytes per element)
 
@@ -76,9 +79,12 @@ __device__ __forceinline__ unsigned off_tr16(int k, int ch) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int BKIND, int NP = 3>
+template <int BKIND, int NP = 3, int NTB = 2>
 __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
   static_assert(NP == 3 || NP == 1, "three exact planes or the h plane alone");
+  static_assert(NTB == 2 || (NTB == 4 && NP == 1), "64 x 128 wave tiles (128 accumulators) only with one plane");
+  constexpr int SBN = 64 * NTB, NBL = SBN / 128;   // NBL: 128-column (row) pieces of the B stage a thread loads
+  constexpr int B_PLANE_B = SBN * 64;              // either image: SBN rows x 64 B, or NBL x (32 k-rows x 256 B)
   constexpr int A_STAGE_B = NP * A_PLANE_B;
   constexpr int STAGE_B = NP * (A_PLANE_B + B_PLANE_B);
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B];
@@ -118,32 +124,38 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
   unsigned a_off0 = 2u * (unsigned)(min(m0 + ar, p.M - 1) * p.lda + k_begin + ac * 8);
   unsigned a_off1 = 2u * (unsigned)(min(m0 + ar + 128, p.M - 1) * p.lda + k_begin + ac * 8);
   const unsigned a_dst = off_row16(ar, ac);
-  unsigned b_off, b_dst, b_step;
+  unsigned b_off[NBL], b_dst, b_step;
   if constexpr (BKIND == 0) {
     const int bk = t >> 4, bch = t & 15;
-    int n = n0 + bch * 8;
-    if (n >= p.N) n = p.N - 8;
-    b_off = 2u * (unsigned)((k_begin + bk) * p.ldb + n);
-    b_dst = off_tr16(bk, bch);
+#pragma unroll
+    for (int h = 0; h < NBL; ++h) {
+      int n = n0 + 128 * h + bch * 8;
+      if (n >= p.N) n = p.N - 8;
+      b_off[h] = 2u * (unsigned)((k_begin + bk) * p.ldb + n);
+    }
+    b_dst = off_tr16(bk, bch);   // + h * 32 * 256: one k-row image per 128 columns
     b_step = 2u * (unsigned)(SBK * p.ldb);
   } else {
-    b_off = 2u * (unsigned)(min(n0 + ar, p.N - 1) * p.ldb + k_begin + ac * 8);
-    b_dst = a_dst;
+#pragma unroll
+    for (int h = 0; h < NBL; ++h) b_off[h] = 2u * (unsigned)(min(n0 + ar + 128 * h, p.N - 1) * p.ldb + k_begin + ac * 8);
+    b_dst = a_dst;               // + h * 128 * 64
     b_step = 2u * SBK;
   }
-  u32x4 ra[NP][2], rb[NP];
+  u32x4 ra[NP][2], rb[NP][NBL];
   auto load_global = [&]() {
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) {
       ra[pl][0] = *reinterpret_cast<const u32x4*>(Apl[pl] + a_off0);
       ra[pl][1] = *reinterpret_cast<const u32x4*>(Apl[pl] + a_off1);
-      rb[pl] = *reinterpret_cast<const u32x4*>(Bpl[pl] + b_off);
+#pragma unroll
+      for (int h = 0; h < NBL; ++h) rb[pl][h] = *reinterpret_cast<const u32x4*>(Bpl[pl] + b_off[h]);
     }
   };
   auto advance = [&](bool more) {
     a_off0 += more ? 2u * SBK : 0u;
     a_off1 += more ? 2u * SBK : 0u;
-    b_off += more ? b_step : 0u;
+#pragma unroll
+    for (int h = 0; h < NBL; ++h) b_off[h] += more ? b_step : 0u;
   };
   auto store_lds = [&](int buf) {
     unsigned char* s = smem + buf * STAGE_B;
@@ -151,25 +163,29 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
     for (int pl = 0; pl < NP; ++pl) {
       *reinterpret_cast<u32x4*>(s + pl * A_PLANE_B + a_dst) = ra[pl][0];
       *reinterpret_cast<u32x4*>(s + pl * A_PLANE_B + a_dst + 128 * 64) = ra[pl][1];
-      *reinterpret_cast<u32x4*>(s + A_STAGE_B + pl * B_PLANE_B + b_dst) = rb[pl];
+#pragma unroll
+      for (int h = 0; h < NBL; ++h) *reinterpret_cast<u32x4*>(s + A_STAGE_B + pl * B_PLANE_B + b_dst + h * 128 * 64) = rb[pl][h];
     }
   };
 
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * (SBN / 2);
   const int r15 = lane & 15, g4 = lane >> 4, tq = r15 >> 2, tp = r15 & 3;
   const unsigned a_rd = off_row16(wm0 + r15, g4);   // + (32 half + 16 i) * 64: the swizzle only sees (r15 >> 2) & 3
   const unsigned b_rd_row = off_row16(wn0 + r15, g4);
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][2 * NTB];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2 * NTB; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[i][j][q] = 0.f;
 
   struct Grp {
     bf16x8 v[2][NP];
+  };
+  struct GrpB {
+    bf16x8 v[NTB][NP];
   };
   auto read_a = [&](Grp& f, int buf, int half) {
     const unsigned char* s = smem + buf * STAGE_B;
@@ -179,21 +195,22 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
       for (int pl = 0; pl < NP; ++pl)
         f.v[i][pl] = *reinterpret_cast<const bf16x8*>(s + pl * A_PLANE_B + a_rd + (32 * half + 16 * i) * 64);
   };
-  auto read_b = [&](Grp& f, int buf, int half) {
+  auto read_b = [&](GrpB& f, int buf, int half) {
     const unsigned char* s = smem + buf * STAGE_B + A_STAGE_B;
     if constexpr (BKIND == 0) {
       // lane 4q+pp of the 16-lane group g4 addresses k-row q, columns 4pp..4pp+3 of a 4 (k) x 16 (n) block; the group's
       // fragment is k = 8 g4 .. 8 g4 + 7: two blocks
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NTB; ++j)
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
           s16x4 part[2];
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf) {
             const int row = 8 * g4 + 4 * hf + tq;
-            const int ch = ((wn0 + 32 * half + 16 * j) >> 3) + (tp >> 1);
-            const unsigned off = off_tr16(row, ch) + 8u * (tp & 1);
+            const int col = wn0 + 16 * NTB * half + 16 * j;   // first column of the tile inside the block
+            const int ch = ((col & 127) >> 3) + (tp >> 1);
+            const unsigned off = (unsigned)((col >> 7) * 32 * 256) + off_tr16(row, ch) + 8u * (tp & 1);
             part[hf] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (s16x4 __attribute__((address_space(3)))*)(s + pl * B_PLANE_B + off));
           }
@@ -202,18 +219,18 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
         }
     } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NTB; ++j)
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
-          f.v[j][pl] = *reinterpret_cast<const bf16x8*>(s + pl * B_PLANE_B + b_rd_row + (32 * half + 16 * j) * 64);
+          f.v[j][pl] = *reinterpret_cast<const bf16x8*>(s + pl * B_PLANE_B + b_rd_row + (16 * NTB * half + 16 * j) * 64);
     }
   };
-  auto quadrant = [&](const Grp& a, const Grp& b, int ah, int bh) {
+  auto quadrant = [&](const Grp& a, const GrpB& b, int ah, int bh) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        f32x4 c = acc[2 * ah + i][2 * bh + j];   // smallest terms first
+      for (int j = 0; j < NTB; ++j) {
+        f32x4 c = acc[2 * ah + i][NTB * bh + j];   // smallest terms first
         if constexpr (NP == 3) {
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v[i][2], b.v[j][0], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v[i][0], b.v[j][2], c, 0, 0, 0);
@@ -222,16 +239,17 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v[i][0], b.v[j][1], c, 0, 0, 0);
         }
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v[i][0], b.v[j][0], c, 0, 0, 0);
-        acc[2 * ah + i][2 * bh + j] = c;
+        acc[2 * ah + i][NTB * bh + j] = c;
       }
   };
 
   constexpr int NQ = 4 * (NP == 3 ? 6 : 1);            // MFMAs per quadrant
   constexpr int RB = 2 * NP * (BKIND == 0 ? 2 : 1);    // LDS reads of a B group
   constexpr int RA = 2 * NP;
-  Grp A0, A1, B0, B1;
+  Grp A0, A1;
+  GrpB B0, B1;
   // one K-step; on entry A0 = A_lo, bx = B_lo of K-step st (stage cur); on exit A0 = A_lo, by_ = B_lo of K-step st + 1
-  auto iter = [&](int st, Grp& bx, Grp& by_) {
+  auto iter = [&](int st, GrpB& bx, GrpB& by_) {
     const int cur = st & 1;
     read_b(by_, cur, 1);
     read_a(A1, cur, 1);
@@ -293,7 +311,7 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
     for (int q = 0; q < 4; ++q) {
       const int row = m0 + wm0 + 16 * i + 4 * g4 + q;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 2 * NTB; ++j) {
         const int col = n0 + wn0 + 16 * j + r15;
         if (row < p.M && col < p.N) Cb[(long)row * p.ldc + col] = acc[i][j][q];
       }
@@ -315,8 +333,14 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
 template <int BKIND>
 int launch_sgemm3(SgP& p, int planes, int batches, int splits, hipStream_t st, const char* what) {
   p.mtiles = cdiv(p.M, SBM);
-  const long tiles = (long)p.mtiles * cdiv(p.N, SBN);
+  // one plane: 256-column blocks (round 3, same box: the Winograd products of a 'medium' step 13.5 -> 10.7 ms, step 105.4 -> 100.8)
+  const bool wide = planes == 1 && p.N >= 256;
+  const long tiles = (long)p.mtiles * cdiv(p.N, wide ? 256 : 128);
   WFAE_REQUIRE(tiles < (1l << 31) && batches <= 65535 && splits <= 65535, WFAE_ERR_BAD_SHAPE, "%s: grid too large", what);
+  if (wide) {
+    hipLaunchKernelGGL((sgemm3_kernel<BKIND, 1, 4>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
+    return check_launch(what);
+  }
   // (An LDS-DMA form of the loaders — global_load_lds_dwordx4, no staging registers or ds_write — measured equal on the
   // Winograd shapes in round 2, 28.96 vs 28.57 ms, and was removed: the operand path is not what the waves wait for.)
   if (planes == 1) hipLaunchKernelGGL((sgemm3_kernel<BKIND, 1>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);

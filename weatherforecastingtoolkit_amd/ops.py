@@ -36,8 +36,9 @@ PEAK_BF16_MFMA = 2500.0e12 # dense bf16
 
 
 def profile_stop():
-    """-> {name: (calls, total_ms, flops, bytes, ideal_ms)}; synchronises the device.  ideal_ms = sum over the launches
-    of max(algorithmic bytes / HBM peak, algorithmic FLOPs / peak of the matrix instruction that launch runs on)"""
+    """-> {name: (calls, total_ms, flops, bytes, ideal_ms, mfma_ms, hbm_ms)}; synchronises the device.  ideal_ms = sum over
+    the launches of max(algorithmic bytes / HBM peak, algorithmic FLOPs / peak of the matrix instruction that launch runs on);
+    mfma_ms / hbm_ms: the two terms summed on their own (which roof binds the label's launches as a whole)"""
     global _prof
     rec, _prof = _prof, None
     torch.cuda.synchronize()
@@ -45,7 +46,8 @@ def profile_stop():
     for k, lst in (rec or {}).items():
         ms = sum(a.elapsed_time(b) for a, b, _, _, _ in lst)
         out[k] = (len(lst), ms, sum(f for _, _, f, _, _ in lst), sum(b for _, _, _, b, _ in lst),
-                  1e3 * sum(max(b / PEAK_HBM, f / pk) for _, _, f, b, pk in lst))
+                  1e3 * sum(max(b / PEAK_HBM, f / pk) for _, _, f, b, pk in lst),
+                  1e3 * sum(f / pk for _, _, f, _, pk in lst), 1e3 * sum(b / PEAK_HBM for _, _, _, b, _ in lst))
     return out
 
 

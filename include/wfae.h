@@ -379,6 +379,11 @@ int wfae_g3b_bwd_weight_bf16(const uint16_t* dy, const uint16_t* x, float* dw, i
  * the current mode (fp32 precision with the split switch on; weight gradient at W <= 96 only: three planes of full-width rows exceed
  * the LDS at W = 384 and allow one block per CU at W = 192, which measured slower than wfae_gconv3x3_bwd_weight's kernel). */
 int wfae_g3b_f32_supported(int C, int H, int W, int groups, int wgrad);
+/* forward (transposed = 0) / data gradient (1) on fp32 tensors: (channels per group, W) = (16, 96) is what
+ * wfae_g3b_f32_supported(…, 0) reports (faster than wfae_gconv3x3_fwd's kernel there); (8, 192) is accepted as well but measured
+ * slower.  Same arguments as wfae_gconv3x3_fwd; workspace >= 3 x the bf16 form's */
+int wfae_g3b_fwd(const float* x, const float* w, float* y, int NB, int C, int H, int W, int groups, int transposed, void* ws,
+                 size_t ws_bytes, wfae_stream_t stream);
 int wfae_g3b_bwd_weight(const float* dy, const float* x, float* dw, int NB, int C, int H, int W, int groups, int accumulate,
                         void* ws, size_t ws_bytes, wfae_stream_t stream);
 int wfae_bn_act_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* gamma, const float* scale, const float* shift,

@@ -37,26 +37,63 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int CPG, int TPR, int W_>
+// eight consecutive pixels of one channel row in registers: bf16 tensors one 16-byte piece, fp32 tensors two
+template <typename T> struct G3Piece;
+template <> struct G3Piece<bf16_t> { u32x4 v; };
+template <> struct G3Piece<float> { u32x4 lo, hi; };
+__device__ __forceinline__ void g3_load(G3Piece<bf16_t>& r, const bf16_t* p, bool ok) {
+  const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+  r.v = ok ? v : u32x4{0u, 0u, 0u, 0u};
+}
+__device__ __forceinline__ void g3_load(G3Piece<float>& r, const float* p, bool ok) {
+  const u32x4 a = *reinterpret_cast<const u32x4*>(p), b = *reinterpret_cast<const u32x4*>(p + 4);
+  r.lo = ok ? a : u32x4{0u, 0u, 0u, 0u};
+  r.hi = ok ? b : u32x4{0u, 0u, 0u, 0u};
+}
+// planes of the piece as MFMA-ready 16-byte rows: bf16 tensors the value itself, fp32 tensors h + m + l == x (common.h split3)
+__device__ __forceinline__ void g3_planes(const G3Piece<bf16_t>& r, u32x4 (&pl)[1]) { pl[0] = r.v; }
+__device__ __forceinline__ void g3_planes(const G3Piece<float>& r, u32x4 (&pl)[3]) {
+  unsigned short h[8], m[8], l[8];
+  const unsigned u[8] = {r.lo[0], r.lo[1], r.lo[2], r.lo[3], r.hi[0], r.hi[1], r.hi[2], r.hi[3]};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) split3(__uint_as_float(u[i]), h[i], m[i], l[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pl[0][i] = (unsigned)h[2 * i] | ((unsigned)h[2 * i + 1] << 16);
+    pl[1][i] = (unsigned)m[2 * i] | ((unsigned)m[2 * i + 1] << 16);
+    pl[2][i] = (unsigned)l[2 * i] | ((unsigned)l[2 * i + 1] << 16);
+  }
+}
+
+
+template <int CPG, int TPR, int W_, int NP, int TPW, typename T>
 struct G3B {
   static constexpr int SC = CPG == 32 ? 32 : 16;   // channels of a slab
   static constexpr int MT = SC / 16;               // 16-row tiles of output channels
   static constexpr int KS = CPG == 32 ? 3 : 2;     // 32-deep K-steps per kx
-  static constexpr int RI = 24 / TPR;              // rows per step: 24 tiles of 16 pixels, 6 per wave
+  static constexpr int RI = 4 * TPW / TPR;         // rows per step: TPW tiles of 16 pixels per wave, four waves
   static constexpr int P = 16 * TPR;               // LDS row pitch in pixels (>= W_; the rest stays zero)
-  static constexpr int R = 2 * RI + 2;             // ring rows
+  // ring rows: bf16 tensors keep the incoming rows in their own slots (one barrier per step); fp32 tensors (three planes:
+  // 3x the bytes) overwrite the rows that just died (two barriers per step)
+  static constexpr bool TWO_BAR = NP != 1;
+  static constexpr int R = TWO_BAR ? RI + 2 : 2 * RI + 2;
   static constexpr int RS = P * 2;                 // bytes
   static constexpr int CS0 = R * RS;
   static constexpr int CS = (CS0 / 32) % 2 ? CS0 : CS0 + 32;   // odd multiple of 32 bytes
-  static constexpr int RING_B = SC * CS;
-  static constexpr int OB_RS = 208;                // 96 pixels x 2 bytes + 16: the four lane groups write different bank octets
+  static constexpr int PLANE_B = SC * CS;
+  static constexpr int RING_B = NP * PLANE_B;
+  static constexpr int ES = sizeof(T);
+  static constexpr int OB_RS = TPW * 16 * ES + 16; // + 16: the four lane groups write different bank windows
   static constexpr int OB_B = MT * 16 * OB_RS;     // per wave
-  static constexpr int XC = W_ / 8;                // 16-byte pieces per channel row
+  static constexpr int PPT = ES;                   // 16-byte pieces of a tile row: 2 (bf16) / 4 (fp32)
+  static constexpr int PPR = TPW * PPT;            // ... of a wave's run
+  static constexpr int XC = W_ / 8;                // 8-pixel pieces per channel row
   static constexpr int CH_ROW = SC * XC;
   static constexpr int NLD = (RI * CH_ROW + 255) / 256;
-  static constexpr int SEG = TPR < 6 ? TPR : 6;    // tiles of one row in a wave's run
-  static constexpr int NSEG = 6 / SEG;
-  static_assert(24 % TPR == 0 && W_ % 8 == 0 && W_ <= P && P - W_ < 16, "geometry");
+  static constexpr int SEG = TPR < TPW ? TPR : TPW;   // tiles of one row in a wave's run
+  static constexpr int NSEG = TPW / SEG;
+  static_assert((4 * TPW) % TPR == 0 && RI >= 1 && W_ % 8 == 0 && W_ <= P && P - W_ < 16, "geometry");
+  static_assert(RING_B + 4 * OB_B <= 160 * 1024, "LDS");
 };
 
 __device__ __forceinline__ float dpp_shr1(float cur, float prev) {   // lane i <- cur[i - 1], lane 0 <- prev[15] (16-lane rows)
@@ -67,11 +104,15 @@ __device__ __forceinline__ float dpp_shl1(float cur, float next) {   // lane i <
   const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(next), 0x12f, 0xf, 0xf, false);          // row_ror:15
   return __int_as_float(__builtin_amdgcn_update_dpp(t, __float_as_int(cur), 0x101, 0xf, 0xf, false));  // row_shl:1
 }
+__device__ __forceinline__ void g3_put(bf16_t* p, float v) { *p = (bf16_t)(pack_bf16(v, 0.f) & 0xffffu); }
+__device__ __forceinline__ void g3_put(float* p, float v) { *p = v; }
 
-template <int CPG, int TPR, int W_>
-__global__ __launch_bounds__(256) void g3b_kernel(const bf16_t* __restrict__ x, const bf16x8* __restrict__ wpk,
-                                                  bf16_t* __restrict__ y, int C, int H, int RH) {
-  using G = G3B<CPG, TPR, W_>;
+// T = bf16_t, NP = 1: bf16 tensors.  T = float, NP = 3: fp32 tensors, every value split exactly into three bf16 planes at the
+// LDS store and the weights likewise, six plane products per fp32 product (the arithmetic of splitgemm.hip: fp32 accuracy)
+template <int CPG, int TPR, int W_, int NP, int TPW, typename T>
+__global__ __launch_bounds__(256) void g3b_kernel(const T* __restrict__ x, const bf16x8* __restrict__ wpk,
+                                                  T* __restrict__ y, int C, int H, int RH) {
+  using G = G3B<CPG, TPR, W_, NP, TPW, T>;
   constexpr int SC = G::SC, MT = G::MT, KS = G::KS, RI = G::RI, R = G::R, RS = G::RS, CS = G::CS;
   __shared__ __attribute__((aligned(16))) unsigned char ring[G::RING_B];
   __shared__ __attribute__((aligned(16))) unsigned char obuf[4 * G::OB_B];
@@ -79,8 +120,8 @@ __global__ __launch_bounds__(256) void g3b_kernel(const bf16_t* __restrict__ x, 
   const int strip = blockIdx.x, vg = blockIdx.y, n = blockIdx.z;
   const int y0 = strip * RH;
   const long HW = (long)H * W_;
-  const bf16_t* __restrict__ xg = x + ((long)n * C + (long)vg * SC) * HW;
-  bf16_t* __restrict__ yg = y + ((long)n * C + (long)vg * SC) * HW;
+  const T* __restrict__ xg = x + ((long)n * C + (long)vg * SC) * HW;
+  T* __restrict__ yg = y + ((long)n * C + (long)vg * SC) * HW;
 
   if constexpr (G::P != W_) {   // pad columns are never written again
     for (int i = t * 16; i < G::RING_B; i += 256 * 16) *reinterpret_cast<u32x4*>(ring + i) = u32x4{0u, 0u, 0u, 0u};
@@ -88,16 +129,19 @@ __global__ __launch_bounds__(256) void g3b_kernel(const bf16_t* __restrict__ x, 
   }
 
   // ---- weights: MFMA A fragments of this slab, in registers for the whole strip
-  bf16x8 afr[3][KS][MT];
+  bf16x8 afr[3][KS][MT][NP];
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) afr[kx][s][mt] = wpk[((((long)vg * 3 + kx) * KS + s) * MT + mt) * 64 + lane];
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+          afr[kx][s][mt][pl] = wpk[(((((long)vg * 3 + kx) * KS + s) * MT + mt) * NP + pl) * 64 + lane];
 
-  // ---- staging: rows [first, first + nrows) of the slab, 16-byte pieces, as they lie in memory; rows outside the image are zero
-  u32x4 rg[G::NLD];
+  // ---- staging: rows [first, first + nrows) of the slab, 8-pixel pieces, as they lie in memory; rows outside the image are zero
+  G3Piece<T> rg[G::NLD];
   auto load_rows = [&](int first, int nrows) {
 #pragma unroll
     for (int j = 0; j < G::NLD; ++j) {
@@ -106,8 +150,7 @@ __global__ __launch_bounds__(256) void g3b_kernel(const bf16_t* __restrict__ x, 
       const int ci = rem / G::XC, xc = rem - ci * G::XC;
       const int row = first + ri;
       const bool ok = id < nrows * G::CH_ROW && row >= 0 && row < H;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(xg + (ok ? (long)ci * HW + (long)row * W_ + xc * 8 : 0));
-      rg[j] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+      g3_load(rg[j], xg + (ok ? (long)ci * HW + (long)row * W_ + xc * 8 : 0), ok);
     }
   };
   auto store_rows = [&](int first, int nrows) {
@@ -117,7 +160,12 @@ __global__ __launch_bounds__(256) void g3b_kernel(const bf16_t* __restrict__ x, 
       const int ri = id / G::CH_ROW, rem = id - ri * G::CH_ROW;
       const int ci = rem / G::XC, xc = rem - ci * G::XC;
       const int slot = (first + ri - y0 + 1) % R;
-      if (id < nrows * G::CH_ROW) *reinterpret_cast<u32x4*>(ring + ci * CS + slot * RS + xc * 16) = rg[j];
+      if (id < nrows * G::CH_ROW) {
+        u32x4 pl[NP];
+        g3_planes(rg[j], pl);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x4*>(ring + q * G::PLANE_B + ci * CS + slot * RS + xc * 16) = pl[q];
+      }
     }
   };
 
@@ -128,24 +176,36 @@ __global__ __launch_bounds__(256) void g3b_kernel(const bf16_t* __restrict__ x, 
   const bool ky_hi = (g4 >> 1) != 0;   // 16-channel slabs: this lane group takes the second tap row of a step
 
   // B fragments of the tile (row index `ridx` into the ring = row - y0 + 1 of tap row 0, column block xb)
-  auto read_b = [&](bf16x8 (&b)[KS], int ridx, int xb) {
+  auto read_b = [&](bf16x8 (&b)[KS][NP], int ridx, int xb) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       int ky_lo = CPG == 32 ? s : 2 * s, ky_up = CPG == 32 ? s : (2 * s + 1 > 2 ? 2 : 2 * s + 1);
       const unsigned rlo = (unsigned)(((ridx + ky_lo) % R) * RS), rup = (unsigned)(((ridx + ky_up) % R) * RS);
       const unsigned roff = CPG == 32 ? rlo : (ky_hi ? rup : rlo);
-      const unsigned char* a = ring + lane_off + roff + xb * 32;
-      const s16x4 p0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a));
-      const s16x4 p1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a + 8 * CS));
-      b[s] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) {
+        const unsigned char* a = ring + pl * G::PLANE_B + lane_off + roff + xb * 32;
+        const s16x4 p0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a));
+        const s16x4 p1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a + 8 * CS));
+        b[s][pl] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
     }
   };
-  auto partial = [&](f32x4 (&acc)[MT], const bf16x8 (&b)[KS], int kx) {
+  auto partial = [&](f32x4 (&acc)[MT], const bf16x8 (&b)[KS][NP], int kx) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < KS; ++s) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kx][s][mt], b[s], c, 0, 0, 0);
+      for (int s = 0; s < KS; ++s) {
+        if constexpr (NP == 3) {   // smallest terms first
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kx][s][mt][2], b[s][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kx][s][mt][0], b[s][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kx][s][mt][1], b[s][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kx][s][mt][1], b[s][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kx][s][mt][0], b[s][1], c, 0, 0, 0);
+        }
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kx][s][mt][0], b[s][0], c, 0, 0, 0);
+      }
       acc[mt] = c;
     }
   };
@@ -167,11 +227,11 @@ __global__ __launch_bounds__(256) void g3b_kernel(const bf16_t* __restrict__ x, 
 
 #pragma unroll
     for (int sg = 0; sg < G::NSEG; ++sg) {
-      const int idx0 = 6 * wave + sg * G::SEG;
+      const int idx0 = TPW * wave + sg * G::SEG;
       const int rowi = idx0 / TPR, xa = idx0 - rowi * TPR;   // row inside the step, first column block
       const int ridx = it * RI + rowi;                        // ring index of tap row 0 (input row r0 + rowi - 1)
       f32x4 prev0[MT], pend[MT], pend2[MT];
-      bf16x8 b[KS];
+      bf16x8 b[KS][NP];
       // the P_0 of the block left of the run feeds pixel 0 of the first tile (zero at the image border)
       if (xa > 0) {
         read_b(b, ridx, xa - 1);
@@ -202,8 +262,7 @@ __global__ __launch_bounds__(256) void g3b_kernel(const bf16_t* __restrict__ x, 
             for (int q = 0; q < 4; ++q) {
               const float v = pend[mt][q] + dpp_shl1(pend2[mt][q], p2[mt][q]);
               const int oc = mt * 16 + 4 * g4 + q;
-              *reinterpret_cast<bf16_t*>(ob + oc * G::OB_RS + ((sg * G::SEG + i - 1) * 16 + i16) * 2) =
-                  (bf16_t)(pack_bf16(v, 0.f) & 0xffffu);
+              g3_put(reinterpret_cast<T*>(ob + oc * G::OB_RS) + (sg * G::SEG + i - 1) * 16 + i16, v);
             }
         }
         if (inside) {
@@ -218,27 +277,31 @@ __global__ __launch_bounds__(256) void g3b_kernel(const bf16_t* __restrict__ x, 
       }
     }
 
-    // ---- the wave's 6 tiles leave as 16-byte pieces: MT x 16 channel rows x 12 pieces
+    // ---- the wave's tiles leave as 16-byte pieces: MT x 16 channel rows x PPR pieces
 #pragma unroll
-    for (int j = 0; j < 3 * MT; ++j) {
+    for (int j = 0; j < (MT * 16 * G::PPR + 63) / 64; ++j) {
       const int id = lane + 64 * j;
-      const int orow = id / 12, ch = id - orow * 12;
-      const int idx = 6 * wave + (ch >> 1);
+      const int orow = id / G::PPR, ch = id - orow * G::PPR;
+      const int idx = TPW * wave + ch / G::PPT;
       const int rowi = idx / TPR, xb = idx - rowi * TPR;
-      const int px = xb * 16 + 8 * (ch & 1);
-      const u32x4 v = *reinterpret_cast<const u32x4*>(ob + orow * G::OB_RS + ch * 16);
-      if (px < W_) *reinterpret_cast<u32x4*>(yg + (long)orow * HW + (long)(r0 + rowi) * W_ + px) = v;
+      const int px = xb * 16 + (16 / G::ES) * (ch % G::PPT);
+      if (id < MT * 16 * G::PPR) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ob + orow * G::OB_RS + ch * 16);
+        if (px < W_) *reinterpret_cast<u32x4*>(yg + (long)orow * HW + (long)(r0 + rowi) * W_ + px) = v;
+      }
     }
 
+    if constexpr (G::TWO_BAR) __syncthreads();   // every wave is done with the rows that the incoming ones replace
     if (more) store_rows(r0 + RI + 1, RI);
     __syncthreads();
   }
 }
 
-// wpk[((((vg * 3 + kx) * KS + s) * MT + mt) * 64 + lane) * 8 + j]: A[m = lane & 15][k = 8 (lane >> 4) + j] of the MFMA
+// wpk[(((((vg * 3 + kx) * KS + s) * MT + mt) * NP + plane) * 64 + lane) * 8 + j]: A[m = lane & 15][k = 8 (lane >> 4) + j]
 //   forward:    out channel co, in channel ci:  w[co][ci - group base][ky][kx]
 //   transposed: (data gradient) the kernel's "out" channel is the convolution's input channel: w[ci][co - group base][2 - ky][2 - kx]
-template <int CPG>
+// NP = 1: the weight rounded to bf16 ('medium' operands); NP = 3: its exact three-plane split
+template <int CPG, int NP>
 __global__ void g3b_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ wpk, int C, int transposed) {
   constexpr int SC = CPG == 32 ? 32 : 16, MT = SC / 16, KS = CPG == 32 ? 3 : 2;
   const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -246,6 +309,7 @@ __global__ void g3b_pack_kernel(const float* __restrict__ w, bf16_t* __restrict_
   if (i0 >= total) return;
   const int j = (int)(i0 & 7), lane = (int)((i0 >> 3) & 63);
   long r = i0 >> 9;
+  const long frag = r;   // ((vg * 3 + kx) * KS + s) * MT + mt
   const int mt = (int)(r % MT); r /= MT;
   const int s = (int)(r % KS); r /= KS;
   const int kx = (int)(r % 3);
@@ -260,22 +324,27 @@ __global__ void g3b_pack_kernel(const float* __restrict__ w, bf16_t* __restrict_
     v = transposed ? w[((long)cin * CPG + (co - gb)) * 9 + (2 - ky) * 3 + (2 - kx)]
                    : w[((long)co * CPG + (cin - gb)) * 9 + ky * 3 + kx];
   }
-  wpk[i0] = (bf16_t)(pack_bf16(v, 0.f) & 0xffffu);
+  bf16_t pl[3];
+  if constexpr (NP == 1) pl[0] = (bf16_t)(pack_bf16(v, 0.f) & 0xffffu);
+  else split3(v, pl[0], pl[1], pl[2]);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) wpk[((frag * NP + p) * 64 + lane) * 8 + j] = pl[p];
 }
 
-template <int CPG, int TPR, int W_>
-int g3b_launch(const bf16_t* x, const float* w, bf16_t* y, int NB, int C, int H, int RH, int transposed, void* ws,
-               size_t ws_bytes, hipStream_t st) {
-  using G = G3B<CPG, TPR, W_>;
+template <int CPG, int TPR, int W_, int NP, int TPW, typename T>
+int g3b_launch(const T* x, const float* w, T* y, int NB, int C, int H, int RH, int transposed, void* ws, size_t ws_bytes,
+               hipStream_t st) {
+  using G = G3B<CPG, TPR, W_, NP, TPW, T>;
   const int slabs = C / G::SC;
   const long frag_elems = (long)slabs * 3 * G::KS * G::MT * 64 * 8;
-  WFAE_REQUIRE(ws && ws_bytes >= (size_t)frag_elems * 2, WFAE_ERR_WORKSPACE, "g3b_fwd: workspace %zu < %zu", ws_bytes,
-               (size_t)frag_elems * 2);
-  hipLaunchKernelGGL((g3b_pack_kernel<CPG>), dim3((unsigned)cdiv(frag_elems, 256)), dim3(256), 0, st, w, (bf16_t*)ws, C,
+  WFAE_REQUIRE(ws && ws_bytes >= (size_t)frag_elems * 2 * NP, WFAE_ERR_WORKSPACE, "g3b_fwd: workspace %zu < %zu", ws_bytes,
+               (size_t)frag_elems * 2 * NP);
+  hipLaunchKernelGGL((g3b_pack_kernel<CPG, NP>), dim3((unsigned)cdiv(frag_elems, 256)), dim3(256), 0, st, w, (bf16_t*)ws, C,
                      transposed);
   int rc = check_launch("g3b_pack");
   if (rc) return rc;
-  hipLaunchKernelGGL((g3b_kernel<CPG, TPR, W_>), dim3(H / RH, slabs, NB), dim3(256), 0, st, x, (const bf16x8*)ws, y, C, H, RH);
+  hipLaunchKernelGGL((g3b_kernel<CPG, TPR, W_, NP, TPW, T>), dim3(H / RH, slabs, NB), dim3(256), 0, st, x, (const bf16x8*)ws, y,
+                     C, H, RH);
   return check_launch("g3b");
 }
 
@@ -331,34 +400,6 @@ struct G3W {
 };
 
 __device__ __forceinline__ unsigned g3w_sw(int ch) { return (unsigned)((0x78 >> (((ch >> 2) & 3) << 1)) & 3); }
-
-// eight consecutive pixels of one channel row in registers: bf16 tensors one 16-byte piece, fp32 tensors two
-template <typename T> struct G3Piece;
-template <> struct G3Piece<bf16_t> { u32x4 v; };
-template <> struct G3Piece<float> { u32x4 lo, hi; };
-__device__ __forceinline__ void g3_load(G3Piece<bf16_t>& r, const bf16_t* p, bool ok) {
-  const u32x4 v = *reinterpret_cast<const u32x4*>(p);
-  r.v = ok ? v : u32x4{0u, 0u, 0u, 0u};
-}
-__device__ __forceinline__ void g3_load(G3Piece<float>& r, const float* p, bool ok) {
-  const u32x4 a = *reinterpret_cast<const u32x4*>(p), b = *reinterpret_cast<const u32x4*>(p + 4);
-  r.lo = ok ? a : u32x4{0u, 0u, 0u, 0u};
-  r.hi = ok ? b : u32x4{0u, 0u, 0u, 0u};
-}
-// planes of the piece as MFMA-ready 16-byte rows: bf16 tensors the value itself, fp32 tensors h + m + l == x (common.h split3)
-__device__ __forceinline__ void g3_planes(const G3Piece<bf16_t>& r, u32x4 (&pl)[1]) { pl[0] = r.v; }
-__device__ __forceinline__ void g3_planes(const G3Piece<float>& r, u32x4 (&pl)[3]) {
-  unsigned short h[8], m[8], l[8];
-  const unsigned u[8] = {r.lo[0], r.lo[1], r.lo[2], r.lo[3], r.hi[0], r.hi[1], r.hi[2], r.hi[3]};
-#pragma unroll
-  for (int i = 0; i < 8; ++i) split3(__uint_as_float(u[i]), h[i], m[i], l[i]);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    pl[0][i] = (unsigned)h[2 * i] | ((unsigned)h[2 * i + 1] << 16);
-    pl[1][i] = (unsigned)m[2 * i] | ((unsigned)m[2 * i + 1] << 16);
-    pl[2][i] = (unsigned)l[2 * i] | ((unsigned)l[2 * i + 1] << 16);
-  }
-}
 
 template <int CPG, int W_, int NP, typename T>
 __global__ __launch_bounds__(256) void g3bw_kernel(const T* __restrict__ dy, const T* __restrict__ x,
@@ -568,11 +609,11 @@ int wfae_g3b_fwd_bf16(const uint16_t* x, const float* w, uint16_t* y, int NB, in
                "g3b_fwd: bf16 activation storage needs wfae_set_matmul_precision(WFAE_PRECISION_BF16)");
   const int cpg = C / groups, rh = g3b_strip(cpg, H, W);
   hipStream_t st = (hipStream_t)stream;
-  if (cpg == 4) return g3b_launch<4, 24, 384>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
-  if (cpg == 8) return g3b_launch<8, 12, 192>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
-  if (cpg == 16) return g3b_launch<16, 6, 96>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
-  if (W == 48) return g3b_launch<32, 3, 48>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
-  return g3b_launch<32, 2, 24>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
+  if (cpg == 4) return g3b_launch<4, 24, 384, 1, 6, bf16_t>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
+  if (cpg == 8) return g3b_launch<8, 12, 192, 1, 6, bf16_t>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
+  if (cpg == 16) return g3b_launch<16, 6, 96, 1, 6, bf16_t>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
+  if (W == 48) return g3b_launch<32, 3, 48, 1, 6, bf16_t>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
+  return g3b_launch<32, 2, 24, 1, 6, bf16_t>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
 }
 
 int wfae_g3b_bwd_weight_bf16(const uint16_t* dy, const uint16_t* x, float* dw, int NB, int C, int H, int W, int groups,
@@ -601,9 +642,32 @@ int wfae_g3b_bwd_weight_bf16(const uint16_t* dy, const uint16_t* x, float* dw, i
  * slower than the fp32-MFMA kernel of dconv.hip (0.335 vs 0.305 ms at 64 channels; W <= 96: 0.155 -> 0.122, 0.179 -> 0.096,
  * 0.077 -> 0.049 ms) */
 int wfae_g3b_f32_supported(int C, int H, int W, int groups, int wgrad) {
-  if (!wgrad) return 0;
-  if (!wfae_g3b_supported(C, H, W, groups) || W > 96) return 0;
-  return wfae::matmul_precision() == WFAE_PRECISION_FP32 && wfae::split_gemm_enabled() ? 1 : 0;
+  if (!wfae_g3b_supported(C, H, W, groups)) return 0;
+  if (wfae::matmul_precision() != WFAE_PRECISION_FP32 || !wfae::split_gemm_enabled()) return 0;
+  if (wgrad) return W <= 96 ? 1 : 0;
+  // forward / data gradient: 16 channels per group @96 (three tiles per wave, two blocks per CU: 0.155 - 0.172 -> 0.119 - 0.129
+  // ms).  8 @192 is built and tested but measured SLOWER than the VALU kernel of dconv.hip (0.228 vs 0.218 ms: the split of
+  // every staged value, three times the transposed reads and 36 MFMAs per tile at two waves per SIMD) and is not routed;
+  // 4 @384 fits one block per CU only; at 32 per group the three-plane weight fragments of a wave exceed the register file
+  const int cpg = C / groups;
+  return cpg == 16 && W == 96 ? 1 : 0;
+}
+
+int wfae_g3b_fwd(const float* x, const float* w, float* y, int NB, int C, int H, int W, int groups, int transposed, void* ws,
+                 size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(x && w && y, WFAE_ERR_NULL_POINTER, "g3b_fwd: null pointer");
+  WFAE_REQUIRE(NB > 0 && NB <= 65535 && C > 0 && H > 0 && W > 0 && groups > 0 && C % groups == 0, WFAE_ERR_BAD_SHAPE,
+               "g3b_fwd: bad shape");
+  WFAE_REQUIRE(wfae_g3b_supported(C, H, W, groups) && ((C / groups == 8 && W == 192) || (C / groups == 16 && W == 96)) &&
+                   wfae::matmul_precision() == WFAE_PRECISION_FP32 && wfae::split_gemm_enabled(),
+               WFAE_ERR_UNSUPPORTED, "g3b_fwd: (channels per group, W) must be (8, 192) or (16, 96) at fp32 precision with the split "
+               "switch on (wfae_gconv3x3_fwd serves every shape)");
+  WFAE_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0,
+               WFAE_ERR_BAD_SHAPE, "g3b_fwd: tensors and workspace must be 16-byte aligned");
+  const int cpg = C / groups, rh = g3b_strip(cpg, H, W);
+  hipStream_t st = (hipStream_t)stream;
+  if (cpg == 8) return g3b_launch<8, 12, 192, 3, 3, float>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
+  return g3b_launch<16, 6, 96, 3, 3, float>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
 }
 
 int wfae_g3b_bwd_weight(const float* dy, const float* x, float* dw, int NB, int C, int H, int W, int groups, int accumulate,

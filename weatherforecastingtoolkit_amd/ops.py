@@ -1091,6 +1091,10 @@ def gconv3x3_fwd(x, w, groups, transposed=False):
     y = torch.empty_like(x)
     ws = workspace()
     cpg = c // groups
+    if sfx == "" and _G3B and _lib.load().wfae_g3b_f32_supported(int(c), int(h), int(wd), int(groups), 0):
+        _call("wfae_g3b_fwd", 2 * x.numel() * cpg * 9, 2 * es * x.numel(), _p(x), _p(w), _p(y), nb, c, h, wd, groups,
+              int(transposed), ws.data_ptr(), ws.numel(), _stream(), label="wfae_gconv3x3_fwd", peak=PEAK_BF16_MFMA / 6)
+        return y
     if sfx == "_bf16" and g3b_supported(c, h, wd, groups):
         _call("wfae_g3b_fwd_bf16", 2 * x.numel() * cpg * 9, 2 * es * x.numel(), _p(x), _p(w), _p(y), nb, c, h, wd, groups,
               int(transposed), ws.data_ptr(), ws.numel(), _stream(), label="wfae_gconv3x3_fwd", peak=PEAK_BF16_MFMA)

@@ -305,6 +305,16 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
 
   // ---- epilogue: accumulator register q of lane (r15, g4) is C[4 g4 + q][r15] of its 16 x 16 tile
   float* __restrict__ Cb = p.C + (long)by * p.c_y + (long)bz * p.c_split;
+  if (m0 + SBM <= p.M && n0 + SBN <= p.N) {   // whole tile (the usual case): no per-element bounds, one base + immediates
+    float* __restrict__ c0 = Cb + (long)(m0 + wm0 + 4 * g4) * p.ldc + n0 + wn0 + r15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 2 * NTB; ++j) c0[(long)(16 * i + q) * p.ldc + 16 * j] = acc[i][j][q];
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -102,6 +102,36 @@ for planes in (3, 1):
 expect(lib.wfae_wino_gemm_up_split(1, P, Q, R, 2, 32, 256, 512, 96, 96, None), SHAPE, "wino_gemm_up_split planes = 2")
 assert lib.wfae_set_split_gemm(0) == 0 and lib.wfae_get_split_gemm() == 0 and lib.wfae_set_split_gemm(1) == 0 and lib.wfae_get_split_gemm() == 1
 checked += 1
+# grouped 3x3 on the matrix pipe (csrc/g3b.hip): shape table, precision mode, workspace, alignment; every model geometry up to the launch
+assert lib.wfae_g3b_supported(32, 384, 384, 8) == 1 and lib.wfae_g3b_supported(64, 192, 192, 8) == 1
+assert lib.wfae_g3b_supported(256, 24, 24, 8) == 1 and lib.wfae_g3b_supported(256, 48, 48, 8) == 1
+assert lib.wfae_g3b_supported(32, 20, 36, 8) == 0 and lib.wfae_g3b_supported(64, 101, 192, 8) == 0 and lib.wfae_g3b_supported(64, 192, 384, 8) == 0
+assert lib.wfae_g3b_f32_supported(128, 96, 96, 8, 1) == 1 and lib.wfae_g3b_f32_supported(64, 192, 192, 8, 1) == 0
+assert lib.wfae_g3b_f32_supported(128, 96, 96, 8, 0) == 1 and lib.wfae_g3b_f32_supported(64, 192, 192, 8, 0) == 0
+checked += 5
+expect(lib.wfae_g3b_fwd_bf16(None, Q, R, 32, 32, 384, 384, 8, 0, WS, big, None), NULL, "g3b_fwd null")
+expect(lib.wfae_g3b_fwd_bf16(P, Q, R, 32, 32, 20, 36, 8, 0, WS, big, None), UNS, "g3b_fwd unsupported shape")
+expect(lib.wfae_g3b_fwd_bf16(P, Q, R, 32, 32, 384, 384, 8, 0, WS, big, None), UNS, "g3b_fwd needs bf16 precision")
+expect(lib.wfae_g3b_bwd_weight_bf16(P, Q, R, 32, 32, 384, 384, 8, 0, WS, big, None), UNS, "g3b_bwd_weight needs bf16 precision")
+expect(lib.wfae_g3b_fwd(P, Q, R, 32, 32, 384, 384, 8, 0, WS, big, None), UNS, "g3b_fwd fp32: 4 per group not served")
+expect(lib.wfae_g3b_bwd_weight(P, Q, R, 32, 64, 192, 192, 8, 0, WS, big, None), UNS, "g3b_bwd_weight fp32: W = 192 not served")
+expect(lib.wfae_g3b_bwd_weight(P, Q, R, 32, 128, 96, 96, 8, 0, WS, 1024, None), WSP, "g3b_bwd_weight fp32 short workspace")
+for c, h in [(128, 96), (256, 48), (256, 24)]:
+    expect(lib.wfae_g3b_bwd_weight(P, Q, R, 32, c, h, h, 8, 0, WS, big, None), ANY_FAIL, f"g3b_bwd_weight fp32 {c}@{h}")
+expect(lib.wfae_g3b_fwd(P, Q, R, 32, 128, 96, 96, 8, 1, WS, big, None), ANY_FAIL, "g3b_fwd fp32 128@96")
+expect(lib.wfae_g3b_fwd(P, Q, R, 32, 64, 192, 192, 8, 0, WS, big, None), ANY_FAIL, "g3b_fwd fp32 64@192 (served, not routed)")
+assert lib.wfae_set_matmul_precision(1) == 0
+try:
+    expect(lib.wfae_g3b_fwd_bf16(P + 2, Q, R, 32, 32, 384, 384, 8, 0, WS, big, None), SHAPE, "g3b_fwd misaligned")
+    expect(lib.wfae_g3b_fwd_bf16(P, Q, R, 32, 32, 384, 384, 8, 0, WS, 64, None), WSP, "g3b_fwd short workspace")
+    expect(lib.wfae_g3b_bwd_weight_bf16(P, Q, R, 32, 32, 384, 384, 8, 0, WS, 1024, None), WSP, "g3b_bwd_weight short workspace")
+    for c, h in [(32, 384), (64, 192), (128, 96), (256, 48), (256, 24)]:
+        for tr in (0, 1):
+            expect(lib.wfae_g3b_fwd_bf16(P, Q, R, 32, c, h, h, 8, tr, WS, big, None), ANY_FAIL, f"g3b_fwd {c}@{h}")
+        expect(lib.wfae_g3b_bwd_weight_bf16(P, Q, R, 32, c, h, h, 8, 0, WS, big, None), ANY_FAIL, f"g3b_bwd_weight {c}@{h}")
+    assert lib.wfae_g3b_f32_supported(128, 96, 96, 8, 1) == 0   # fp32 planes only at fp32 precision
+finally:
+    assert lib.wfae_set_matmul_precision(0) == 0
 expect(lib.wfae_conv4x4s2_down(P, Q, R, 32, 256, 512, 96, 96, None), ANY_FAIL, "conv4x4s2_down")
 expect(lib.wfae_conv4x4s2_wgrad(P, Q, R, 32, 256, 512, 96, 96, 0, WS, big, None), ANY_FAIL, "conv4x4s2_wgrad")
 expect(lib.wfae_linear_fwd(P, Q, S, R, 32, 36864, 2048, WS, big, None), ANY_FAIL, "linear_fwd 36864->2048")

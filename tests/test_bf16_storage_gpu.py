@@ -145,7 +145,8 @@ def test_gconv3_bf16_storage(ops_medium, dev, nb, c, groups, h, w):
     assert relerr(dw, dw32) < 2e-5
 
 
-@pytest.mark.parametrize("nb,c,h,w", [(2, 32, 48, 384), (1, 32, 24, 384), (2, 64, 48, 192), (1, 64, 72, 192), (2, 128, 48, 96),
+@pytest.mark.parametrize("nb,c,h,w", [(2, 32, 48, 384), (1, 32, 24, 384), (1, 32, 25, 384), (2, 64, 48, 192), (1, 64, 72, 192), (1, 64, 40, 192),
+                                      (2, 128, 48, 96),
                                       (3, 256, 48, 48), (2, 256, 16, 48), (2, 256, 24, 24), (1, 256, 12, 24)])
 def test_g3b_implicit_gemm_matches_the_direct_kernels(ops_medium, dev, nb, c, h, w):
     """csrc/g3b.hip (bf16 MFMA, row ring, output-side tap shifts) against the dconv.hip kernels on the same bf16 tensors and

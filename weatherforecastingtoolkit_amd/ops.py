@@ -324,7 +324,7 @@ def conv1x1_fwd_bnact(x, st, w, bias=None, res=None, stats=False):
 
 # weight gradients on csrc/c1w.hip (both operands as K-contiguous rows, no LDS transpose): fp32 tensors at fp32 precision with
 # the split GEMMs on, bf16-stored tensors at 'medium'
-_C1W = os.environ.get("WFAE_C1W", "1") != "0"
+_C1W = True   # A/B through set_c1w()
 
 
 def set_c1w(on):
@@ -403,7 +403,7 @@ def conv1x1_bwd_weight(dy, x, dw, accumulate=False):
 # ------------------------------------------- 1x1 conv on the bf16 pipe (c1gemm)
 # csrc/c1gemm.hip: the Bottleneck's 1x1 convolutions with the weight as three exact bf16 planes and the activation split
 # once per loaded value on its way into LDS; epilogues: residual, BatchNorm sums, BatchNorm-backward reduce / dx.
-_C1GEMM = os.environ.get("WFAE_C1GEMM", "1") != "0"
+_C1GEMM = True   # A/B through set_c1gemm()
 
 
 def set_c1gemm(on):
@@ -419,7 +419,13 @@ def c1gemm_supported(m, k, hw):
 
 
 # ---- bf16 storage: csrc/c1b.hip (no format change between HBM and the matrix core)
-_C1B = os.environ.get("WFAE_C1B", "1") != "0"
+_C1B = True   # A/B through set_c1b()
+
+
+def set_c1b(on):
+    """A/B switch: bf16 1x1 forward / data gradient on csrc/c1b.hip or on the element-typed generic GEMM kernel"""
+    global _C1B
+    _C1B = bool(on)
 
 
 def c1b_supported(m, k, hw):
@@ -1069,7 +1075,7 @@ def gconv3x3_supported(c, groups):
     return c % groups == 0 and (c // groups) in (4, 8, 16, 32)
 
 
-_G3B = os.environ.get("WFAE_G3B", "1") != "0"
+_G3B = True   # A/B through set_g3b()
 
 
 def set_g3b(on):

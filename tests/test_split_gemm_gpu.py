@@ -35,11 +35,14 @@ def _err(c, ref64, scale64):
 
 
 @pytest.mark.parametrize("kind", [0, 1])
-@pytest.mark.parametrize("y,m,n,k", [(1, 256, 128, 32), (3, 300, 200, 96), (2, 64, 136, 64), (1, 512, 384, 2048), (2, 40, 8, 32), (9, 300, 200, 64)])
+@pytest.mark.parametrize("y,m,n,k", [(1, 256, 128, 32), (3, 300, 200, 96), (2, 64, 136, 64), (1, 512, 384, 2048), (2, 40, 8, 32), (9, 300, 200, 64),
+                                     (40, 300, 512, 128), (25, 512, 704, 64), (70, 256, 384, 256)])
 def test_split_gemm_matches_fp32_accuracy(ops, dev, kind, y, m, n, k):
     """C = A B from split operands against fp64: the error (relative to sum |a||b|, the natural scale of a dot product)
     is within 1.5x of torch's own fp32 matmul on the same data, at every tile tail (M, N not multiples of the 256 x 128
-    tile, several batches)"""
+    tile, several batches).  The last three shapes have more tiles than the chip has CUs and an even number of K-steps: the
+    persistent launch, whose loader fetches a workgroup's next tile while the current one is finished (2, 4 and 8 K-steps,
+    partial tiles among them)"""
     g = torch.Generator().manual_seed(1000 * kind + m + n + k)
     a = (torch.randn(y, m, k, generator=g) * torch.exp2(torch.randint(-6, 6, (y, m, 1), generator=g).float())).to(dev)
     b = torch.randn(y, k, n, generator=g).to(dev)

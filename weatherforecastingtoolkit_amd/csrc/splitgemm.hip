@@ -41,6 +41,8 @@ struct SgP {
   int lda, ldb, ldc;
   int k_per_split;        // multiple of 32
   int mtiles;
+  int tiles, ny;          // work items: tile fastest, then batch (ny of them), then K-split
+  int total;              // tiles * ny * splits
 };
 
 constexpr int SBM = 256, SBK = 32, SNT = 512;
@@ -79,7 +81,7 @@ __device__ __forceinline__ unsigned off_tr16(int k, int ch) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int BKIND, int NP = 3, int NTB = 2>
+template <int BKIND, int NP = 3, int NTB = 2, bool PERSIST = false>
 __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
   static_assert(NP == 3 || NP == 1, "three exact planes or the h plane alone");
   static_assert(NTB == 2 || (NTB == 4 && NP == 1), "64 x 128 wave tiles (128 accumulators) only with one plane");
@@ -89,58 +91,93 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
   constexpr int STAGE_B = NP * (A_PLANE_B + B_PLANE_B);
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  // XCD-aware placement.  Workgroups go round-robin over the 8 XCDs in launch order (x fastest, then y, z), each XCD
-  // with its own L2.  gridDim.x % 8 == 0: every XCD gets a contiguous run of the tiles of one batch.  Otherwise (few
-  // tiles per batch / K-split: the weight gradients) whole (y, z) groups are dealt to the XCDs, so that the tiles which
-  // share the group's operands run side by side under ONE L2 instead of fetching them from HBM once per XCD.
-  int bid = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if ((gridDim.x & 7) == 0) {
-    bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  // XCD-aware placement; workgroups go round-robin over the 8 XCDs in launch order, each XCD with its own L2.
+  // Classic launch (grid = tiles x batches x splits, one tile per workgroup): gridDim.x % 8 == 0: every XCD gets a
+  // contiguous run of the tiles of one batch; otherwise (few tiles per batch / K-split: the weight gradients) whole (y, z)
+  // groups are dealt to the XCDs, so that the tiles which share the group's operands run side by side under ONE L2.
+  // PERSISTENT launch (round 3, three-plane operands; one workgroup per CU when every item has the same even number of
+  // K-steps): items (tile, batch, K-split) in the linear order tile-fastest, XCD x owns the contiguous run [x W8, (x + 1) W8)
+  // and its gridDim.x / 8 workgroups walk it together (item = x W8 + slot + (gridDim.x / 8) i).  The loader runs two K-steps
+  // ahead ACROSS items: while a tile's last two K-steps are multiplied, the first two of the workgroup's next tile travel
+  // HBM -> registers -> LDS, and the tile's epilogue is the only gap in the matrix pipe.  Same box, layer shapes of the
+  // model (kbench totals): down 8.27 -> 7.95, up 8.85 -> 8.41 ms, weight gradients 9.25 -> 9.23; with one-plane operands
+  // (short K loops, L2-bound) the static partition measured 4 % slower and is not used.
+  int item, item_end, per;
+  int c_bid = 0, c_by = 0, c_bz = 0;   // classic launch: the tile of this workgroup
+  if constexpr (PERSIST) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int w8 = (p.total + 7) / 8;
+    per = gridDim.x >> 3;
+    item = xcd * w8 + slot;
+    item_end = min(p.total, (xcd + 1) * w8);
+    if (item >= item_end) return;   // whole workgroup: nobody reaches a barrier
   } else {
-    const unsigned nxt = gridDim.x, ngroups = gridDim.y * gridDim.z;
-    const unsigned L = blockIdx.x + nxt * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (L < (ngroups & ~7u) * nxt) {
-      const unsigned slot = L >> 3, G = (L & 7) + 8 * (slot / nxt);
-      bid = (int)(slot % nxt);
-      by = (int)(G % gridDim.y);
-      bz = (int)(G / gridDim.y);
+    c_bid = blockIdx.x; c_by = blockIdx.y; c_bz = blockIdx.z;
+    if ((gridDim.x & 7) == 0) {
+      c_bid = (c_bid & 7) * (gridDim.x >> 3) + (c_bid >> 3);
+    } else {
+      const unsigned nxt = gridDim.x, ngroups = gridDim.y * gridDim.z;
+      const unsigned L = blockIdx.x + nxt * (blockIdx.y + gridDim.y * blockIdx.z);
+      if (L < (ngroups & ~7u) * nxt) {
+        const unsigned sl = L >> 3, G = (L & 7) + 8 * (sl / nxt);
+        c_bid = (int)(sl % nxt);
+        c_by = (int)(G % gridDim.y);
+        c_bz = (int)(G / gridDim.y);
+      }
     }
+    item = 0; item_end = 1; per = 1;
   }
-  const int m0 = (bid % p.mtiles) * SBM, n0 = (bid / p.mtiles) * SBN;
-  const int k_begin = bz * p.k_per_split;
-  const int k_end = min(p.K, k_begin + p.k_per_split);
-  const int nsteps = (k_end - k_begin) / SBK;
 
-  // uniform plane bases + 32-bit per-thread byte offsets (one batch matrix is far below 4 GB): one address register per
-  // stream instead of a pair, no 64-bit plane arithmetic in the loop
+  const int ac = t & 3, ar = t >> 2;
+  const unsigned a_dst = off_row16(ar, ac);
+  const int bk = t >> 4, bch = t & 15;
+  const unsigned b_dst = BKIND == 0 ? off_tr16(bk, bch) : a_dst;   // + h * 32 * 256 (k-row image per 128 columns) / + h * 128 * 64
+  const unsigned b_step = BKIND == 0 ? 2u * (unsigned)(SBK * p.ldb) : 2u * SBK;
+
+  // ---- loader cursor: the (item, K-step) the next global loads fetch — up to two K-steps and one item ahead of the multiply
   const char* __restrict__ Apl[NP];
   const char* __restrict__ Bpl[NP];
+  unsigned a_off0, a_off1, b_off[NBL];
+  int ld_next = item;   // the item the cursor moves to when it has fetched the last K-step of its current one
+  int ld_k = 0, ld_nsteps = 0;
+  auto tile_of = [&](int it, int& m0_, int& n0_, int& by_i, int& bz_i) {
+    int bid;
+    if constexpr (PERSIST) {
+      const int r = it / p.tiles;
+      bid = it - r * p.tiles;
+      bz_i = r / p.ny;
+      by_i = r - bz_i * p.ny;
+    } else {
+      bid = c_bid; by_i = c_by; bz_i = c_bz;
+    }
+    m0_ = (bid % p.mtiles) * SBM;
+    n0_ = (bid / p.mtiles) * SBN;
+  };
+  auto set_cursor = [&](int it) {
+    int m0_, n0_, by_i, bz_i;
+    tile_of(it, m0_, n0_, by_i, bz_i);
+    const int kb = bz_i * p.k_per_split;
+    ld_nsteps = (min(p.K, kb + p.k_per_split) - kb) / SBK;
+    ld_k = 0;
 #pragma unroll
-  for (int pl = 0; pl < NP; ++pl) {
-    Apl[pl] = reinterpret_cast<const char*>(p.A + (long)by * p.a_y + pl * p.a_plane);
-    Bpl[pl] = reinterpret_cast<const char*>(p.B + (long)by * p.b_y + pl * p.b_plane);
-  }
-  const int ac = t & 3, ar = t >> 2;
-  unsigned a_off0 = 2u * (unsigned)(min(m0 + ar, p.M - 1) * p.lda + k_begin + ac * 8);
-  unsigned a_off1 = 2u * (unsigned)(min(m0 + ar + 128, p.M - 1) * p.lda + k_begin + ac * 8);
-  const unsigned a_dst = off_row16(ar, ac);
-  unsigned b_off[NBL], b_dst, b_step;
-  if constexpr (BKIND == 0) {
-    const int bk = t >> 4, bch = t & 15;
+    for (int pl = 0; pl < NP; ++pl) {
+      Apl[pl] = reinterpret_cast<const char*>(p.A + (long)by_i * p.a_y + pl * p.a_plane);
+      Bpl[pl] = reinterpret_cast<const char*>(p.B + (long)by_i * p.b_y + pl * p.b_plane);
+    }
+    // rows / columns beyond the matrix are clamped to valid ones (their products land where the epilogue does not store)
+    a_off0 = 2u * (unsigned)(min(m0_ + ar, p.M - 1) * p.lda + kb + ac * 8);
+    a_off1 = 2u * (unsigned)(min(m0_ + ar + 128, p.M - 1) * p.lda + kb + ac * 8);
 #pragma unroll
     for (int h = 0; h < NBL; ++h) {
-      int n = n0 + 128 * h + bch * 8;
-      if (n >= p.N) n = p.N - 8;
-      b_off[h] = 2u * (unsigned)((k_begin + bk) * p.ldb + n);
+      if constexpr (BKIND == 0) {
+        int n = n0_ + 128 * h + bch * 8;
+        if (n >= p.N) n = p.N - 8;
+        b_off[h] = 2u * (unsigned)((kb + bk) * p.ldb + n);
+      } else {
+        b_off[h] = 2u * (unsigned)(min(n0_ + ar + 128 * h, p.N - 1) * p.ldb + kb + ac * 8);
+      }
     }
-    b_dst = off_tr16(bk, bch);   // + h * 32 * 256: one k-row image per 128 columns
-    b_step = 2u * (unsigned)(SBK * p.ldb);
-  } else {
-#pragma unroll
-    for (int h = 0; h < NBL; ++h) b_off[h] = 2u * (unsigned)(min(n0 + ar + 128 * h, p.N - 1) * p.ldb + k_begin + ac * 8);
-    b_dst = a_dst;               // + h * 128 * 64
-    b_step = 2u * SBK;
-  }
+  };
   u32x4 ra[NP][2], rb[NP][NBL];
   auto load_global = [&]() {
 #pragma unroll
@@ -151,11 +188,21 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
       for (int h = 0; h < NBL; ++h) rb[pl][h] = *reinterpret_cast<const u32x4*>(Bpl[pl] + b_off[h]);
     }
   };
-  auto advance = [&](bool more) {
-    a_off0 += more ? 2u * SBK : 0u;
-    a_off1 += more ? 2u * SBK : 0u;
+  // after every load_global: one K-step on; past the item's last one the cursor moves to the workgroup's next item (a
+  // uniform branch, once per item) or, when there is none, stays on the last K-step (re-loaded, stored to the idle stage,
+  // never read)
+  auto advance = [&]() {
+    if (__builtin_expect(++ld_k < ld_nsteps, 1)) {
+      a_off0 += 2u * SBK;
+      a_off1 += 2u * SBK;
 #pragma unroll
-    for (int h = 0; h < NBL; ++h) b_off[h] += more ? b_step : 0u;
+      for (int h = 0; h < NBL; ++h) b_off[h] += b_step;
+    } else if (ld_next < item_end) {
+      set_cursor(ld_next);
+      ld_next += per;
+    } else {
+      ld_k = ld_nsteps - 1;
+    }
   };
   auto store_lds = [&](int buf) {
     unsigned char* s = smem + buf * STAGE_B;
@@ -253,9 +300,8 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
     const int cur = st & 1;
     read_b(by_, cur, 1);
     read_a(A1, cur, 1);
-    store_lds(cur ^ 1);   // K-step st + 1; in the last iteration a stale copy nobody reads
-    load_global();        // K-step st + 2
-    advance(st + 3 < nsteps);
+    store_lds(cur ^ 1);   // K-step st + 1 (the last iteration: K-step 0 of the next item, or a stale copy nobody reads)
+    load_global();        // K-step st + 2 (the last two iterations: K-steps 0 and 1 of the next item)
     quadrant(A0, bx, 0, 0);
     quadrant(A0, by_, 0, 1);
     if constexpr (NP == 3) {
@@ -286,46 +332,68 @@ __global__ __launch_bounds__(SNT, 2) void sgemm3_kernel(SgP p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  if (nsteps > 0) {
-    load_global();
-    advance(nsteps > 1);
-    store_lds(0);
-    load_global();
-    advance(nsteps > 2);
-    __syncthreads();
-    read_a(A0, 0, 0);
-    read_b(B0, 0, 0);
+  // ---- prologue of the workgroup's first item
+  set_cursor(item);
+  ld_next = item + per;
+  load_global();
+  advance();
+  store_lds(0);
+  load_global();
+  advance();
+  __syncthreads();
+  read_a(A0, 0, 0);
+  read_b(B0, 0, 0);
+
+  for (; item < item_end; item += per) {
+    int m0, n0, by, bz;
+    tile_of(item, m0, n0, by, bz);
+    const int k_begin = bz * p.k_per_split;
+    const int nsteps = (min(p.K, k_begin + p.k_per_split) - k_begin) / SBK;
+    // (persistent launches have an even nsteps: K-step 0 of every item lies in stage 0 and B0 holds its B_lo)
     int st = 0;
+    // the cursor moves BETWEEN the iterations: its once-per-item branch must not cut the body of an iteration, whose
+    // memory instructions the scheduler spreads between the MFMAs (sched_group_barrier works inside one basic block)
     for (; st + 1 < nsteps; st += 2) {
       iter(st, B0, B1);
+      advance();
       iter(st + 1, B1, B0);
+      advance();
     }
-    if (st < nsteps) iter(st, B0, B1);
-  }
+    if (st < nsteps) {
+      iter(st, B0, B1);
+      advance();
+    }
 
-  // ---- epilogue: accumulator register q of lane (r15, g4) is C[4 g4 + q][r15] of its 16 x 16 tile
-  float* __restrict__ Cb = p.C + (long)by * p.c_y + (long)bz * p.c_split;
-  if (m0 + SBM <= p.M && n0 + SBN <= p.N) {   // whole tile (the usual case): no per-element bounds, one base + immediates
-    float* __restrict__ c0 = Cb + (long)(m0 + wm0 + 4 * g4) * p.ldc + n0 + wn0 + r15;
+    // ---- epilogue: accumulator register q of lane (r15, g4) is C[4 g4 + q][r15] of its 16 x 16 tile
+    float* __restrict__ Cb = p.C + (long)by * p.c_y + (long)bz * p.c_split;
+    if (m0 + SBM <= p.M && n0 + SBN <= p.N) {   // whole tile (the usual case): no per-element bounds, one base + immediates
+      float* __restrict__ c0 = Cb + (long)(m0 + wm0 + 4 * g4) * p.ldc + n0 + wn0 + r15;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 2 * NTB; ++j) c0[(long)(16 * i + q) * p.ldc + 16 * j] = acc[i][j][q];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = m0 + wm0 + 16 * i + 4 * g4 + q;
+#pragma unroll
+          for (int j = 0; j < 2 * NTB; ++j) {
+            const int col = n0 + wn0 + 16 * j + r15;
+            if (row < p.M && col < p.N) Cb[(long)row * p.ldc + col] = acc[i][j][q];
+          }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int j = 0; j < 2 * NTB; ++j)
 #pragma unroll
-        for (int j = 0; j < 2 * NTB; ++j) c0[(long)(16 * i + q) * p.ldc + 16 * j] = acc[i][j][q];
-    return;
+        for (int q = 0; q < 4; ++q) acc[i][j][q] = 0.f;
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = m0 + wm0 + 16 * i + 4 * g4 + q;
-#pragma unroll
-      for (int j = 0; j < 2 * NTB; ++j) {
-        const int col = n0 + wn0 + 16 * j + r15;
-        if (row < p.M && col < p.N) Cb[(long)row * p.ldc + col] = acc[i][j][q];
-      }
-    }
 }
 
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, unsigned short* __restrict__ o, long n, int planes) {
@@ -345,16 +413,30 @@ int launch_sgemm3(SgP& p, int planes, int batches, int splits, hipStream_t st, c
   p.mtiles = cdiv(p.M, SBM);
   // one plane: 256-column blocks (round 3, same box: the Winograd products of a 'medium' step 13.5 -> 10.7 ms, step 105.4 -> 100.8)
   const bool wide = planes == 1 && p.N >= 256;
-  const long tiles = (long)p.mtiles * cdiv(p.N, wide ? 256 : 128);
-  WFAE_REQUIRE(tiles < (1l << 31) && batches <= 65535 && splits <= 65535, WFAE_ERR_BAD_SHAPE, "%s: grid too large", what);
-  if (wide) {
-    hipLaunchKernelGGL((sgemm3_kernel<BKIND, 1, 4>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
-    return check_launch(what);
-  }
+  p.tiles = p.mtiles * cdiv(p.N, wide ? 256 : 128);
+  p.ny = batches;
+  const long total = (long)p.tiles * batches * splits;
+  WFAE_REQUIRE(total < (1l << 30), WFAE_ERR_BAD_SHAPE, "%s: grid too large", what);
+  p.total = (int)total;
+  // persistent (three planes) when every item has the same even number of K-steps (the stage parity and the role of the
+  // two B register groups then repeat from item to item): one workgroup per CU; else one workgroup per tile
+  const bool uniform = splits == 1 || p.K % p.k_per_split == 0;
+  const int ksteps = (splits == 1 ? p.K : p.k_per_split) / SBK;
+  static const int ncu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return (n + 7) / 8 * 8;
+  }();
+  WFAE_REQUIRE(p.tiles > 0 && batches <= 65535 && splits <= 65535, WFAE_ERR_BAD_SHAPE, "%s: grid too large", what);
+  const dim3 classic((unsigned)p.tiles, batches, splits);
   // (An LDS-DMA form of the loaders — global_load_lds_dwordx4, no staging registers or ds_write — measured equal on the
   // Winograd shapes in round 2, 28.96 vs 28.57 ms, and was removed: the operand path is not what the waves wait for.)
-  if (planes == 1) hipLaunchKernelGGL((sgemm3_kernel<BKIND, 1>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
-  else hipLaunchKernelGGL((sgemm3_kernel<BKIND, 3>), dim3((unsigned)tiles, batches, splits), dim3(SNT), 0, st, p);
+  if (wide) hipLaunchKernelGGL((sgemm3_kernel<BKIND, 1, 4>), classic, dim3(SNT), 0, st, p);
+  else if (planes == 1) hipLaunchKernelGGL((sgemm3_kernel<BKIND, 1>), classic, dim3(SNT), 0, st, p);
+  else if (uniform && ksteps >= 2 && ksteps % 2 == 0 && p.total > ncu)
+    hipLaunchKernelGGL((sgemm3_kernel<BKIND, 3, 2, true>), dim3(ncu), dim3(SNT), 0, st, p);
+  else hipLaunchKernelGGL((sgemm3_kernel<BKIND, 3>), classic, dim3(SNT), 0, st, p);
   return check_launch(what);
 }
 

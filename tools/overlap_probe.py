@@ -42,4 +42,4 @@ with torch.cuda.stream(s1): gemm(1)
 with torch.cuda.stream(s2): mem(1)
 for rep in range(3):
     a, b, c = timed(gemm, None), timed(None, mem), timed(gemm, mem)
-    print(f"{which}{' prio' if prio else ''} dynlds={os.environ.get('WFAE_GEMM_DYNLDS', '0')}: gemm alone {a:.2f} ms   bn alone {b:.2f} ms   both concurrently {c:.2f} ms   (sum {a+b:.2f}, max {max(a,b):.2f})", flush=True)
+    print(f"{which}{' prio' if prio else ''}: gemm alone {a:.2f} ms   bn alone {b:.2f} ms   both concurrently {c:.2f} ms   (sum {a+b:.2f}, max {max(a,b):.2f})", flush=True)

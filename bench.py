@@ -33,6 +33,8 @@ Extra objects in the line:
                 per-kernel statistics do; for that kernel `achieved` counts the executed bf16 MFMA
                 work (six products per fp32 product) against the dense bf16 peak and
                 `fp32_equivalent_tflops` the same work counted once.
+  bf16_storage  the same step timed in the same run at `--precision medium` (bf16 activation storage + bf16 MFMA operands:
+                BASELINE config 5's regime): {ms_per_step, value, peak_mem_GiB, hbm_fraction} — a side figure, never `value`.
   fp32_mfma_only  the same step timed in the same run with WFAE_SPLIT_GEMM=0 (every GEMM on
                 v_mfma_f32_32x32x2_f32): a side figure, never `value`; config.matmul says which
                 GEMMs the headline runs on the bf16 pipe with exact three-plane operands.
@@ -158,44 +160,91 @@ def kernel_source_tag():
     return h.hexdigest()[:16]
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, deadline_s=None):
     """`python bench.py --gpus N` (N > 1) with no launcher around it: start the N ranks as CHILD processes, one per GPU
     (RANK = LOCAL_RANK = 0..N-1, rendezvous on 127.0.0.1), relay rank 0's JSON line, return the worst exit status.
     Runs before anything in this process has imported torch or touched HIP: a process that has initialised the GPU must
-    neither fork ranks nor exec (the reference leaves this to Lightning's launcher, experiments/ae_v2/train.py:332-343)."""
+    neither fork ranks nor exec (the reference leaves this to Lightning's launcher, experiments/ae_v2/train.py:332-343).
+    Every rank runs in a session of its own; SIGTERM / SIGINT / SIGHUP to this parent (a harness `timeout`, a closed terminal)
+    and the overall deadline take all of them down — terminate, then kill, by process group — so no rank is left holding a GPU
+    or waiting in a collective.  The rendezvous port is picked by binding port 0; if a rank fails to bind it (taken in
+    between) the launch is retried on a fresh port."""
+    import signal
     import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n))
-    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between processes on this driver
-    base.setdefault("OMP_NUM_THREADS", "4")
+
     procs = []
-    for r in range(n):
-        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        # rank 0 owns stdout (the ONE JSON line); the other ranks' stdout goes to stderr so nothing else lands on it
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=None if r == 0 else sys.stderr))
+
+    def stop_all(grace=3.0):
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            live = [p for p in procs if p.poll() is None]
+            if not live:
+                return
+            for p in live:
+                try:
+                    os.killpg(p.pid, sig)          # start_new_session: the rank's pid is its process-group id
+                except (ProcessLookupError, PermissionError):
+                    pass
+            t_end = time.time() + grace
+            while time.time() < t_end and any(p.poll() is None for p in live):
+                time.sleep(0.05)
+
+    class _Stop(Exception):
+        pass
+
+    def on_signal(signum, frame):
+        raise _Stop(signum)
+
+    old_handlers = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
+    deadline = time.time() + (deadline_s if deadline_s else float(os.environ.get("WFAE_BENCH_DEADLINE_S", "3000")))
     rc = 0
     try:
-        pending = set(range(n))
-        while pending:
-            for r in list(pending):
-                code = procs[r].poll()
-                if code is None:
-                    continue
-                pending.discard(r)
-                if code != 0:
-                    rc = rc or code
-                    for q in pending:       # a rank died: the others would wait in a collective for ever
-                        procs[q].terminate()
-            time.sleep(0.05)
+        for attempt in range(3):
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+            base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n))
+            base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between processes on this driver
+            base.setdefault("OMP_NUM_THREADS", "4")
+            del procs[:]
+            for r in range(n):
+                env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+                # rank 0 owns stdout (the ONE JSON line); the other ranks' stdout goes to stderr so nothing else lands on it
+                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                              stdout=None if r == 0 else sys.stderr, start_new_session=True))
+                if os.environ.get("WFAE_BENCH_VERBOSE"):
+                    print(f"bench.py: rank {r} pid {procs[-1].pid}", file=sys.stderr, flush=True)
+            rc = 0
+            pending = set(range(n))
+            while pending:
+                if time.time() > deadline:
+                    print(f"bench.py: {n}-rank run exceeded its deadline; stopping every rank", file=sys.stderr)
+                    rc = 124
+                    break
+                for r in list(pending):
+                    code = procs[r].poll()
+                    if code is None:
+                        continue
+                    pending.discard(r)
+                    if code != 0:
+                        rc = rc or code
+                        pending.clear()             # a rank died: the others would wait in a collective for ever
+                        break
+                time.sleep(0.05)
+            stop_all()
+            if rc != EADDRINUSE_RC:
+                break
+    except _Stop as e:
+        print(f"bench.py: signal {e.args[0]}: stopping every rank", file=sys.stderr)
+        rc = 128 + int(e.args[0])
     finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+        stop_all()
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
     return rc
+
+
+EADDRINUSE_RC = 98   # a rank's exit status when the rendezvous port was taken between the parent's probe and its bind
 
 
 def check_launch(args):
@@ -211,6 +260,8 @@ def check_launch(args):
     if rank == 0:
         print(json.dumps({"check_launch": True, "n_gpus": world, "requested": args.gpus,
                           "dp": {"ranks_seen": int(ones.item()), "backend": backend if world > 1 else None}}), flush=True)
+    if os.environ.get("WFAE_BENCH_TEST_SLEEP"):      # tests/test_dp_gloo_cpu.py: keep the ranks alive so the parent can be signalled
+        time.sleep(float(os.environ["WFAE_BENCH_TEST_SLEEP"]))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -227,6 +278,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run weight gradients on the main stream")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra fp32-MFMA-only timing (profiling runs)")
+    ap.add_argument("--no-medium-leg", action="store_true", help="skip the extra bf16-storage ('medium') timing")
     ap.add_argument("--fp32-mfma-only", action="store_true",
                     help="keep the Winograd-domain GEMMs on v_mfma_f32_32x32x2_f32 (no split bf16 operands)")
     ap.add_argument("--check-launch", action="store_true",
@@ -256,7 +308,18 @@ def main():
     backend = os.environ.get("WFAE_DIST_BACKEND", "nccl")
     if backend != "nccl":
         os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
-    rank, world, local = parallel.init_from_env(backend)
+    want = int(os.environ.get("WORLD_SIZE", "1"))
+    if backend == "nccl" and want > 1 and torch.cuda.device_count() < want:
+        # RCCL needs one device per rank: say so before any rank enters a collective it could never leave
+        print(f"bench.py: --gpus {want} over RCCL needs {want} visible GPUs, this node shows {torch.cuda.device_count()} "
+              "(WFAE_DIST_BACKEND=gloo rehearses several ranks on one card)", file=sys.stderr)
+        sys.exit(2)
+    try:
+        rank, world, local = parallel.init_from_env(backend)
+    except RuntimeError as e:      # the rendezvous port was taken between the parent's probe and rank 0's bind: the parent retries
+        if "address already in use" in str(e).lower() or "EADDRINUSE" in str(e):
+            sys.exit(EADDRINUSE_RC)
+        raise
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -337,6 +400,30 @@ def main():
         fence()
         strict = (time.perf_counter() - t1) / args.steps
         ops.set_split_gemm(True)
+    # BASELINE config 5's precision in the same run: bf16 activation storage + bf16 MFMA operands ('medium'), same model,
+    # optimiser state, batch, steps and warm-up rule — a side figure beside the headline, never `value`
+    peak_mem_headline = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    medium = None
+    if args.precision == "highest" and not args.no_medium_leg:
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(dev)
+        ops.set_float32_matmul_precision("medium")
+        ops.set_activation_storage(torch.bfloat16)
+        try:
+            for _ in range(max(1, args.warmup)):
+                step()
+            fence()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            medium = ((time.perf_counter() - t2) / args.steps, torch.cuda.max_memory_allocated(dev) / 2 ** 30)
+        finally:
+            ops.set_float32_matmul_precision("highest")
+        if world > 1:
+            tm = torch.tensor([medium[0]], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            medium = (float(tm.item()), medium[1])
     ranks_seen, xchg_ms = 1, None
     if world > 1:
         ones = torch.ones(1, device=dev)
@@ -380,7 +467,7 @@ def main():
                                   "v_mfma_f32_32x32x2_f32 everywhere" if args.precision == "highest" else
                                   "bf16-rounded MFMA operands")},
             "final_loss": final_loss,
-            "peak_mem_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+            "peak_mem_GiB": peak_mem_headline,
             "step_roofline": {"hbm_fraction": BYTES_PER_FRAME_384 * (0.5 if bf16_storage else 1.0) * scale * fps / world / PEAK_HBM,
                               "algorithmic_bytes_per_frame": BYTES_PER_FRAME_384 * (0.5 if bf16_storage else 1.0) * scale,
                               "direct_form_gflop_per_frame": FLOPS_PER_FRAME_384 * scale / 1e9},
@@ -388,8 +475,16 @@ def main():
         if strict is not None:
             out["fp32_mfma_only"] = {"ms_per_step": 1e3 * strict, "value": world * B / strict, "unit": "frames/s",
                                      "note": "same step, same run, WFAE_SPLIT_GEMM=0: every GEMM on v_mfma_f32_32x32x2_f32"}
+        if medium is not None:
+            m_fps = world * B / medium[0]
+            out["bf16_storage"] = {"ms_per_step": 1e3 * medium[0], "value": m_fps, "unit": "frames/s", "peak_mem_GiB": medium[1],
+                                   "hbm_fraction": 0.5 * BYTES_PER_FRAME_384 * scale * m_fps / world / PEAK_HBM,
+                                   "note": "same step, same run at --precision medium (BASELINE config 5's regime, "
+                                           "experiments/ae_v2_2/train.py:223): bf16 activation storage + bf16 MFMA operands, fp32 "
+                                           "accumulation / parameters / statistics; a side figure, never `value`"}
         if world > 1:
             out["dp"] = {"ranks_seen": ranks_seen, "backend": backend, "overlap": bool(dp._hooks),
+                         "nccl_algo": os.environ.get("NCCL_ALGO"),
                          "grad_exchange_ms_per_step": xchg_ms,
                          "payload_bytes": 4 * sum(a.numel for a in opt.arenas)}
         if prof:

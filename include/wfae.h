@@ -53,7 +53,11 @@ typedef enum {
  *        would hand over a buffer of half the byte size: check wfae_version() >= 101 before using them.
  *   102  round 3: wfae_c1gemm_* (1x1 convolutions on the bf16 matrix pipe with exact split operands, fused BatchNorm
  *        backward epilogues), the bf16 ACTIVATION STORAGE entry points (*_bf16, *_bf16in, *_bf16out, wfae_convert_*),
- *        wfae_c1b_*, wfae_c1w_*, wfae_g3b_* added; nothing removed. */
+ *        wfae_c1b_*, wfae_c1w_*, wfae_g3b_* added; nothing removed.
+ *   103  round 4: REMOVED wfae_c1gemm_* (six entry points), wfae_conv1x1_bwd_data_bnred / _bndx and
+ *        wfae_bn_act_bwd_from_rows (the fused BatchNorm-backward epilogues: parity-green, never faster — the record is
+ *        profiles/r03_kbench_c1_fused_bn_backward.txt); wfae_g3b_fwd no longer serves 8 channels per group.  ADDED
+ *        wfae_c1r_* (register-direct 1x1 convolutions of the C <= 256 stages). */
 int wfae_version(void);
 const char* wfae_last_error_string(void);
 /* upper bound of scratch bytes any single call needs for a problem whose
@@ -121,54 +125,26 @@ int wfae_conv1x1_bwd_data(const float* dy, const float* w, float* dx, int NB, in
 int wfae_conv1x1_bwd_weight(const float* dy, const float* x, float* dw, int NB, int Cin, int Cout,
                             int HW, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
 
-/* ---- The Bottleneck's 1x1 convolutions on the bf16 matrix pipe at fp32 accuracy (csrc/c1gemm.hip, ABI 102).
- * Same products as wfae_conv1x1_fwd / wfae_conv1x1_bwd_data (pipeline/models/ae_64x8x8_lin.py:15,19) with the weight as
- * three exact bf16 planes (the "split" operands of the Winograd section below) and the fp32 activation split once per
- * loaded value on its way into LDS: y[n,m,p] = sum_k W[m,k] f(x[n,k,p]).
- *   c1gemm_supported:     1 when M % 64 == 0, K % 32 == 0, HW % 4 == 0 (other shapes: wfae_conv1x1_*).
- *   c1gemm_split_weights: w (Cout,Cin) -> W3 [3][Cout][Cin] and Wt3 [3][Cin][Cout] (3 * Cout * Cin uint16 each); the
- *                         forward passes W3 with (M, K) = (Cout, Cin), the data gradient Wt3 with (M, K) = (Cin, Cout).
- *   c1gemm_fwd:           y = W f(x) (+ res); pro_scale / pro_shift [K] non-null: f = GELU(x * scale[k] + shift[k]) (the
- *                         fused BatchNorm + GELU prologue of wfae_conv1x1_fwd_bnact, same arithmetic), else f = identity.
- *                         stat_part non-null: BatchNorm sums of y as *stat_rows partial rows, sum[rows][M] then
- *                         sumsq[rows][M] (fp64; finish with wfae_bn_stats_from_rows); capacity 2 * rows * M doubles,
- *                         rows = wfae_c1gemm_stat_rows(M, K, NB, HW).
- *   c1gemm_bnred:         da = W dt (the data gradient of a C/4 -> C ... or any 1x1 convolution) and, while da is on
- *                         chip, the reductions of the BatchNorm + GELU backward of the layer in front of it
- *                         (wfae_bn_act_bwd phase 1): part = sum dU [rows][M] then sum dU * xhat [rows][M], dU = da *
- *                         gelu'(x * bn_scale + bn_shift), xhat = (x - mean) * invstd, x (NB,M,HW) the BatchNorm input.
- *                         da may be null: nothing is stored (the recompute form, followed by c1gemm_bndx).  Finish with
- *                         wfae_bn_act_bwd_from_rows, which leaves what wfae_bn_act_bwd(phases = 2) reads.
- *   c1gemm_bndx:          dx = gamma * invstd * (dU - mean dU - xhat * mean(dU xhat)) (+ res) with da = W dt recomputed
- *                         on chip (wfae_bn_act_bwd phase 2 without ever storing da); coef = the 2 M floats at the head
- *                         of the workspace wfae_bn_act_bwd_from_rows wrote. */
-int wfae_c1gemm_supported(int M, int K, int HW);
-int wfae_c1gemm_stat_rows(int M, int K, int NB, int HW);
-int wfae_c1gemm_split_weights(const float* w, uint16_t* W3, uint16_t* Wt3, int Cout, int Cin, wfae_stream_t stream);
-int wfae_c1gemm_fwd(const uint16_t* W3, const float* x, const float* pro_scale, const float* pro_shift, const float* res,
-                    float* y, int NB, int K, int M, int HW, double* stat_part, int64_t stat_capacity, int* stat_rows,
-                    wfae_stream_t stream);
-int wfae_c1gemm_bnred(const uint16_t* W3, const float* dt, const float* x, const float* bn_scale, const float* bn_shift,
-                      const float* save_mean, const float* save_invstd, float* da, int NB, int K, int M, int HW,
-                      double* part, int64_t part_capacity, int* part_rows, wfae_stream_t stream);
-int wfae_c1gemm_bndx(const uint16_t* W3, const float* dt, const float* x, const float* gamma, const float* bn_scale,
-                     const float* bn_shift, const float* save_mean, const float* save_invstd, const float* coef,
-                     const float* res, float* dx, int NB, int K, int M, int HW, int training, wfae_stream_t stream);
-/* The same two fusions on the fp32 GEMM kernel of wfae_conv1x1_bwd_data (any Cin % 4 == 0, HW % 4 == 0; the short
- * reductions K = C / 4 of the high-resolution stages, where that kernel's occupancy beats c1gemm's):
- *   conv1x1_bwd_data_bnred: dx = da = conv1x1_bwd_data(dy, w) (dx may be null: not stored) + the partial rows
- *                           sum dU [rows][Cin], sum dU xhat [rows][Cin] of the BatchNorm + GELU in front, x (NB,Cin,HW) its
- *                           input; part_capacity >= 4 * ceil(NB * HW / 128) * Cin doubles; finish with
- *                           wfae_bn_act_bwd_from_rows.
- *   conv1x1_bwd_data_bndx:  dx = gamma invstd (dU - mean dU - xhat mean(dU xhat)) (+ res) with da recomputed on chip; coef =
- *                           the head of the workspace wfae_bn_act_bwd_from_rows wrote. */
-int wfae_conv1x1_bwd_data_bnred(const float* dy, const float* w, const float* x, const float* bn_scale, const float* bn_shift,
-                                const float* save_mean, const float* save_invstd, float* dx, int NB, int Cin, int Cout, int HW,
-                                double* part, int64_t part_capacity, int* part_rows, wfae_stream_t stream);
-int wfae_conv1x1_bwd_data_bndx(const float* dy, const float* w, const float* x, const float* gamma, const float* bn_scale,
-                               const float* bn_shift, const float* save_mean, const float* save_invstd, const float* coef,
-                               const float* res, float* dx, int NB, int Cin, int Cout, int HW, int training,
-                               wfae_stream_t stream);
+/* ---- The Bottleneck's 1x1 convolutions at the HBM-bound stages, "register-direct" (csrc/c1r.hip, ABI 103).
+ * Same products as wfae_conv1x1_fwd[_stats|_bnact] / wfae_conv1x1_bwd_data (pipeline/models/ae_64x8x8_lin.py:15,19):
+ *   y[n,m,p] = sum_k A[m,k] f(x[n,k,p]) (+ res[n,m,p]),   A[m,k] = w[m * w_sm + k * w_sk]
+ * (forward: M = Cout, K = Cin, w_sm = Cin, w_sk = 1; data gradient: M = Cin, K = Cout, w_sm = 1, w_sk = Cin — the same
+ * (Cout, Cin) weight tensor either way).  fp32 tensors; every operand value is carried exactly as three bf16 values (six
+ * v_mfma_f32_16x16x32_bf16 products per fp32 product, fp32 accumulation: the accuracy of the fp32 path, needs the split
+ * GEMMs on).  The activation goes HBM -> registers -> matrix core with no LDS staging (16-byte loads of four pixels of eight
+ * channel rows per lane; the four pixel components feed four MFMAs), results leave as 16-byte stores; the weights are split
+ * by the kernel itself into an LDS image.  Served: (M, K) = (32, 128), (64, 256), (128, 32), (256, 64) — the C = 128 and
+ * C = 256 stages — with HW % 64 == 0 (wfae_c1r_supported).
+ *   pro_scale / pro_shift [K] non-null: f = GELU(x * scale[k] + shift[k]) (wfae_conv1x1_fwd_bnact's prologue), else identity;
+ *   res non-null: residual add (M > K only);
+ *   stat_part non-null: BatchNorm sums of y, *stat_rows = wfae_c1r_stat_rows(...) partial rows, sum[rows][M] then
+ *   sumsq[rows][M] in fp64 (one row per wave of the persistent grid; finish with wfae_bn_stats_from_rows); capacity
+ *   2 * rows * M doubles.  stat_rows is a HOST pointer. */
+int wfae_c1r_supported(int M, int K, int HW);
+int wfae_c1r_stat_rows(int M, int K, int NB, int HW);
+int wfae_c1r_fwd(const float* w, int64_t w_sm, int64_t w_sk, const float* x, const float* pro_scale, const float* pro_shift,
+                 const float* res, float* y, int NB, int K, int M, int HW, double* stat_part, int64_t stat_capacity,
+                 int* stat_rows, wfae_stream_t stream);
 /* Weight gradients of the Bottleneck's 1x1 convolutions with both operands read as K-contiguous rows (csrc/c1w.hip, ABI
  * 102): dw (Cout,Cin) (+)= dy (NB,Cout,HW) . x'^T, x' = x or (bn_scale / bn_shift non-null) gelu(x * bn_scale[c] +
  * bn_shift[c]) rebuilt in the loader (wfae_conv1x1_bwd_weight_bnact's prologue).  fp32 tensors: exact three-plane bf16
@@ -180,12 +156,6 @@ int wfae_c1w_bwd_weight(const float* dy, const float* x, const float* bn_scale, 
                         int Cout, int HW, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
 int wfae_c1w_bwd_weight_bf16(const uint16_t* dy, const uint16_t* x, const float* bn_scale, const float* bn_shift, float* dw, int NB,
                              int Cin, int Cout, int HW, int accumulate, void* ws, size_t ws_bytes, wfae_stream_t stream);
-/* wfae_bn_act_bwd phase 1 from partial rows a producer left (wfae_c1gemm_bnred): dgamma / dbeta and the coefficients at
- * the head of ws, exactly as phase 1 leaves them — follow with wfae_bn_act_bwd(phases = 2, same ws) or wfae_c1gemm_bndx
- * (coef = (const float*)ws). */
-int wfae_bn_act_bwd_from_rows(const double* part, int rows, int C, float* dgamma, float* dbeta, int accumulate, void* ws,
-                              size_t ws_bytes, wfae_stream_t stream);
-
 /* ---- nn.Linear (to_latent / from_latent, ae_64x8x8_lin.py:74-75,92,98) ---
  * y[b,o] = sum_i x[b,i] w[o,i] + bias[o] */
 int wfae_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In,

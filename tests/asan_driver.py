@@ -84,6 +84,8 @@ expect(lib.wfae_split_gemm(2, 3, P, Q, R, 64, 64, 64, 1, None), SHAPE, "split_ge
 expect(lib.wfae_split_gemm(0, 3, P, Q, R, 64, 64, 48, 1, None), UNS, "split_gemm K % 32")
 expect(lib.wfae_split_gemm(0, 3, P + 2, Q, R, 64, 64, 64, 1, None), SHAPE, "split_gemm misaligned planes")
 expect(lib.wfae_split_gemm(0, 2, P, Q, R, 64, 64, 64, 1, None), SHAPE, "split_gemm planes = 2")
+expect(lib.wfae_split_gemm(0, 3, P, Q, R, 65536, 64, 32768, 1, None), SHAPE, "split_gemm operand plane >= 2^31 elements (32-bit loader offsets)")
+expect(lib.wfae_split_gemm(1, 3, P, Q, R, 64, 65536, 32768, 1, None), SHAPE, "split_gemm B plane >= 2^31 elements")
 expect(lib.wfae_split_bf16x3(P, None, 16, 3, None), NULL, "split_bf16x3 null")
 expect(lib.wfae_split_bf16x3(P, Q, 0, 3, None), SHAPE, "split_bf16x3 n = 0")
 assert lib.wfae_wino_split_supported(1, 32, 256, 512, 96, 96) == 1 and lib.wfae_wino_split_supported(1, 1, 256, 512, 8, 8) == 0
@@ -119,7 +121,7 @@ expect(lib.wfae_g3b_bwd_weight(P, Q, R, 32, 128, 96, 96, 8, 0, WS, 1024, None), 
 for c, h in [(128, 96), (256, 48), (256, 24)]:
     expect(lib.wfae_g3b_bwd_weight(P, Q, R, 32, c, h, h, 8, 0, WS, big, None), ANY_FAIL, f"g3b_bwd_weight fp32 {c}@{h}")
 expect(lib.wfae_g3b_fwd(P, Q, R, 32, 128, 96, 96, 8, 1, WS, big, None), ANY_FAIL, "g3b_fwd fp32 128@96")
-expect(lib.wfae_g3b_fwd(P, Q, R, 32, 64, 192, 192, 8, 0, WS, big, None), ANY_FAIL, "g3b_fwd fp32 64@192 (served, not routed)")
+expect(lib.wfae_g3b_fwd(P, Q, R, 32, 64, 192, 192, 8, 0, WS, big, None), UNS, "g3b_fwd fp32 64@192: 8 per group not served")
 assert lib.wfae_set_matmul_precision(1) == 0
 try:
     expect(lib.wfae_g3b_fwd_bf16(P + 2, Q, R, 32, 32, 384, 384, 8, 0, WS, big, None), SHAPE, "g3b_fwd misaligned")
@@ -132,9 +134,31 @@ try:
     assert lib.wfae_g3b_f32_supported(128, 96, 96, 8, 1) == 0   # fp32 planes only at fp32 precision
 finally:
     assert lib.wfae_set_matmul_precision(0) == 0
+# register-direct 1x1 convolutions (csrc/c1r.hip): shape table, strides, residual rule, stat capacity, then every served geometry up to the launch
+assert lib.wfae_c1r_supported(32, 128, 384 * 384) == 1 and lib.wfae_c1r_supported(256, 64, 192 * 192) == 1
+assert lib.wfae_c1r_supported(64, 256, 100) == 0 and lib.wfae_c1r_supported(128, 512, 96 * 96) == 0
+assert lib.wfae_c1r_stat_rows(64, 256, 32, 192 * 192) > 0 and lib.wfae_c1r_stat_rows(64, 256, 1, 64) == 8
+checked += 6
+expect(lib.wfae_c1r_fwd(None, 256, 1, Q, None, None, None, R, 32, 256, 64, 192 * 192, None, 0, None, None), NULL, "c1r_fwd null")
+expect(lib.wfae_c1r_fwd(P, 256, 1, Q, None, None, None, R, 32, 256, 64, 100, None, 0, None, None), UNS, "c1r_fwd HW % 64")
+expect(lib.wfae_c1r_fwd(P, 512, 1, Q, None, None, None, R, 32, 512, 128, 96 * 96, None, 0, None, None), UNS, "c1r_fwd unserved (M, K)")
+expect(lib.wfae_c1r_fwd(P, 7, 1, Q, None, None, None, R, 32, 256, 64, 192 * 192, None, 0, None, None), SHAPE, "c1r_fwd weight strides")
+expect(lib.wfae_c1r_fwd(P, 256, 1, Q, None, None, S, R, 32, 256, 64, 192 * 192, None, 0, None, None), UNS, "c1r_fwd residual on a narrowing product")
+expect(lib.wfae_c1r_fwd(P, 256, 1, Q + 4, None, None, None, R, 32, 256, 64, 192 * 192, None, 0, None, None), UNS, "c1r_fwd misaligned x")
+expect(lib.wfae_c1r_fwd(P, 256, 1, Q, S, None, None, R, 32, 256, 64, 192 * 192, None, 0, None, None), NULL, "c1r_fwd scale without shift")
+rows_c = ctypes.c_int(0)
+expect(lib.wfae_c1r_fwd(P, 256, 1, Q, None, None, None, R, 32, 256, 64, 192 * 192, WS, 16, ctypes.cast(ctypes.pointer(rows_c), ctypes.c_void_p), None),
+       WSP, "c1r_fwd short stat buffer")
+for m, k, hw in [(32, 128, 384 * 384), (64, 256, 192 * 192), (128, 32, 384 * 384), (256, 64, 192 * 192)]:
+    expect(lib.wfae_c1r_fwd(P, k, 1, Q, S, S, S if m > k else None, R, 32, k, m, hw, WS, big, ctypes.cast(ctypes.pointer(rows_c), ctypes.c_void_p), None),
+           ANY_FAIL, f"c1r_fwd {k}->{m}")
+    expect(lib.wfae_c1r_fwd(P, 1, m, Q, None, None, None, R, 32, k, m, hw, None, 0, None, None), ANY_FAIL, f"c1r_fwd transposed {k}->{m}")
+assert lib.wfae_set_split_gemm(0) == 0
+expect(lib.wfae_c1r_fwd(P, 256, 1, Q, None, None, None, R, 32, 256, 64, 192 * 192, None, 0, None, None), UNS, "c1r_fwd needs the split switch")
+assert lib.wfae_set_split_gemm(1) == 0
 expect(lib.wfae_conv4x4s2_down(P, Q, R, 32, 256, 512, 96, 96, None), ANY_FAIL, "conv4x4s2_down")
 expect(lib.wfae_conv4x4s2_wgrad(P, Q, R, 32, 256, 512, 96, 96, 0, WS, big, None), ANY_FAIL, "conv4x4s2_wgrad")
 expect(lib.wfae_linear_fwd(P, Q, S, R, 32, 36864, 2048, WS, big, None), ANY_FAIL, "linear_fwd 36864->2048")
 expect(lib.wfae_linear_bwd_weight_splitk(P, Q, R, 2048, 512, 512, 0, WS, big, None), ANY_FAIL, "linear_bwd_weight_splitk")
-assert lib.wfae_version() == 102 and lib.wfae_workspace_bytes(1 << 24) >= (1 << 26)
+assert lib.wfae_version() == 103 and lib.wfae_workspace_bytes(1 << 24) >= (1 << 26)
 print(f"asan driver: {checked} calls, no sanitizer report")

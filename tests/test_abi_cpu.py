@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in _lib.parse_header():
         assert hasattr(lib, name), f"libwfae.so does not export {name}"
     bound = _lib.load()
-    assert bound.wfae_version() == 102
+    assert bound.wfae_version() == 103
     assert bound.wfae_workspace_bytes(1 << 24) >= (1 << 24) * 4
     assert bound.wfae_last_error_string() is not None
 

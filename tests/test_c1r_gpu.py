@@ -1,0 +1,101 @@
+"""csrc/c1r.hip — the register-direct 1x1 convolutions of the C <= 256 Bottleneck stages (pipeline/models/ae_64x8x8_lin.py:15,19),
+through the C ABI: against torch fp64 on the CPU (the oracle's primitive for this op is F.conv2d), against the fp32 kernels
+of gemm.hip on the same tensors, bit-identity of the fused BatchNorm + GELU prologue, and the BatchNorm sums of the epilogue."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests._util import relerr
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(32, 128), (64, 256), (128, 32), (256, 64)]     # (M, K) served: C = 128 and C = 256 stages, both directions
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * (hi - lo) + lo).float()
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from weatherforecastingtoolkit_amd import ops as o
+    return o
+
+
+def err64(y, ref64):
+    return float((y.double().cpu() - ref64).abs().max() / ref64.abs().max())
+
+
+@pytest.mark.parametrize("m,k", SHAPES)
+@pytest.mark.parametrize("nb,h,w", [(1, 8, 8), (3, 16, 20), (2, 24, 24), (37, 8, 16)])
+def test_c1r_forward_and_data_gradient_match_fp64_like_the_fp32_kernels(ops, dev, m, k, nb, h, w):
+    """forward (A = w) and data gradient (A = w^T) on c1r vs fp64; the error must stay at the level of gemm.hip's exact-fp32
+    MFMA kernel on the same tensors.  Grids from one partial block (8 tiles) to several tiles per wave (37 images)."""
+    assert ops.c1r_supported(m, k, h * w)
+    x = rnd((nb, k, h, w), 1).to(dev)
+    wt = rnd((m, k, 1, 1), 2, -0.3, 0.3).to(dev)           # forward weight (Cout = m, Cin = k)
+    wt_t = rnd((k, m, 1, 1), 3, -0.3, 0.3).to(dev)         # a (Cout = k, Cin = m) weight whose data gradient is the same product
+    ref_f = F.conv2d(x.double().cpu(), wt.double().cpu())
+    ref_d = F.conv_transpose2d(x.double().cpu(), wt_t.double().cpu())
+    res = {}
+    for on in (False, True):
+        ops.set_c1r(on)
+        try:
+            res[on] = (ops.conv1x1_fwd(x, wt), ops.conv1x1_bwd_data(x, wt_t))
+        finally:
+            ops.set_c1r(True)
+    assert not torch.equal(res[True][0], res[False][0]), "c1r did not run (same bits as gemm.hip)"
+    for i, ref in enumerate((ref_f, ref_d)):
+        e_old, e_new = err64(res[False][i], ref), err64(res[True][i], ref)
+        assert e_new <= max(2.0 * e_old, 2e-6), (i, e_new, e_old)
+
+
+@pytest.mark.parametrize("m,k", SHAPES)
+def test_c1r_prologue_residual_and_stats(ops, dev, m, k):
+    nb, h, w = 5, 16, 24
+    x = rnd((nb, k, h, w), 4, -2.0, 2.0).to(dev)
+    wt = rnd((m, k, 1, 1), 5, -0.3, 0.3).to(dev)
+    r = rnd((nb, m, h, w), 6).to(dev) if m > k else None
+    ones, zeros = torch.ones(k, device=dev), torch.zeros(k, device=dev)
+    st = ops.bn_stats_train(x, rnd((k,), 7, 0.5, 1.5).to(dev), rnd((k,), 8).to(dev), zeros.clone(), ones.clone())
+    a = ops.bn_act_fwd(x, st, 1)
+    # (1) the fused BatchNorm + GELU prologue is bit-identical to the two-kernel form
+    y_two = ops.conv1x1_fwd(a, wt, None, r)
+    y_fused = ops.conv1x1_fwd_bnact(x, st, wt, None, r)
+    assert torch.equal(y_two, y_fused)
+    ref = F.conv2d(a.double().cpu(), wt.double().cpu()) + (0 if r is None else r.double().cpu())
+    assert err64(y_fused, ref) < 3e-6
+    # (2) BatchNorm sums of the epilogue == the separate statistics pass on the stored tensor; the result is unchanged
+    gamma, beta = rnd((m,), 9, 0.5, 1.5).to(dev), rnd((m,), 10).to(dev)
+    for fn in (lambda: ops.conv1x1_fwd_stats(a, wt, None, r), lambda: ops.conv1x1_fwd_bnact(x, st, wt, None, r, stats=True)):
+        y, sr = fn()
+        assert torch.equal(y, y_two) and sr is not None
+        rm0, rv0, rm1, rv1 = torch.zeros(m, device=dev), torch.ones(m, device=dev), torch.zeros(m, device=dev), torch.ones(m, device=dev)
+        s_sep = ops.bn_stats_train(y, gamma, beta, rm0, rv0)
+        s_epi = ops.bn_stats_from_rows(sr, tuple(y.shape), gamma, beta, rm1, rv1)
+        for name in ("mean", "invstd", "scale", "shift"):
+            assert relerr(getattr(s_epi, name), getattr(s_sep, name)) < 2e-7, name
+        assert relerr(rm1, rm0) < 2e-7 and relerr(rv1, rv0) < 2e-7
+    # (3) repeat launches are bit-identical (fixed tile -> wave assignment, no atomics)
+    y2, sr2 = ops.conv1x1_fwd_bnact(x, st, wt, None, r, stats=True)
+    assert torch.equal(y2, y_two) and torch.equal(sr2.part, sr.part)
+
+
+def test_c1r_full_size_stage_shapes(ops, dev):
+    """the four products at B = 32 and the model's resolutions (384x384 with 128 channels, 192x192 with 256): a linearity check
+    that needs no CPU reference — conv(x1 + x2) == conv(x1) + conv(x2) to fp32 rounding, and the last tile of the last image is written"""
+    for c, hh in ((128, 384), (256, 192)):
+        mid = c // 4
+        for m, k in ((mid, c), (c, mid)):
+            x1 = (torch.rand((32, k, hh, hh), device=dev) - 0.5)
+            x2 = (torch.rand((32, k, hh, hh), device=dev) - 0.5)
+            wt = (torch.rand((m, k, 1, 1), device=dev) - 0.5) * 0.2
+            y1, y2 = ops.conv1x1_fwd(x1, wt), ops.conv1x1_fwd(x2, wt)
+            x1 += x2
+            y12 = ops.conv1x1_fwd(x1, wt)
+            y1 += y2
+            d = float((y12 - y1).abs().max() / y1.abs().max())
+            assert d < 2e-6, (m, k, d)
+            assert float(y12[-1, :, -1, -64:].abs().min()) > 0.0
+            del x1, x2, y1, y2, y12

@@ -180,3 +180,81 @@ def test_rccl_backend_single_rank(dev):
     p.join(60)
     assert res[0] is True and res[1] == 1 and res[2] == "nccl", res
     assert p.exitcode == 0
+
+
+def _gan_worker(rank, world, port, q):
+    """AE+GAN step (experiments/ae_v2_2) on two ranks: the generator's all-reduce started before the discriminator's forward /
+    backward and finished after it (BASELINE config 5's overlap) against the reference's literal serial order"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    try:
+        import weatherforecastingtoolkit_amd.experiments.ae_v2_2 as pkg
+        from weatherforecastingtoolkit_amd import config as C, functional as Fn, parallel, synth
+        from weatherforecastingtoolkit_amd.experiments.ae_v2_2.train import CARRIED_KEYS, Model
+        parallel.init_from_env("gloo")
+        dev = torch.device("cuda:0")
+        cfg = C.load(os.path.join(os.path.dirname(pkg.__file__), "config.yaml"), CARRIED_KEYS)
+        cfg.trainer.total_train_steps = 10
+        cfg.lpips.disc_start = 0
+        x = torch.from_numpy(synth.uniform_frames(4, 128, seed=21))[2 * rank:2 * rank + 2].to(dev)
+        out, started = [], []
+        for overlap in (False, True):
+            torch.manual_seed(7)
+            model = Model(cfg, img_size=128).to(dev).train()
+            model.overlap_exchange = overlap
+            Fn.set_wgrad_overlap(True)
+            model.configure_optimizers()
+            calls = [0]
+            orig = model._dp[0].start_reduce
+
+            def counted(orig=orig, calls=calls):
+                calls[0] += 1
+                pending_before = len(model._dp[0]._pending)
+                orig()
+                calls.append(len(model._dp[0]._pending) - pending_before)
+
+            model._dp[0].start_reduce = counted
+            logs = None
+            for _ in range(2):
+                _, logs = model.training_step({"vil": x}, 0)
+            Fn.join_side_stream()
+            torch.cuda.synchronize()
+            started.append(calls)
+            out.append((model.g_opt.arenas[0].flat_p.clone(), model.d_opt.arenas[0].flat_p.clone(),
+                        float(logs["train/g_grad_norm"]), float(logs["train/d_grad_norm"])))
+            Fn.set_wgrad_overlap(False)
+        same_order = torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and out[0][2:] == out[1][2:]
+        gl = [torch.zeros_like(out[1][0]) for _ in range(world)]
+        dist.all_gather(gl, out[1][0])
+        dl = [torch.zeros_like(out[1][1]) for _ in range(world)]
+        dist.all_gather(dl, out[1][1])
+        same_ranks = torch.equal(gl[0], gl[1]) and torch.equal(dl[0], dl[1])
+        q.put((rank, bool(same_order), bool(same_ranks), started))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "error", repr(e) + traceback.format_exc()[-1500:], None))
+
+
+def test_gan_generator_exchange_under_discriminator_backward(dev):
+    """VERDICT r3 item 3 / SURVEY 8(f) next-2: with the generator's gradient exchange overlapping the discriminator's forward
+    and backward, two G-then-D optimiser steps give BIT-IDENTICAL generator and discriminator parameters and gradient norms
+    to the serial order, on both ranks; the overlapped runs really took the split path (asynchronous all-reduces in flight
+    when the discriminator's work was queued)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_gan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in ps)
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, same_order, same_ranks, started in res:
+        assert same_order is True, (rank, same_order, same_ranks)
+        assert same_ranks is True
+        serial, over = started
+        # serial order: start_reduce only from inside reduce_gradients (one per step); overlapped: called by training_step and
+        # it left asynchronous work pending (> 0 handles) each time
+        assert serial[0] == 2 and over[0] == 2 and all(n > 0 for n in over[1:]), started

@@ -61,8 +61,8 @@ def test_conv1x1(ops, dev, nb, cin, cout, h, w):
 @pytest.mark.parametrize("nb,cin,cout,h,w,res,served", [
     (8, 64, 256, 64, 64, True, True), (8, 256, 64, 96, 96, False, True), (16, 32, 128, 64, 48, True, True),
     (3, 128, 512, 96, 96, False, True),
-    (2, 32, 128, 16, 16, True, False),      # under-filled grid: the 32-row kernel (four wave columns) runs
-    (5, 128, 32, 16, 8, False, False), (2, 18, 33, 5, 5, False, False)])
+    (2, 32, 128, 16, 16, True, True), (5, 128, 32, 16, 8, False, True),     # csrc/c1r.hip: one partial row per wave
+    (2, 18, 33, 5, 5, False, False)])
 def test_conv1x1_fused_bn_stats(ops, dev, nb, cin, cout, h, w, res, served):
     """BatchNorm statistics reduced in the GEMM epilogue (wfae_conv1x1_fwd_stats + wfae_bn_stats_from_rows) equal
     wfae_bn_stats_train on the stored output: scale / shift / saved statistics and the running-stat update; shapes the

@@ -203,7 +203,7 @@ def test_grouped3x3_weight_gradient_on_split_planes_matches_fp32_accuracy(ops, d
     assert float((dw2 - 2 * res[True]).abs().max()) <= 1e-6 * float(res[True].abs().max())
 
 
-@pytest.mark.parametrize("nb,c,h,w", [(2, 64, 48, 192), (1, 64, 72, 192), (2, 128, 48, 96), (1, 128, 96, 96)])
+@pytest.mark.parametrize("nb,c,h,w", [(2, 128, 48, 96), (1, 128, 96, 96)])
 def test_grouped3x3_forward_on_split_planes_matches_fp32_accuracy(ops, dev, nb, c, h, w):
     """csrc/g3b.hip g3b_kernel on fp32 tensors (x and the weights as three exact bf16 planes, six products per fp32 product,
     tap shifts on the output side) against fp64, forward and data gradient, beside the dconv.hip kernels on the same data"""
@@ -219,7 +219,7 @@ def test_grouped3x3_forward_on_split_planes_matches_fp32_accuracy(ops, dev, nb, 
     res = {}
     from weatherforecastingtoolkit_amd import _lib
 
-    def direct(t, tr):   # the entry point itself: (8, 192) is served but not routed (measured slower than dconv.hip's kernel)
+    def direct(t, tr):   # the entry point itself
         out, ws = torch.empty_like(t), ops.workspace()
         _lib.call("wfae_g3b_fwd", t.data_ptr(), wt.data_ptr(), out.data_ptr(), nb, c, h, w, groups, int(tr), ws.data_ptr(),
                   ws.numel(), torch.cuda.current_stream().cuda_stream)

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-gan", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--serial-exchange", action="store_true", help="the reference's literal order: G exchange + step before the D pass")
     ap.add_argument("--precision", choices=["highest", "medium"], default="highest")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -40,6 +41,7 @@ def main():
     model = Model(cfg, img_size=a.size).to(dev).train()
     Fn.set_wgrad_overlap(not a.no_overlap)
     model.configure_optimizers()
+    model.overlap_exchange = not a.serial_exchange
     x = torch.from_numpy(synth.uniform_frames(a.batch, a.size, seed=1234)).to(dev)
     for _ in range(a.warmup):
         model.training_step({"vil": x}, 0)
@@ -52,7 +54,11 @@ def main():
     print(json.dumps({"workload": f"ae_v2_2 AE{'' if a.no_gan else '+GAN'} step {a.size}x{a.size} B={a.batch} "
                                   f"{'fp32' if a.precision == 'highest' else 'bf16 operands'}",
                       "ms_per_step": ms, "frames_per_s": a.batch / ms * 1e3,
-                      "mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30}), flush=True)
+                      "mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
+                      "dp": {"world": model._dp[0].world, "overlap": bool(model.overlap_exchange),
+                             "note": "generator all-reduce started before, finished after the discriminator's forward / backward "
+                                     "(experiments/ae_v2_2/train.py::training_step); one rank here: no collective runs, never "
+                                     "timed on RCCL"}}), flush=True)
     Fn.set_wgrad_overlap(False)
     ops.profile_start()
     for _ in range(2):

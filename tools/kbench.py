@@ -120,69 +120,34 @@ def main():
                     acc("conv1_" + nm, ms, 4)
                 del x, w, dy, r, dw
     if "c1" in only:
-        # csrc/c1gemm.hip against the kernels it replaces, per Bottleneck stage: forward / data gradient of both 1x1
-        # convolutions, and the BatchNorm-backward sequences of the first BatchNorm (C channels):
-        #   old   : conv1x1_bwd_data + bn_act_bwd (reduce pass + dx pass)
-        #   bnred : c1gemm_bnred (reduce in the GEMM epilogue) + finalize + dx pass
-        #   recomp: c1gemm_bnred(store=False) + finalize + c1gemm_bndx (da never in HBM)
-        for c, h in stages[:4] + stages[7:]:
-            mult = 4 if c == 128 or h == S // 16 else 8
+        # csrc/c1r.hip (register-direct, exact three-plane bf16 operands) against gemm.hip's kernels, per Bottleneck stage it
+        # serves: the four 1x1 products in the forms the step launches them (prologue / residual / BatchNorm sums)
+        for c, h in [(256, S // 2), (128, S)]:
+            mult = 4 if c == 128 else 8
             mid = c // 4
             n = B * h * h
             x, t2 = rnd(B, c, h, h), rnd(B, mid, h, h)
             w1, w3 = rnd(mid, c, 1, 1) * c ** -0.5, rnd(c, mid, 1, 1) * mid ** -0.5
             g, b_, rm, rv = torch.ones(c, device=dev), torch.zeros(c, device=dev), torch.zeros(c, device=dev), torch.ones(c, device=dev)
             st = ops.bn_stats_train(x, g, b_, rm, rv)
-            dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
-            W1, W1t = ops.c1_split_weights(w1)
-            W3, W3t = ops.c1_split_weights(w3)
+            g3, b3 = torch.ones(mid, device=dev), torch.zeros(mid, device=dev)
+            st3 = ops.bn_stats_train(t2, g3, b3, torch.zeros(mid, device=dev), torch.ones(mid, device=dev))
             fl = 2 * n * c * mid
             by1, by3 = 4 * n * (c + mid), 4 * n * (c + mid) + 4 * n * c
-            rows = []
-            if ops.c1gemm_supported(mid, c, h * h):
-                rows += [(f"fwd  {c}->{mid} bnact old", lambda: ops.conv1x1_fwd_bnact(x, st, w1), fl, by1, "fwd1_old"),
-                         (f"fwd  {c}->{mid} bnact c1gemm", lambda: ops.c1gemm_fwd(W1, x, st), fl, by1, "fwd1_c1"),
-                         (f"dgrad {c}->{mid} (da3) old", lambda: ops.conv1x1_bwd_data(x, w3), fl, by1, "dgrad3_old"),
-                         (f"dgrad {c}->{mid} (da3) c1gemm", lambda: ops.c1gemm_fwd(W3t, x), fl, by1, "dgrad3_c1")]
-            if ops.c1gemm_supported(c, mid, h * h):
-                rows += [(f"fwd  {mid}->{c} +res old", lambda: ops.conv1x1_fwd(t2, w3, None, x), fl, by3, "fwd3_old"),
-                         (f"fwd  {mid}->{c} +res c1gemm", lambda: ops.c1gemm_fwd(W3, t2, None, x), fl, by3, "fwd3_c1"),
-                         (f"dgrad {mid}->{c} (da1) old", lambda: ops.conv1x1_bwd_data(t2, w1), fl, by1, "dgrad1_old"),
-                         (f"dgrad {mid}->{c} (da1) c1gemm", lambda: ops.c1gemm_fwd(W1t, t2), fl, by1, "dgrad1_c1")]
-
-                def seq_old():
-                    da = ops.conv1x1_bwd_data(t2, w1)
-                    ops.bn_act_bwd(da, x, g, st, dg, db, x, 1, True)
-
-                def seq_red():
-                    da, sr = ops.c1gemm_bnred(W1t, t2, x, st)
-                    ops.bn_act_bwd_from_rows(sr, c, dg, db)
-                    ops.bn_act_bwd_dx(da, x, g, st, x, 1, True)
-
-                def seq_rec():
-                    _, sr = ops.c1gemm_bnred(W1t, t2, x, st, store=False)
-                    ops.bn_act_bwd_from_rows(sr, c, dg, db)
-                    ops.c1gemm_bndx(W1t, t2, x, g, st, x, True)
-                def seq_red0():
-                    da, sr = ops.conv1x1_bwd_data_bnred(t2, w1, x, st)
-                    ops.bn_act_bwd_from_rows(sr, c, dg, db)
-                    ops.bn_act_bwd_dx(da, x, g, st, x, 1, True)
-
-                def seq_rec0():
-                    _, sr = ops.conv1x1_bwd_data_bnred(t2, w1, x, st, store=False)
-                    ops.bn_act_bwd_from_rows(sr, c, dg, db)
-                    ops.conv1x1_bwd_data_bndx(t2, w1, x, g, st, x, True)
-                byo = 4 * n * (mid + c) + 4 * n * 2 * c + 4 * n * 4 * c
-                rows += [(f"bn1 bwd C={c}: gemm.hip bnred + dx", seq_red0, fl, byo - 4 * n * c, "bn1seq_gemm_bnred"),
-                         (f"bn1 bwd C={c}: gemm.hip bnred(no store) + bndx", seq_rec0, 2 * fl, 4 * n * (2 * mid + 5 * c), "bn1seq_gemm_recompute"),
-                         (f"bn1 bwd C={c}: dgrad + reduce + dx (old)", seq_old, fl, byo, "bn1seq_old"),
-                         (f"bn1 bwd C={c}: bnred + dx", seq_red, fl, byo - 4 * n * c, "bn1seq_bnred"),
-                         (f"bn1 bwd C={c}: bnred(no store) + bndx", seq_rec, 2 * fl, 4 * n * (2 * mid + 5 * c), "bn1seq_recompute")]
+            rows = [(f"fwd  {c}->{mid} bnact+stats", lambda: ops.conv1x1_fwd_bnact(x, st, w1, stats=True), fl, by1, "fwd1"),
+                    (f"fwd  {c}->{mid} plain", lambda: ops.conv1x1_fwd(x, w1), fl, by1, "fwd1_plain"),
+                    (f"dgrad {c}->{mid} (da3)", lambda: ops.conv1x1_bwd_data(x, w3), fl, by1, "dgrad3"),
+                    (f"fwd  {mid}->{c} +res+stats", lambda: ops.conv1x1_fwd_stats(t2, w3, None, x), fl, by3, "fwd3"),
+                    (f"fwd  {mid}->{c} bnact+res+stats", lambda: ops.conv1x1_fwd_bnact(t2, st3, w3, None, x, stats=True), fl, by3, "fwd3_bnact"),
+                    (f"dgrad {mid}->{c} (da1)", lambda: ops.conv1x1_bwd_data(t2, w1), fl, by1, "dgrad1")]
             for tag, fn, f_, b2, key in rows:
-                ms = timeit(fn, R)
-                report(f"c1 @{h} {tag}", ms, f_, b2)
-                acc(key, ms, mult)
-            del x, t2, w1, w3, W1, W1t, W3, W3t
+                for on in (False, True):
+                    ops.set_c1r(on)
+                    ms = timeit(fn, R)
+                    report(f"c1 @{h} {tag} {'c1r' if on else 'gemm.hip'}", ms, f_, b2)
+                    acc(key + ("_c1r" if on else "_old"), ms, mult)
+            ops.set_c1r(True)
+            del x, t2, w1, w3
     if "c1b" in only:
         # bf16 storage ('medium'): csrc/c1b.hip against gemm.hip's bf16-storage kernels, per Bottleneck stage
         ops.set_float32_matmul_precision("medium")

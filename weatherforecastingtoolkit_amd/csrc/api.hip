@@ -40,7 +40,7 @@ int fail(int code, const char* fmt, ...) {
 
 extern "C" {
 
-int wfae_version(void) { return 102; }  // 0.1.2 (see the ABI history in include/wfae.h)
+int wfae_version(void) { return 103; }  // 0.1.3 (see the ABI history in include/wfae.h)
 
 int wfae_set_matmul_precision(int mode) {
   WFAE_REQUIRE(mode == WFAE_PRECISION_FP32 || mode == WFAE_PRECISION_BF16, WFAE_ERR_BAD_SHAPE,

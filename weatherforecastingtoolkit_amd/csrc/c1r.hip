@@ -1,0 +1,388 @@
+// c1r.hip — the Bottleneck's 1x1 convolutions (pipeline/models/ae_64x8x8_lin.py:15,19) forward and data gradient on fp32
+// tensors at the HBM-bound stages (C <= 256: 128 @384x384 and 256 @192x192 hold two thirds of the family's bytes):
+//   Y[img][m][p] = sum_k A[m][k] f(X[img][k][p]) (+ res[img][m][p])        m < M, k < K, p < HW
+// "REGISTER-DIRECT": the activation never passes through LDS.  v_mfma_f32_16x16x32_bf16 wants, per lane, eight consecutive
+// k of ONE column; NCHW has the pixel contiguous.  A lane therefore loads eight rows k0 + 8 (l >> 4) + i (i < 8) as 16-byte
+// pieces of FOUR consecutive pixels 4 (l & 15) .. + 3 and feeds component jj of the eight pieces to the jj-th of four MFMAs:
+// the column of MFMA jj handled by lane n is pixel 4 n + jj — a relabelling of columns that the result layout undoes for
+// free, because a lane's accumulators [jj = 0..3][q] are four consecutive pixels of row 4 (l >> 4) + q: one 16-byte store.
+//   * every global access is a 16-byte piece of a 256-byte row segment (4 rows per wave-instruction), loads and stores
+//     alike; no LDS transpose, no LDS epilogue, no block barrier after the prologue: the 8 waves of a block run free of
+//     each other, so one wave's split / GELU arithmetic and MFMAs sit under the others' memory waits;
+//   * fp32 accuracy on the bf16 matrix pipe: every loaded value is split ONCE (each wave owns all M rows of its 64
+//     pixels) into three exact bf16 planes in registers (x = h + m + l, split3 of common.h), six products per fp32
+//     product, smallest terms first (splitgemm.hip);
+//   * the weights (<= 16 K values) are split by the block itself on its way in and stay in LDS as the three-plane row
+//     image of splitgemm.hip (off_row16: conflict-free ds_read_b128 fragments) for the whole launch — blocks are
+//     persistent, one per CU, each wave strides over 64-pixel tiles (adjacent waves take adjacent tiles: 2 KiB of every
+//     row at a time per block);
+//   * narrowing products (K = C, M = C/4: the C -> C/4 forward and the C/4 -> C data gradient... of the other conv): the K
+//     loop streams 32-row chunks, one chunk of loads in flight ahead of the multiply, all M rows accumulate at once;
+//     widening products (K = C/4, M = C): the split operand of the tile stays in registers and M is walked in passes of
+//     16 MG rows with the residual rows of the next pass and the first chunk of the next tile in flight;
+//   * optional BatchNorm + GELU prologue f = gelu(x * scale[k] + shift[k]) (bn_act_fwd_kernel's arithmetic, as in
+//     gemm.hip's PRO loaders), residual add, and the BatchNorm sums of the result: fp32 sums of four, fp64 across the
+//     16 lanes of a DPP row, accumulated in fp64 per wave in LDS over all its tiles and written as ONE partial row per
+//     wave (the StatRows format of wfae_conv1x1_fwd_stats, finished by wfae_bn_stats_from_rows).
+#include "common.h"
+#include <stdlib.h>
+
+using namespace wfae;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct C1RP {
+  const float* W;            // A[m][k] = W[m * w_sm + k * w_sk]
+  long w_sm, w_sk;
+  const float* X;            // [NB][K][HW]
+  float* Y;                  // [NB][M][HW]
+  const float* res;          // [NB][M][HW] or null
+  const float* pro_scale;    // PRO: folded BatchNorm scale / shift of the input channels [K]
+  const float* pro_shift;
+  double* part0;             // STATS: [gridDim.x * 8][M] sums, one row per wave
+  double* part1;             // sums of squares
+  int HW;                    // % 64 == 0: a 64-pixel tile never leaves its image
+  int tpi;                   // tiles per image
+  int ntiles;
+};
+
+
+// row image of splitgemm.hip for 16-row ds_read_b128 fragments (lane = row l & 15, 16-byte chunk l >> 4)
+__device__ __forceinline__ unsigned swz16(int r) { return (0x78u >> (((r >> 2) & 3) << 1)) & 3u; }
+
+#define C1R_DPP_F64(v, CTRL)                                                                                     \
+  __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true),                       \
+                   __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true))
+__device__ __forceinline__ double row_sum16(double v) {   // lane 15 of every 16-lane DPP row ends up with the row total
+  v += C1R_DPP_F64(v, 0x111);
+  v += C1R_DPP_F64(v, 0x112);
+  v += C1R_DPP_F64(v, 0x114);
+  v += C1R_DPP_F64(v, 0x118);
+  return v;
+}
+
+// two values -> their three exact bf16 planes, packed (a in the low half)
+struct Planes3 { unsigned h, m, l; };
+__device__ __forceinline__ Planes3 split_pair(float a, float b) {
+  Planes3 r;
+  r.h = pack_bf16(a, b);
+  const float a1 = a - bf16_lo(r.h), b1 = b - bf16_hi(r.h);
+  r.m = pack_bf16(a1, b1);
+  r.l = pack_bf16(a1 - bf16_lo(r.m), b1 - bf16_hi(r.m));
+  return r;
+}
+
+template <int KCH, int MT, int MG, bool PRO, bool STATS, int RWAVES = 8>
+__global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel(C1RP p) {
+  constexpr int RNT = 64 * RWAVES;
+  constexpr int K = 32 * KCH, M = 16 * MT, NPASS = MT / MG;
+  constexpr bool BRES = NPASS > 1;                 // the split operand of a tile stays in registers, M in passes
+  static_assert(MT % MG == 0, "whole passes");
+  constexpr int PLANE_B = M * 64;                  // one plane of one 32-deep chunk: M rows x 64 bytes
+  constexpr int A_B = KCH * 3 * PLANE_B;
+  constexpr int PRO_B = PRO ? 2 * K * 4 : 0;
+  constexpr int ST_B = STATS ? RWAVES * 2 * M * 8 : 0;
+  static_assert(A_B + PRO_B + ST_B <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[A_B + PRO_B + ST_B];
+  float* const lsc = reinterpret_cast<float*>(smem + A_B);
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int n16 = lane & 15, kg = lane >> 4;
+  double* const lst = reinterpret_cast<double*>(smem + A_B + PRO_B) + (STATS ? wave * 2 * M : 0);
+
+  // ---- the weights: split on the way in, three-plane row image [chunk][plane][m][64 B]
+  {
+    const bool kfast = p.w_sk == 1;
+    for (int idx = t; idx < M * K / 8; idx += RNT) {
+      int m, ch;
+      if (kfast) { ch = idx % (K / 8); m = idx / (K / 8); } else { m = idx % M; ch = idx / M; }
+      const float* src = p.W + (long)m * p.w_sm + (long)(8 * ch) * p.w_sk;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = src[(long)e * p.w_sk];
+      const Planes3 q0 = split_pair(v[0], v[1]), q1 = split_pair(v[2], v[3]), q2 = split_pair(v[4], v[5]), q3 = split_pair(v[6], v[7]);
+      const u32x4 h = {q0.h, q1.h, q2.h, q3.h}, mm = {q0.m, q1.m, q2.m, q3.m}, l = {q0.l, q1.l, q2.l, q3.l};
+      const unsigned off = (unsigned)((ch >> 2) * 3 * PLANE_B + m * 64) + ((((unsigned)ch & 3u) ^ swz16(m)) << 4);
+      *reinterpret_cast<u32x4*>(smem + off) = h;
+      *reinterpret_cast<u32x4*>(smem + off + PLANE_B) = mm;
+      *reinterpret_cast<u32x4*>(smem + off + 2 * PLANE_B) = l;
+    }
+    if constexpr (PRO) {
+      for (int i = t; i < K; i += RNT) {
+        lsc[i] = p.pro_scale[i];
+        lsc[K + i] = p.pro_shift[i];
+      }
+    }
+    if constexpr (STATS) {
+      for (int i = lane; i < 2 * M; i += 64) lst[i] = 0.0;
+    }
+  }
+  __syncthreads();
+
+  const long rowB = (long)p.HW * 4;                                          // bytes between two channel rows
+  const unsigned lane_in = (unsigned)((4 * n16 + 8 * kg * p.HW) * 4);       // this lane's piece of row 8 kg (+ i rows)
+  const unsigned lane_out = (unsigned)((4 * n16 + 4 * kg * p.HW) * 4);      // result rows 4 kg + q
+  const unsigned a_rd = (unsigned)(n16 * 64) + (((unsigned)kg ^ swz16(n16)) << 4);
+  const int tstride = gridDim.x * RWAVES;
+  int tile = blockIdx.x * RWAVES + wave;
+
+  auto tile_off = [&](int tl, int chans) -> long {   // byte offset of a tile's first pixel in a [NB][chans][HW] tensor
+    const int img = tl / p.tpi;
+    return ((long)img * chans * p.HW + (long)(tl - img * p.tpi) * 64) * 4;
+  };
+  auto load_chunk = [&](f32x4 (&r)[8], int tl, int c) {
+    const char* xb = reinterpret_cast<const char*>(p.X) + tile_off(tl, K) + (long)(32 * c) * rowB;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = *reinterpret_cast<const f32x4*>(xb + i * rowB + lane_in);
+  };
+  // prologue + split of one chunk: b[jj][plane] = the eight k of this lane, pixel 4 n16 + jj
+  auto split_chunk = [&](f32x4 (&r)[8], u32x4 (&b)[4][3], int c) {
+    if constexpr (PRO) {
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(lsc + 32 * c + 8 * kg), s1 = *reinterpret_cast<const f32x4*>(lsc + 32 * c + 8 * kg + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(lsc + K + 32 * c + 8 * kg), h1 = *reinterpret_cast<const f32x4*>(lsc + K + 32 * c + 8 * kg + 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float s = i < 4 ? s0[i & 3] : s1[i & 3], h = i < 4 ? h0[i & 3] : h1[i & 3];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) r[i][jj] = gelu_f(fmaf(r[i][jj], s, h));
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const Planes3 q0 = split_pair(r[0][jj], r[1][jj]), q1 = split_pair(r[2][jj], r[3][jj]);
+      const Planes3 q2 = split_pair(r[4][jj], r[5][jj]), q3 = split_pair(r[6][jj], r[7][jj]);
+      b[jj][0] = u32x4{q0.h, q1.h, q2.h, q3.h};
+      b[jj][1] = u32x4{q0.m, q1.m, q2.m, q3.m};
+      b[jj][2] = u32x4{q0.l, q1.l, q2.l, q3.l};
+    }
+  };
+  // acc[mt][jj] += A(rows 16 (mt0 + mt) .., chunk c) x b: six products per fp32 product, smallest terms first
+  auto multiply = [&](f32x4 (&acc)[MG][4], const u32x4 (&b)[4][3], int c, int a_pass_off) {
+#pragma unroll
+    for (int mt = 0; mt < MG; ++mt) {
+      bf16x8 a[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        a[pl] = *reinterpret_cast<const bf16x8*>(smem + a_pass_off + (c * 3 + pl) * PLANE_B + mt * (16 * 64) + a_rd);
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          acc[mt][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[pr]], __builtin_bit_cast(bf16x8, b[jj][PB[pr]]), acc[mt][jj], 0, 0, 0);
+    }
+  };
+  auto load_res = [&](f32x4 (&rv)[MG][4], int tl, int mt0) {
+    const char* rb = reinterpret_cast<const char*>(p.res) + tile_off(tl, M) + (long)(16 * mt0) * rowB;
+#pragma unroll
+    for (int mt = 0; mt < MG; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rv[mt][q] = *reinterpret_cast<const f32x4*>(rb + (16 * mt + q) * rowB + lane_out);
+  };
+  // lane (n16, kg): acc[mt][jj][q] = Y[row 16 (mt0 + mt) + 4 kg + q][pixel 4 n16 + jj]
+  auto store_pass = [&](const f32x4 (&acc)[MG][4], const f32x4 (&rv)[MG][4], bool with_res, int tl, int mt0) {
+    char* yb = reinterpret_cast<char*>(p.Y) + tile_off(tl, M) + (long)(16 * mt0) * rowB;
+#pragma unroll
+    for (int mt = 0; mt < MG; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = {acc[mt][0][q], acc[mt][1][q], acc[mt][2][q], acc[mt][3][q]};
+        if (with_res) v += rv[mt][q];
+        *reinterpret_cast<f32x4*>(yb + (16 * mt + q) * rowB + lane_out) = v;
+        if constexpr (STATS) {   // fp32 sums of four enter the fp64 reduction, as in chan_reduce_kernel
+          const float s1 = (v.x + v.y) + (v.z + v.w);
+          const float s2 = fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);
+          const double d1 = row_sum16((double)s1), d2 = row_sum16((double)s2);
+          if (n16 == 15) {
+            const int m = 16 * (mt0 + mt) + 4 * kg + q;
+            lst[m] += d1;
+            lst[M + m] += d2;
+          }
+        }
+      }
+  };
+
+  const bool with_res = p.res != nullptr;
+  if (tile < p.ntiles) {
+    f32x4 cur[8];
+    load_chunk(cur, tile, 0);
+    if constexpr (!BRES) {
+      // ---- narrowing: stream the K chunks, all M rows at once
+      while (tile < p.ntiles) {
+        const int nxt_tile = tile + tstride < p.ntiles ? tile + tstride : tile;   // past the end: a harmless re-read
+        f32x4 acc[MG][4];
+        f32x4 rv[MG][4];   // never read: the narrowing products of the model carry no residual (the host refuses one)
+#pragma unroll
+        for (int mt = 0; mt < MG; ++mt)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[mt][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+          f32x4 nxt[8];
+          if (c + 1 < KCH) load_chunk(nxt, tile, c + 1);
+          else load_chunk(nxt, nxt_tile, 0);
+          // ONE chunk of loads in flight ahead of the multiply: without the fences the scheduler hoists the loads of every
+          // chunk of the unrolled loop to the top (128 - 256 staging registers, spills)
+          __builtin_amdgcn_sched_barrier(0);
+          u32x4 b[4][3];
+          split_chunk(cur, b, c);
+          multiply(acc, b, c, 0);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        store_pass(acc, rv, false, tile, 0);
+        tile += tstride;
+      }
+    } else {
+      // ---- widening: the tile's split operand stays in registers, M in passes of 16 MG rows
+      while (tile < p.ntiles) {
+        const int nxt_tile = tile + tstride < p.ntiles ? tile + tstride : tile;
+        f32x4 more[KCH > 1 ? KCH - 1 : 1][8];
+#pragma unroll
+        for (int c = 1; c < KCH; ++c) load_chunk(more[c - 1], tile, c);
+        f32x4 rcur[MG][4], rnxt[MG][4];
+        if (with_res) load_res(rcur, tile, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 b[KCH][4][3];
+        split_chunk(cur, b[0], 0);
+#pragma unroll
+        for (int c = 1; c < KCH; ++c) split_chunk(more[c - 1], b[c], c);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int pass = 0; pass < NPASS; ++pass) {
+          const int mt0 = pass * MG;
+          if (pass + 1 < NPASS) {
+            if (with_res) load_res(rnxt, tile, mt0 + MG);
+          } else {
+            load_chunk(cur, nxt_tile, 0);   // the first chunk of the wave's next tile travels under the last pass
+          }
+          f32x4 acc[MG][4];
+#pragma unroll
+          for (int mt = 0; mt < MG; ++mt)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[mt][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < KCH; ++c) multiply(acc, b[c], c, mt0 * (16 * 64));
+          store_pass(acc, rcur, with_res, tile, mt0);
+          if (with_res && pass + 1 < NPASS) {
+#pragma unroll
+            for (int mt = 0; mt < MG; ++mt)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) rcur[mt][q] = rnxt[mt][q];
+          }
+        }
+        tile += tstride;
+      }
+    }
+  }
+  if constexpr (STATS) {   // one partial row per wave (zeros from a wave that had no tile)
+    const long row = (long)blockIdx.x * RWAVES + wave;
+    for (int i = lane; i < M; i += 64) {
+      p.part0[row * M + i] = lst[i];
+      p.part1[row * M + i] = lst[M + i];
+    }
+  }
+}
+
+struct Shape { int M, K; };
+// served (M, K): the Bottleneck products of the C = 128 and C = 256 stages
+inline int shape_id(int M, int K) {
+  if (M == 32 && K == 128) return 0;
+  if (M == 64 && K == 256) return 1;
+  if (M == 128 && K == 32) return 2;
+  if (M == 256 && K == 64) return 3;
+  return -1;
+}
+
+inline int num_cus() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  return n;
+}
+
+// waves per block, by shape.  Measured on one box (tools/kbench.py --only c1, profiles/r04_kbench_c1r_knobs.txt): every shape
+// runs one block per CU (the weight image of the C = 256 shapes fills the LDS); 8 waves except the widening C = 256 product,
+// whose 230-register waves run faster one per SIMD (0.545 -> 0.504 ms with residual + sums).  A block barrier per tile (to keep
+// the block's waves on adjacent tiles in phase) and three 4-wave blocks per CU at the C = 128 shapes changed nothing (+-2 %).
+inline int waves_of(int sid) { return sid == 3 ? 4 : 8; }
+
+inline int grid_for(long ntiles, int waves) {
+  const long g = (ntiles + waves - 1) / waves;
+  return (int)(g < num_cus() ? g : num_cus());
+}
+
+template <int KCH, int MT, int MG, int NW>
+void launch_shape(const C1RP& p, bool pro, bool stats, int grid, hipStream_t st) {
+  const dim3 g((unsigned)grid), b(64 * NW);
+  if (pro && stats) hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, true, true, NW>), g, b, 0, st, p);
+  else if (pro) hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, true, false, NW>), g, b, 0, st, p);
+  else if (stats) hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, false, true, NW>), g, b, 0, st, p);
+  else hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, false, false, NW>), g, b, 0, st, p);
+}
+
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int wfae_c1r_supported(int M, int K, int HW) {
+  return (shape_id(M, K) >= 0 && HW > 0 && HW % 64 == 0 && wfae::split_gemm_enabled()) ? 1 : 0;
+}
+
+int wfae_c1r_stat_rows(int M, int K, int NB, int HW) {
+  const int sid = shape_id(M, K);
+  if (sid < 0 || HW <= 0 || HW % 64 != 0 || NB <= 0) return 0;
+  return grid_for((long)NB * (HW / 64), waves_of(sid)) * waves_of(sid);
+}
+
+int wfae_c1r_fwd(const float* w, int64_t w_sm, int64_t w_sk, const float* x, const float* pro_scale, const float* pro_shift,
+                 const float* res, float* y, int NB, int K, int M, int HW, double* stat_part, int64_t stat_capacity, int* stat_rows,
+                 wfae_stream_t stream) {
+  WFAE_REQUIRE(w && x && y, WFAE_ERR_NULL_POINTER, "c1r_fwd: null pointer");
+  WFAE_REQUIRE(NB > 0 && K > 0 && M > 0 && HW > 0 && (int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "c1r_fwd: bad shape");
+  const int sid = shape_id(M, K);
+  WFAE_REQUIRE(sid >= 0 && HW % 64 == 0, WFAE_ERR_UNSUPPORTED,
+               "c1r_fwd: serves (M, K) = (32, 128), (64, 256), (128, 32), (256, 64) with HW %% 64 == 0 (M %d, K %d, HW %d)", M, K, HW);
+  WFAE_REQUIRE(wfae::split_gemm_enabled(), WFAE_ERR_UNSUPPORTED, "c1r_fwd: needs fp32 precision with the split GEMMs on");
+  WFAE_REQUIRE((w_sm == K && w_sk == 1) || (w_sm == 1 && w_sk == M), WFAE_ERR_BAD_SHAPE,
+               "c1r_fwd: the weight is (M, K) row-major (strides K, 1) or its transpose (strides 1, M)");
+  WFAE_REQUIRE(al16(x) && al16(y) && (!res || al16(res)), WFAE_ERR_UNSUPPORTED, "c1r_fwd: tensors must be 16-byte aligned");
+  WFAE_REQUIRE(!res || M > K, WFAE_ERR_UNSUPPORTED, "c1r_fwd: the residual add belongs to the widening products (M > K)");
+  WFAE_REQUIRE((pro_scale != nullptr) == (pro_shift != nullptr) && (stat_part != nullptr) == (stat_rows != nullptr),
+               WFAE_ERR_NULL_POINTER, "c1r_fwd: scale / shift and stat_part / stat_rows go together");
+  C1RP p = {};
+  p.W = w; p.w_sm = w_sm; p.w_sk = w_sk;
+  p.X = x; p.Y = y; p.res = res;
+  p.pro_scale = pro_scale; p.pro_shift = pro_shift;
+  p.HW = HW; p.tpi = HW / 64; p.ntiles = NB * p.tpi;
+  const int grid = grid_for(p.ntiles, waves_of(sid));
+  if (stat_part) {
+    const int rows = grid * waves_of(sid);
+    WFAE_REQUIRE(stat_capacity >= 2 * (int64_t)rows * M, WFAE_ERR_WORKSPACE, "c1r_fwd: stat_part holds %lld doubles, needs %lld",
+                 (long long)stat_capacity, (long long)(2 * (int64_t)rows * M));
+    *stat_rows = rows;
+    p.part0 = stat_part;
+    p.part1 = stat_part + (long)rows * M;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const bool pro = pro_scale != nullptr, stats = stat_part != nullptr;
+  switch (sid) {
+    case 0: launch_shape<4, 2, 2, 8>(p, pro, stats, grid, st); break;
+    case 1: launch_shape<8, 4, 4, 8>(p, pro, stats, grid, st); break;
+    case 2: launch_shape<1, 8, 1, 8>(p, pro, stats, grid, st); break;
+    default: launch_shape<2, 16, 1, 4>(p, pro, stats, grid, st); break;
+  }
+  return check_launch("c1r_fwd");
+}
+
+}  // extern "C"

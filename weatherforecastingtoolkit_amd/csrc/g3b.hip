@@ -646,8 +646,8 @@ int wfae_g3b_f32_supported(int C, int H, int W, int groups, int wgrad) {
   if (wfae::matmul_precision() != WFAE_PRECISION_FP32 || !wfae::split_gemm_enabled()) return 0;
   if (wgrad) return W <= 96 ? 1 : 0;
   // forward / data gradient: 16 channels per group @96 (three tiles per wave, two blocks per CU: 0.155 - 0.172 -> 0.119 - 0.129
-  // ms).  8 @192 is built and tested but measured SLOWER than the VALU kernel of dconv.hip (0.228 vs 0.218 ms: the split of
-  // every staged value, three times the transposed reads and 36 MFMAs per tile at two waves per SIMD) and is not routed;
+  // ms).  8 @192 measured SLOWER than the VALU kernel of dconv.hip (0.228 vs 0.218 ms: the split of every staged value,
+  // three times the transposed reads and 36 MFMAs per tile at two waves per SIMD) and was removed in round 4;
   // 4 @384 fits one block per CU only; at 32 per group the three-plane weight fragments of a wave exceed the register file
   const int cpg = C / groups;
   return cpg == 16 && W == 96 ? 1 : 0;
@@ -658,15 +658,13 @@ int wfae_g3b_fwd(const float* x, const float* w, float* y, int NB, int C, int H,
   WFAE_REQUIRE(x && w && y, WFAE_ERR_NULL_POINTER, "g3b_fwd: null pointer");
   WFAE_REQUIRE(NB > 0 && NB <= 65535 && C > 0 && H > 0 && W > 0 && groups > 0 && C % groups == 0, WFAE_ERR_BAD_SHAPE,
                "g3b_fwd: bad shape");
-  WFAE_REQUIRE(wfae_g3b_supported(C, H, W, groups) && ((C / groups == 8 && W == 192) || (C / groups == 16 && W == 96)) &&
-                   wfae::matmul_precision() == WFAE_PRECISION_FP32 && wfae::split_gemm_enabled(),
-               WFAE_ERR_UNSUPPORTED, "g3b_fwd: (channels per group, W) must be (8, 192) or (16, 96) at fp32 precision with the split "
-               "switch on (wfae_gconv3x3_fwd serves every shape)");
+  WFAE_REQUIRE(wfae_g3b_f32_supported(C, H, W, groups, 0), WFAE_ERR_UNSUPPORTED,
+               "g3b_fwd: (channels per group, W) must be (16, 96) at fp32 precision with the split switch on (wfae_gconv3x3_fwd "
+               "serves every shape)");
   WFAE_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0,
                WFAE_ERR_BAD_SHAPE, "g3b_fwd: tensors and workspace must be 16-byte aligned");
   const int cpg = C / groups, rh = g3b_strip(cpg, H, W);
   hipStream_t st = (hipStream_t)stream;
-  if (cpg == 8) return g3b_launch<8, 12, 192, 3, 3, float>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
   return g3b_launch<16, 6, 96, 3, 3, float>(x, w, y, NB, C, H, rh, transposed, ws, ws_bytes, st);
 }
 

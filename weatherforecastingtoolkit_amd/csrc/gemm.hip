@@ -91,23 +91,6 @@ struct GemmP {
   // written to HBM; the arithmetic is the one of bn_act_fwd_kernel (norm_act.hip), bit for bit.
   const float* b_scale;
   const float* b_shift;
-  // BatchNorm + GELU BACKWARD of the layer in front of a 1x1 convolution, fused into the vector epilogue of that
-  // convolution's data-gradient GEMM (E_BATCHED, B_NCONTIG, two wave columns): the result tile is dA = W^T dT, bn_x the
-  // BatchNorm input (same shape as C), bn_a / bn_b its folded scale / shift, bn_mu / bn_is the batch mean / invstd [M].
-  //   bn_mode 1: store dA and leave sum dU, sum dU * xhat (dU = dA gelu'(x a + b), xhat = (x - mu) is) per (row, 64-column
-  //              wave tile) in stat_sum / stat_sq — bn_act_bwd_reduce_kernel's arithmetic, its pass over (dA, x) disappears;
-  //   bn_mode 2: the same without storing dA (it is recomputed by a bn_mode 3 launch);
-  //   bn_mode 3: C = gamma is (dU - k1 - xhat k2) + res, k = bn_coef[2m..] * bn_inv_count — bn_act_bwd_dx_kernel's
-  //              arithmetic on a dA that never left the chip.
-  int bn_mode;
-  const float* bn_x;
-  const float* bn_a;
-  const float* bn_b;
-  const float* bn_mu;
-  const float* bn_is;
-  const float* bn_gamma;
-  const float* bn_coef;
-  float bn_inv_count;
   // 4x4 s2 geometry (gather kinds): lo side Hlo x Wlo, hi side 2Hlo x 2Wlo
   int Chi, Clo, Hlo, Wlo;
   // grouped 3x3 weight gradient (B_WGRAD3): blockIdx.y = group, Chi = total channels,
@@ -1066,10 +1049,6 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
     const bool nok = n < p.N;
     CT* cb = reinterpret_cast<CT*>(p.C);
     const CT* rbp = nullptr;
-    const float* xbp = nullptr;
-    (void)xbp;
-    // BatchNorm-backward epilogues (GemmP::bn_mode): 1x1 data-gradient launches only (fp32 storage)
-    constexpr bool BNE = EK == E_BATCHED && BKD == B_NCONTIG && PRO == 0 && WNW == 2 && std::is_same<CT, float>::value;
     long mstride;
     if constexpr (EK == E_BATCHED) {
       cb += (long)blockIdx.y * p.c_y;
@@ -1078,9 +1057,6 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
       const int pn = nn - img * p.c_hw;
       cb += (long)img * p.c_img + pn;
       if (p.res) rbp = reinterpret_cast<const CT*>(p.res) + (long)img * p.res_img + pn;
-      if constexpr (BNE) {
-        if (p.bn_mode) xbp = p.bn_x + (long)img * p.c_img + pn;
-      }
       mstride = p.c_ld;
     } else {
       cb += ((long)z * gridDim.y + blockIdx.y) * p.M * p.N + n;
@@ -1103,44 +1079,6 @@ __global__ __launch_bounds__(NT, (BM >= 256 ? 2 : ((BKD == B_DOWN || BKD == B_UP
         const int row = it * RPI + rsub;
         float4 v = *reinterpret_cast<const float4*>(&sw[row * COLS + c4 * 4]);
         const int m = m0 + wm0 + g * SROWS + row;
-        if constexpr (BNE) {
-          if (p.bn_mode) {   // wave-uniform
-            const bool okm = nok && m < p.M;
-            const int mc = m < p.M ? m : p.M - 1;
-            const float4 xv = *reinterpret_cast<const float4*>(xbp + (long)mc * mstride);
-            const float a = p.bn_a[mc], b = p.bn_b[mc], mu = p.bn_mu[mc], is = p.bn_is[mc];
-            const float d0 = v.x * gelu_grad_f(fmaf(xv.x, a, b)), d1 = v.y * gelu_grad_f(fmaf(xv.y, a, b));
-            const float d2 = v.z * gelu_grad_f(fmaf(xv.z, a, b)), d3 = v.w * gelu_grad_f(fmaf(xv.w, a, b));
-            const float h0 = (xv.x - mu) * is, h1 = (xv.y - mu) * is, h2 = (xv.z - mu) * is, h3 = (xv.w - mu) * is;
-            float* dst = cb + (long)mc * mstride;
-            if (p.bn_mode == 3) {   // bn_act_bwd_dx_kernel's one()
-              const float gi = p.bn_gamma[mc] * is;
-              const float k1 = p.bn_coef[2 * mc] * p.bn_inv_count, k2 = p.bn_coef[2 * mc + 1] * p.bn_inv_count;
-              float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (rbp) rv = *reinterpret_cast<const float4*>(rbp + (long)mc * mstride);
-              typedef float vf4 __attribute__((ext_vector_type(4)));
-              const vf4 o = {gi * (d0 - k1 - h0 * k2) + rv.x, gi * (d1 - k1 - h1 * k2) + rv.y,
-                             gi * (d2 - k1 - h2 * k2) + rv.z, gi * (d3 - k1 - h3 * k2) + rv.w};
-              if (okm) __builtin_nontemporal_store(o, reinterpret_cast<vf4*>(dst));
-            } else {                // bn_act_bwd_reduce_kernel's quad()
-              if (p.bn_mode == 1 && okm) *reinterpret_cast<float4*>(dst) = v;
-              double s1 = 0.0, s2 = 0.0;
-              if (okm) {
-                s1 = (double)((d0 + d1) + (d2 + d3));
-                s2 = (double)(fmaf(d0, h0, d1 * h1) + fmaf(d2, h2, d3 * h3));
-              }
-              static_assert(F4R == 16, "one DPP row per output row");
-              s1 = dpp_row_sum(s1);
-              s2 = dpp_row_sum(s2);
-              if (c4 == F4R - 1 && m < p.M) {
-                const long prow = (long)(n0 / BN) * 2 + (wave % WNW);
-                p.stat_sum[prow * p.M + m] = s1;
-                p.stat_sq[prow * p.M + m] = s2;
-              }
-            }
-            continue;
-          }
-        }
         if (nok && m < p.M) {
           CT* dst = cb + (long)m * mstride;
           if constexpr (EK == E_BATCHED) {
@@ -1401,7 +1339,6 @@ int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what,
         constexpr int split_min_k = 128, split_min_m = 64;   // (K >= 32..128, M >= 32..64 all within 1 % in round 2)
         if (wfae::split_gemm_enabled() && p.K >= split_min_k && p.M >= split_min_m) {
           int bm = pick_bm(p.M, (long)ntiles * ydim * zdim);
-          if (p.bn_mode && bm == 32) bm = 64;
           if (bm == 128) {
             dim3 grid(cdiv(p.M, 128) * ntiles, ydim, zdim);
             hipLaunchKernelGGL((gemm_kernel<128, 2, 2, AK, BKD, EK, true, 32, 2, PRO>), grid, block, 0, st, p);
@@ -1422,7 +1359,6 @@ int launch_gemm_v(const GemmP& p_in, int zdim, hipStream_t st, const char* what,
       }
     }
     int bm = big ? 256 : pick_bm(p.M, (long)ntiles * ydim * zdim);
-    if (p.bn_mode && bm == 32) bm = 64;   // the BatchNorm-backward epilogues live in the two-wave-column kernels
     if (big) {
     } else if (bm == 128) {
       dim3 grid(cdiv(p.M, 128) * ntiles, ydim, zdim);
@@ -1673,58 +1609,6 @@ int wfae_conv1x1_bwd_data(const float* dy, const float* w, float* dx, int NB, in
 int wfae_conv1x1_bwd_data_bf16(const uint16_t* dy, const float* w, uint16_t* dx, int NB, int Cin, int Cout, int HW,
                                wfae_stream_t stream) {
   return conv1x1_bwd_data_impl(dy, w, dx, NB, Cin, Cout, HW, stream);
-}
-
-// wfae_conv1x1_bwd_data with the BatchNorm + GELU backward of the layer in front fused into its epilogue (GemmP::bn_mode)
-static int conv1x1_bwd_data_bn(int mode, const float* dy, const float* w, const float* x, const float* gamma, const float* scale,
-                               const float* shift, const float* mean, const float* invstd, const float* coef, const float* res,
-                               float* dx, int NB, int Cin, int Cout, int HW, int training, double* part, int64_t part_capacity,
-                               int* part_rows, wfae_stream_t stream, const char* what) {
-  WFAE_REQUIRE(dy && w && x && scale && shift && mean && invstd, WFAE_ERR_NULL_POINTER, "%s: null pointer", what);
-  WFAE_REQUIRE(NB > 0 && Cin > 0 && Cout > 0 && HW > 0, WFAE_ERR_BAD_SHAPE, "%s: bad shape", what);
-  WFAE_REQUIRE((int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "%s: NB*HW too large", what);
-  WFAE_REQUIRE(Cin % 4 == 0 && HW % 4 == 0 && aligned16(w) && aligned16(dy) && aligned16(x) && (!dx || aligned16(dx)) &&
-                   (!res || aligned16(res)),
-               WFAE_ERR_UNSUPPORTED, "%s: needs Cin %% 4 == 0, HW %% 4 == 0 and 16-byte aligned tensors (Cin %d, HW %d)", what,
-               Cin, HW);
-  GemmP p = {};
-  p.A = w; p.B = dy; p.C = dx;
-  p.M = Cin; p.N = NB * HW; p.K = Cout; p.k_per_split = cdiv(Cout, BK) * BK;
-  p.a_ld = Cin;  // A(m=ci,k=co) = w[co*Cin + ci]
-  p.b_hw = HW; p.b_img = (long)Cout * HW; p.b_ld = HW;
-  p.c_hw = HW; p.c_img = (long)Cin * HW; p.c_ld = HW; p.res_img = (long)Cin * HW;
-  p.a_vec = p.b_vec = p.c_vec = 1;
-  p.bn_mode = mode;
-  p.bn_x = x; p.bn_a = scale; p.bn_b = shift; p.bn_mu = mean; p.bn_is = invstd;
-  if (mode == 3) {
-    p.bn_gamma = gamma; p.bn_coef = coef; p.res = res;
-    p.bn_inv_count = training ? (float)(1.0 / ((double)NB * HW)) : 0.f;
-  } else {
-    const int64_t rows = 2 * (int64_t)cdiv(p.N, BN);
-    WFAE_REQUIRE(part_capacity >= 2 * rows * Cin, WFAE_ERR_WORKSPACE, "%s: part holds %lld doubles, needs %lld", what,
-                 (long long)part_capacity, (long long)(2 * rows * Cin));
-    *part_rows = (int)rows;
-    p.stat_sum = part;
-    p.stat_sq = part + rows * Cin;
-  }
-  return launch_gemm_v<A_MCONTIG, B_NCONTIG, E_BATCHED, true>(p, 1, (hipStream_t)stream, what);
-}
-
-int wfae_conv1x1_bwd_data_bnred(const float* dy, const float* w, const float* x, const float* bn_scale, const float* bn_shift,
-                                const float* save_mean, const float* save_invstd, float* dx, int NB, int Cin, int Cout, int HW,
-                                double* part, int64_t part_capacity, int* part_rows, wfae_stream_t stream) {
-  WFAE_REQUIRE(part && part_rows, WFAE_ERR_NULL_POINTER, "conv1x1_bwd_data_bnred: null pointer");
-  return conv1x1_bwd_data_bn(dx ? 1 : 2, dy, w, x, nullptr, bn_scale, bn_shift, save_mean, save_invstd, nullptr, nullptr, dx, NB,
-                             Cin, Cout, HW, 1, part, part_capacity, part_rows, stream, "conv1x1_bwd_data_bnred");
-}
-
-int wfae_conv1x1_bwd_data_bndx(const float* dy, const float* w, const float* x, const float* gamma, const float* bn_scale,
-                               const float* bn_shift, const float* save_mean, const float* save_invstd, const float* coef,
-                               const float* res, float* dx, int NB, int Cin, int Cout, int HW, int training,
-                               wfae_stream_t stream) {
-  WFAE_REQUIRE(gamma && coef && dx, WFAE_ERR_NULL_POINTER, "conv1x1_bwd_data_bndx: null pointer");
-  return conv1x1_bwd_data_bn(3, dy, w, x, gamma, bn_scale, bn_shift, save_mean, save_invstd, coef, res, dx, NB, Cin, Cout, HW,
-                             training, nullptr, 0, nullptr, stream, "conv1x1_bwd_data_bndx");
 }
 
 int wfae_conv1x1_bwd_weight(const float* dy, const float* x, float* dw, int NB, int Cin, int Cout,

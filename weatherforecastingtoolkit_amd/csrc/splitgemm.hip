@@ -451,6 +451,9 @@ int split_gemm(int kind, int planes, const unsigned short* A, const unsigned sho
   WFAE_REQUIRE(planes == 1 || planes == 3, WFAE_ERR_BAD_SHAPE, "%s: planes must be 3 (exact fp32 split) or 1 (bf16 operands)", what);
   WFAE_REQUIRE(K % SBK == 0 && k_per_split % SBK == 0 && (kind == 1 || N % 8 == 0) && M > 0 && N >= 8, WFAE_ERR_UNSUPPORTED,
                "%s: the split GEMM needs K %% 32 == 0 and 16-byte operand rows", what);
+  // the loaders address one plane of one batch with 32-bit BYTE offsets (2 * element index, one VGPR per operand stream)
+  WFAE_REQUIRE((long)M * K < (1l << 31) - (1l << 16) && (long)K * N < (1l << 31) - (1l << 16), WFAE_ERR_BAD_SHAPE,
+               "%s: one operand plane of one batch must stay below 2^31 elements (M %d, N %d, K %d)", what, M, N, K);
   SgP p = {};
   p.A = A; p.B = B; p.C = C;
   p.a_plane = a_plane; p.b_plane = b_plane;

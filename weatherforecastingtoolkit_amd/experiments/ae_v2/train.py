@@ -243,8 +243,9 @@ def main(argv=None):
                     help="stop (and checkpoint) after this many optimiser steps WITHOUT changing the schedule — an "
                          "interrupted run that `--resume True` continues")
     ap.add_argument("--matmul-precision", default="high", choices=["highest", "high", "medium"],
-                    help="reference: torch.set_float32_matmul_precision('high') (train.py main); 'medium' = bf16 "
-                         "MFMA operands (BASELINE config 5)")
+                    help="reference: torch.set_float32_matmul_precision('high') (train.py main).  'medium' = BASELINE "
+                         "config 5's regime and MORE than torch's meaning of the word: bf16 MFMA operands AND bf16 activation "
+                         "storage in HBM (the counterpart of bf16 autocast); WFAE_BF16_STORAGE=0 keeps the tensors fp32")
     ap.add_argument("--data-dir", default=None, help="SEVIR root (CATALOG.csv + data/); default: synthetic events")
     ap.add_argument("--data-format", choices=("npy", "h5"), default="npy")
     ap.add_argument("--model", choices=("tf", "lin"), default="tf",

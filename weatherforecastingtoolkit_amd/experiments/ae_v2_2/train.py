@@ -94,6 +94,7 @@ class Model(tnn.Module):
         self.accumulate_grad_batches = cfg.trainer.accumulate_grad_batches
         self.global_step = 0
         self._dp = None
+        self.overlap_exchange = True    # generator all-reduce under the discriminator's forward / backward (training_step)
         self.on_after_backward = None   # optional callable(tag) run after each backward ("g" / "d"), like Lightning's hook
 
     def forward(self, x):
@@ -131,14 +132,20 @@ class Model(tnn.Module):
             aeloss.backward()
         if self.on_after_backward is not None:
             self.on_after_backward("g")
+        disc_on = self.global_step >= self.cfg.lpips.disc_start
+        # BASELINE config 5 "overlap D/G backward with all-reduce": the generator's gradient exchange is STARTED here and
+        # finished after the discriminator's forward / backward has been queued.  Legal because the discriminator's loss
+        # reads the detached reconstruction and its own parameters only (reference :147-150), so the generator's clip + step
+        # may wait; the arithmetic and its order per tensor are unchanged — bit-identical to the serial order
+        # (tests/test_gan_gpu.py).  `overlap_exchange = False` restores the reference's literal order.
+        overlap = step_now and disc_on and self.overlap_exchange
         if step_now:
-            self._dp[0].reduce_gradients()
-            logs["train/g_grad_norm"] = self.g_opt.clip_grad_norm_(clip)
-            self.g_opt.step()
-            self.g_sch.step()
-            self.g_opt.zero_grad(set_to_none=True)
+            if overlap:
+                self._dp[0].start_reduce()
+            else:
+                self._g_step(logs, clip)
         # ---- discriminator
-        if self.global_step >= self.cfg.lpips.disc_start:
+        if disc_on:
             discloss, log_d = self.loss(inp, pred, 1, self.get_last_layer(), "train", self.global_step)
             logs.update(log_d)
             if self.accumulate_grad_batches != 1:
@@ -146,6 +153,8 @@ class Model(tnn.Module):
             discloss.backward()
             if self.on_after_backward is not None:
                 self.on_after_backward("d")
+            if overlap:
+                self._g_step(logs, clip, started=True)
             if step_now:
                 self._dp[1].reduce_gradients()
                 logs["train/d_grad_norm"] = self.d_opt.clip_grad_norm_(clip)
@@ -159,6 +168,17 @@ class Model(tnn.Module):
             self.global_step += 1
         return pred, logs
 
+
+    def _g_step(self, logs, clip, started=False):
+        """generator: finish (or run) the gradient exchange, clip, step, schedule (reference :136-141)"""
+        if started:
+            self._dp[0].finish_reduce()
+        else:
+            self._dp[0].reduce_gradients()
+        logs["train/g_grad_norm"] = self.g_opt.clip_grad_norm_(clip)
+        self.g_opt.step()
+        self.g_sch.step()
+        self.g_opt.zero_grad(set_to_none=True)
 
     @torch.no_grad()
     def validation_step(self, batch, batch_idx=0, split="val"):
@@ -183,8 +203,9 @@ def main(argv=None):
     ap.add_argument("--stop-after", type=int, default=-1,
                     help="stop (and checkpoint) after this many steps WITHOUT changing the schedule; `--resume True` continues")
     ap.add_argument("--matmul-precision", default="high", choices=["highest", "high", "medium"],
-                    help="reference: torch.set_float32_matmul_precision('high') (train.py main); 'medium' = bf16 "
-                         "MFMA operands (BASELINE config 5)")
+                    help="reference: torch.set_float32_matmul_precision('high') (train.py main).  'medium' = BASELINE "
+                         "config 5's regime and MORE than torch's meaning of the word: bf16 MFMA operands AND bf16 activation "
+                         "storage in HBM (the counterpart of bf16 autocast); WFAE_BF16_STORAGE=0 keeps the tensors fp32")
     args, unknown = ap.parse_known_args(argv)
     cfg = C.load(args.config, CARRIED_KEYS)
     cli = C.from_dotlist(unknown)

@@ -73,20 +73,6 @@ FUSE_A3_MAXC = 128
 PRODUCER_STATS = os.environ.get("WFAE_PRODUCER_STATS", "1") == "1"
 
 
-# Bottleneck 1x1 convolutions on csrc/c1gemm.hip where it measured faster (ops.c1gemm_preferred: reductions K >= 512).
-# C1_BNRED: the reductions of the BatchNorm + GELU backward in front of a 1x1 convolution (sum dU, sum dU * xhat) taken in the
-# epilogue of the data-gradient GEMM that produces dA instead of by a pass over (dA, x); C1_RECOMPUTE_MAXC: for Bottlenecks
-# of at most this many channels the C-wide dA of the first BatchNorm is never written (one GEMM reduces, a second
-# recomputes it inside the dx epilogue).  Both are built, parity-tested (tests/test_c1gemm_gpu.py) and OFF: measured at the
-# step's shapes (tools/kbench.py --only c1, profiles/r03_kbench_c1_fused_bn_backward.txt) the fused sequences move 14-38 %
-# fewer bytes and take the same time or longer (C = 256 @192: 1.55 ms fused / 1.61 recompute vs 1.55 separate passes;
-# C = 128 @384: 2.91 / 2.82 vs 2.90) — gelu' costs ~25 vector instructions per element (0.39 ms per C-wide tensor of the
-# 384 x 384 stage at 100 % VALU utilisation), which a streaming pass hides under its HBM time with 8 waves per SIMD and a
-# GEMM epilogue does not.
-C1_BNRED = os.environ.get("WFAE_C1_BNRED", "0") == "1"
-C1_RECOMPUTE_MAXC = int(os.environ.get("WFAE_C1_RECOMPUTE_MAXC", "0"))
-
-
 def set_wgrad_overlap(flag: bool):
     global _overlap
     _overlap = bool(flag)
@@ -214,10 +200,11 @@ def _c(t):
 
 
 # ----------------------------------------------------------- 4x4 s2 units --
-def _down_fwd(x, w):
+def _down_fwd(x, w, unit=False):
     if w.shape[1] < 16:
-        # the one-channel first layer reads the fp32 frame and writes the stack's activation storage type
-        out = ops.activation_dtype() if (x.dtype == torch.float32 and w.shape[1] == 1) else torch.float32
+        # the one-channel first layer of the MODEL's stack (unit=True: DownUnitFn) reads the fp32 frame and writes the stack's
+        # activation storage type; the generic Conv2d(.., 4, 2, 1) layer (Conv4x4DownFn) keeps the dtype of its input
+        out = ops.activation_dtype() if (unit and x.dtype == torch.float32 and w.shape[1] == 1) else torch.float32
         return ops.dconv_fwd(x, w, None, 4, 2, 1, 1, out_dtype=out)
     return ops.conv4x4s2_down(x, w)
 
@@ -243,7 +230,7 @@ def _down_forward(x, w, stats=False):
     """-> (t, pl, U, V[, StatParts of t]): 4x4 s2 convolution of x; U, V are None on the direct path"""
     pl = _down_plan(x, w)
     if pl is None:
-        return (_down_fwd(x, w), None, None, None) + ((None,) if stats else ())
+        return (_down_fwd(x, w, unit=True), None, None, None) + ((None,) if stats else ())
     U, V = ops.wino_weights(w, pl), ops.wino_in(x, pl)
     if stats:
         t, sp = ops.wino_down(U, V, pl, stats=True, out_dtype=x.dtype)
@@ -564,29 +551,15 @@ def _mk_stats(mean, invstd, scale, shift):
     return st
 
 
-def _dgrad_bn(dt, w, Wt3, x, gamma, st, dgamma, dbeta, res, training, recompute):
+def _dgrad_bn(dt, w, Wt, x, gamma, st, dgamma, dbeta, res, training):
     """dx of  conv1x1(gelu(bn(x)), w)  given dt = dL/d(conv output): the data gradient dA = W^T dT followed by the
-    BatchNorm + GELU backward at x (+ res, the residual-branch gradient).  C1_BNRED: the per-channel reductions ride in the
-    GEMM epilogue; `recompute`: dA is never written — one GEMM reduces, a second recomputes it inside the dx epilogue.
-    Wt3: bf16 planes of w^T when this product runs on c1gemm (else an empty tensor: gemm.hip's kernel)."""
-    c = x.shape[1]
-    if Wt3 is not None and Wt3.numel() > 0 and Wt3.dtype == ops.BF16:      # bf16 storage: the data gradient on csrc/c1b.hip
-        da = ops.c1b_fwd(Wt3, dt, label="wfae_c1b_dgrad")
-        return ops.bn_act_bwd(da, x, gamma, st, dgamma, dbeta, res, 1, training)
-    on_c1 = Wt3 is not None and Wt3.numel() > 0
-    if not (C1_BNRED and (on_c1 or ops.conv1x1_bn_fusable(c, x.shape[2] * x.shape[3]))):
-        da = ops.c1gemm_fwd(Wt3, dt, label="wfae_c1gemm_dgrad") if on_c1 else ops.conv1x1_bwd_data(dt, w)
-        return ops.bn_act_bwd(da, x, gamma, st, dgamma, dbeta, res, 1, training)
-    if on_c1:
-        da, sr = ops.c1gemm_bnred(Wt3, dt, x, st, store=not recompute)
+    BatchNorm + GELU backward at x (+ res, the residual-branch gradient).  Wt: the bf16 plane of w^T when the tensors
+    are bf16-stored (csrc/c1b.hip), else an empty tensor (fp32 storage: wfae_conv1x1_bwd_data)."""
+    if Wt is not None and Wt.numel() > 0 and Wt.dtype == ops.BF16:
+        da = ops.c1b_fwd(Wt, dt, label="wfae_c1b_dgrad")
     else:
-        da, sr = ops.conv1x1_bwd_data_bnred(dt, w, x, st, store=not recompute)
-    ops.bn_act_bwd_from_rows(sr, c, dgamma, dbeta)
-    if not recompute:
-        return ops.bn_act_bwd_dx(da, x, gamma, st, res, 1, training)
-    if on_c1:
-        return ops.c1gemm_bndx(Wt3, dt, x, gamma, st, res, training)
-    return ops.conv1x1_bwd_data_bndx(dt, w, x, gamma, st, res, training)
+        da = ops.conv1x1_bwd_data(dt, w)
+    return ops.bn_act_bwd(da, x, gamma, st, dgamma, dbeta, res, 1, training)
 
 
 class BottleneckFn(Function):
@@ -608,12 +581,10 @@ class BottleneckFn(Function):
         fuse = training and STAT_FUSION
         emit = fuse and getattr(mod, "emit_stats", False)
         C, mid, hw = x.shape[1], w1.shape[0], x.shape[2] * x.shape[3]
-        # csrc/c1gemm.hip serves (M = mid, K = C): the C -> C/4 forward and the C/4 -> C data gradient; (M = C, K = mid): the
-        # C/4 -> C forward and the C -> C/4 data gradient.  The weight planes are written once here and reused in backward.
-        use1, use3 = ops.c1gemm_preferred(mid, C, hw), ops.c1gemm_preferred(C, mid, hw)
-        W1p = ops.c1_split_weights(w1) if (use1 or use3) else (None, None)
-        W3p = ops.c1_split_weights(w3) if (use1 or use3) else (None, None)
-        # bf16 storage: csrc/c1b.hip for the same four products (one bf16 weight plane each way)
+        # bf16 storage: csrc/c1b.hip serves the four 1x1 products — (M = mid, K = C): the C -> C/4 forward and the C/4 -> C data
+        # gradient; (M = C, K = mid): the C/4 -> C forward and the C -> C/4 data gradient — with one bf16 weight plane each way,
+        # written once here and reused in backward
+        W1p = W3p = (None, None)
         cb1 = x.dtype == ops.BF16 and ops.c1b_supported(mid, C, hw)
         cb3 = x.dtype == ops.BF16 and ops.c1b_supported(C, mid, hw)
         if cb1 or cb3:
@@ -624,9 +595,6 @@ class BottleneckFn(Function):
         if cb1:
             src, pro = (x, st1) if fused1 else (a1, None)
             t1, sr2 = ops.c1b_fwd(W1p[0], src, pro, None, True) if fuse else (ops.c1b_fwd(W1p[0], src, pro), None)
-        elif use1:
-            src, pro = (x, st1) if fused1 else (a1, None)
-            t1, sr2 = ops.c1gemm_fwd(W1p[0], src, pro, None, True) if fuse else (ops.c1gemm_fwd(W1p[0], src, pro), None)
         elif fused1:
             t1, sr2 = ops.conv1x1_fwd_bnact(x, st1, w1, stats=True) if fuse else (ops.conv1x1_fwd_bnact(x, st1, w1), None)
         else:
@@ -646,15 +614,13 @@ class BottleneckFn(Function):
             a3 = ops.bn_act_fwd(t2, st3, 1)
             if cb3:
                 y, mod._out_stats = ops.c1b_fwd(W3p[0], a3, None, x, True) if emit else (ops.c1b_fwd(W3p[0], a3, None, x), None)
-            elif use3:
-                y, mod._out_stats = ops.c1gemm_fwd(W3p[0], a3, None, x, True) if emit else (ops.c1gemm_fwd(W3p[0], a3, None, x), None)
             else:
                 y, mod._out_stats = ops.conv1x1_fwd_stats(a3, w3, None, x) if emit else (ops.conv1x1_fwd(a3, w3, None, x), None)
         ctx.save_for_backward(x, _opt(a1), t1, a2, t2, _opt(a3), g1, w1, g2, wg, g3, w3,
                               st1.mean, st1.invstd, st1.scale, st1.shift,
                               st2.mean, st2.invstd, st2.scale, st2.shift,
                               st3.mean, st3.invstd, st3.scale, st3.shift,
-                              _opt(W1p[1] if (use3 or cb3) else None), _opt(W3p[1] if (use1 or cb1) else None))
+                              _opt(W1p[1] if cb3 else None), _opt(W3p[1] if cb1 else None))
         ctx.training = training
         ctx.groups = groups
         ctx.betas = (b1, b2, b3)
@@ -664,7 +630,7 @@ class BottleneckFn(Function):
     def backward(ctx, dy):
         (x, a1, t1, a2, t2, a3, g1, w1, g2, wg, g3, w3, *s) = ctx.saved_tensors
         st1, st2, st3 = _mk_stats(*s[0:4]), _mk_stats(*s[4:8]), _mk_stats(*s[8:12])
-        W1t, W3t = s[12], s[13]     # bf16 planes of w1^T (M = C, K = mid) and w3^T (M = mid, K = C); empty: not on c1gemm
+        W1t, W3t = s[12], s[13]     # bf16 planes of w1^T (M = C, K = mid) and w3^T (M = mid, K = C); empty: fp32 storage
         tr = ctx.training
         dy = _c(dy)
         mid = w1.shape[0]
@@ -674,7 +640,7 @@ class BottleneckFn(Function):
         else:
             _wgrad(lambda: ops.conv1x1_bwd_weight(dy, a3, dw3), dy, a3)
         dg3, db3 = grad_buffer(g3), grad_buffer(ctx.betas[2])
-        dt2 = _dgrad_bn(dy, w3, W3t, t2, g3, st3, dg3, db3, None, tr, False)
+        dt2 = _dgrad_bn(dy, w3, W3t, t2, g3, st3, dg3, db3, None, tr)
         dwg = grad_buffer(wg)
         _wgrad(lambda: _g3_wgrad(dt2, a2, dwg, ctx.groups), dt2, a2)
         da2 = _g3_dgrad(dt2, wg, mid, ctx.groups)
@@ -688,7 +654,7 @@ class BottleneckFn(Function):
         else:
             _wgrad(lambda: ops.conv1x1_bwd_weight(dt1, a1, dw1), dt1, a1)
         dg1, db1 = grad_buffer(g1), grad_buffer(ctx.betas[0])
-        dx = _dgrad_bn(dt1, w1, W1t, x, g1, st1, dg1, db1, dy, tr, x.shape[1] <= C1_RECOMPUTE_MAXC)
+        dx = _dgrad_bn(dt1, w1, W1t, x, g1, st1, dg1, db1, dy, tr)
         return dx, dg1, db1, dw1, dg2, db2, dwg, dg3, db3, dw3, None, None
 
 

@@ -91,8 +91,6 @@ _PEAK_OF = {
     "wfae_conv1x1_fwd_bf16": lambda a: PEAK_BF16_MFMA,
     "wfae_conv1x1_bwd_data": lambda a: _gemm_peak(a[4], a[5]),            # M = Cin, K = Cout
     "wfae_conv1x1_bwd_data_bf16": lambda a: PEAK_BF16_MFMA,
-    "wfae_conv1x1_bwd_data_bnred": lambda a: _gemm_peak(a[9], a[10]),
-    "wfae_conv1x1_bwd_data_bndx": lambda a: _gemm_peak(a[12], a[13]),
     # weight gradients: M = Cout, or Cin when the roles are swapped (Cin < Cout and Cin < 128); K = the pixels
     "wfae_conv1x1_bwd_weight": lambda a: _gemm_peak(a[4] if (a[4] < a[5] and a[4] < 128) else a[5], 1 << 20),
     "wfae_conv1x1_bwd_weight_bnact": lambda a: _gemm_peak(a[6] if (a[6] < a[7] and a[6] < 128) else a[7], 1 << 20),
@@ -109,9 +107,6 @@ _PEAK_OF = {
     "wfae_wino_gemm_up": lambda a: _default_peak(),
     "wfae_wino_gemm_wgrad": lambda a: _default_peak(),
     "wfae_split_gemm": lambda a: _planes_peak(a[1]),
-    "wfae_c1gemm_fwd": lambda a: PEAK_BF16_MFMA / 6,
-    "wfae_c1gemm_bnred": lambda a: PEAK_BF16_MFMA / 6,
-    "wfae_c1gemm_bndx": lambda a: PEAK_BF16_MFMA / 6,
     "wfae_conv4x4s2_down": lambda a: _default_peak(),
     "wfae_conv4x4s2_up": lambda a: _default_peak(),
     "wfae_conv4x4s2_wgrad": lambda a: _default_peak(),
@@ -213,6 +208,54 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+# ----------------------------------------------- 1x1 conv, register-direct (c1r)
+# csrc/c1r.hip: the Bottleneck's four 1x1 products on fp32 tensors at the C <= 256 stages (activation HBM -> registers ->
+# bf16 matrix core with exact three-plane operands, no LDS staging).  The wfae_conv1x1_* wrappers below route to it.
+_C1R = True   # A/B through set_c1r()
+
+
+def set_c1r(on):
+    """A/B switch: the fp32 1x1 forward / data gradient of the C <= 256 stages on csrc/c1r.hip or on gemm.hip"""
+    global _C1R
+    _C1R = bool(on)
+
+
+def c1r_supported(m, k, hw):
+    return (_C1R and _SPLIT_GEMM and _lib.load().wfae_get_matmul_precision() == 0
+            and bool(_lib.load().wfae_c1r_supported(int(m), int(k), int(hw))))
+
+
+def _c1r_take(m, k, hw, fused):
+    """route this product to c1r?  Measured per shape (profiles/r04_kbench_c1r_knobs.txt): at C = 256 gemm.hip's kernels are
+    bound by the fp32 MFMA instruction and c1r wins all four products (0.346 -> 0.312, 0.445 -> 0.320, 0.685 -> 0.504,
+    0.500 -> 0.404 ms); at C = 128 both are HBM-bound: c1r wins the launches that carry a BatchNorm + GELU prologue or a residual
+    + BatchNorm-sum epilogue (0.720 -> 0.645, 1.135 -> 1.068 ms), gemm.hip's LDS-tiled kernel the two plain data gradients
+    (0.544 / 0.557 vs 0.580 / 0.604 ms: 512-byte row segments per load against 256)."""
+    return c1r_supported(m, k, hw) and (fused or m * k == 64 * 256)
+
+
+def _c1r(w, transposed, x, st, res, stats, label):
+    """y = A f(x) (+ res): A = w (Cout, Cin) or, transposed, w^T (the data gradient); -> y | (y, StatRows)"""
+    import ctypes
+    nb, k, h, wd = x.shape
+    cout, cin = w.shape[0], w.shape[1]
+    m, sm, sk = (cin, 1, cin) if transposed else (cout, cin, 1)
+    y = torch.empty((nb, m, h, wd), dtype=torch.float32, device=x.device)
+    fl = 2 * nb * h * wd * k * m
+    by = 4 * (nb * h * wd * (k + m) + k * m) + (0 if res is None else 4 * nb * h * wd * m)
+    ps, ph = (None, None) if st is None else (_p(st.scale), _p(st.shift))
+    if not stats:
+        _call("wfae_c1r_fwd", fl, by, _p(w), sm, sk, _p(x), ps, ph, _p(res), _p(y), nb, k, m, h * wd, None, 0, None, _stream(),
+              label=label, peak=PEAK_BF16_MFMA / 6)
+        return y
+    rows_n = int(_lib.load().wfae_c1r_stat_rows(m, k, nb, h * wd))
+    part = torch.empty(2 * rows_n * m, dtype=torch.float64, device=x.device)
+    rows = ctypes.c_int(0)
+    _call("wfae_c1r_fwd", fl, by, _p(w), sm, sk, _p(x), ps, ph, _p(res), _p(y), nb, k, m, h * wd, part.data_ptr(), part.numel(),
+          ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream(), label=label, peak=PEAK_BF16_MFMA / 6)
+    return y, StatRows(part, rows.value)
+
+
 # ----------------------------------------------------------------- 1x1 conv
 def _conv1x1_fwd_bf16(x, st, w, bias, res, stats):
     """the merged bf16-storage entry point: optional BatchNorm + GELU prologue (st), optional BatchNorm sums (stats)"""
@@ -245,6 +288,8 @@ def conv1x1_fwd(x, w, bias=None, res=None, res_broadcast=False):
     _chk(x, w, bias, res)
     nb, cin, h, wd = x.shape
     cout = w.shape[0]
+    if bias is None and not res_broadcast and (res is None or cout > cin) and _c1r_take(cout, cin, h * wd, res is not None):
+        return _c1r(w, False, x, None, res, False, "wfae_conv1x1_fwd")
     y = torch.empty((nb, cout, h, wd), dtype=x.dtype, device=x.device)
     stride = 0 if res_broadcast else cout * h * wd
     _call("wfae_conv1x1_fwd", 2 * nb * h * wd * cin * cout, 4 * (nb * h * wd * (cin + cout) + cin * cout) + (0 if res is None else 4 * nb * h * wd * cout), _p(x), _p(w), _p(bias), _p(res), stride, _p(y), nb, cin, cout, h * wd, _stream())
@@ -281,6 +326,8 @@ def conv1x1_fwd_stats(x, w, bias=None, res=None):
     _chk(x, w, bias, res)
     nb, cin, h, wd = x.shape
     cout = w.shape[0]
+    if bias is None and (res is None or cout > cin) and _c1r_take(cout, cin, h * wd, True):
+        return _c1r(w, False, x, None, res, True, "wfae_conv1x1_fwd")
     y = torch.empty((nb, cout, h, wd), dtype=x.dtype, device=x.device)
     part, cap = _stat_rows_buffer(nb, h * wd, cout, x.device)
     rows = ctypes.c_int(0)
@@ -308,6 +355,8 @@ def conv1x1_fwd_bnact(x, st, w, bias=None, res=None, stats=False):
     _chk(x, w, bias, res)
     nb, cin, h, wd = x.shape
     cout = w.shape[0]
+    if bias is None and (res is None or cout > cin) and _c1r_take(cout, cin, h * wd, True):
+        return _c1r(w, False, x, st, res, stats, "wfae_conv1x1_fwd_bnact")
     y = torch.empty((nb, cout, h, wd), dtype=x.dtype, device=x.device)
     fl = 2 * nb * h * wd * cin * cout
     by = 4 * (nb * h * wd * (cin + cout) + cin * cout) + (0 if res is None else 4 * nb * h * wd * cout)
@@ -376,6 +425,8 @@ def conv1x1_bwd_data(dy, w):
     _chk(w)
     nb, cout, h, wd = dy.shape
     cin = w.shape[1]
+    if not sfx and _c1r_take(cin, cout, h * wd, False):
+        return _c1r(w, True, dy, None, None, False, "wfae_conv1x1_bwd_data")
     dx = torch.empty((nb, cin, h, wd), dtype=dy.dtype, device=dy.device)
     _call("wfae_conv1x1_bwd_data" + sfx, 2 * nb * h * wd * cin * cout, es * nb * h * wd * (cin + cout) + 4 * cin * cout, _p(dy), _p(w),
           _p(dx), nb, cin, cout, h * wd, _stream(), label="wfae_conv1x1_bwd_data")
@@ -398,24 +449,6 @@ def conv1x1_bwd_weight(dy, x, dw, accumulate=False):
     _call("wfae_conv1x1_bwd_weight", 2 * nb * h * wd * cin * cout, 4 * (nb * h * wd * (cin + cout) + cin * cout), _p(dy), _p(x), _p(dw), nb, cin, cout, h * wd, int(accumulate),
               ws.data_ptr(), ws.numel(), _stream())
     return dw
-
-
-# ------------------------------------------- 1x1 conv on the bf16 pipe (c1gemm)
-# csrc/c1gemm.hip: the Bottleneck's 1x1 convolutions with the weight as three exact bf16 planes and the activation split
-# once per loaded value on its way into LDS; epilogues: residual, BatchNorm sums, BatchNorm-backward reduce / dx.
-_C1GEMM = True   # A/B through set_c1gemm()
-
-
-def set_c1gemm(on):
-    global _C1GEMM
-    _C1GEMM = bool(on)
-
-
-def c1gemm_supported(m, k, hw):
-    """True when csrc/c1gemm.hip serves y (m channels) = W (m x k) x at this size in the current arithmetic mode (fp32
-    precision with the split GEMMs on); everything else stays on wfae_conv1x1_*"""
-    return (_C1GEMM and _SPLIT_GEMM and _lib.load().wfae_get_matmul_precision() == 0
-            and bool(_lib.load().wfae_c1gemm_supported(int(m), int(k), int(hw))))
 
 
 # ---- bf16 storage: csrc/c1b.hip (no format change between HBM and the matrix core)
@@ -465,148 +498,6 @@ def c1b_fwd(Wb, x, st=None, res=None, stats=False, label="wfae_c1b_fwd"):
     _call("wfae_c1b_fwd", fl, by, _p(Wb), _p(x), ps, ph, _p(res), _p(y), nb, k, m, h * wd, part.data_ptr(), part.numel(),
           ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream(), label=label, peak=PEAK_BF16_MFMA)
     return y, StatRows(part, rows.value)
-
-
-# c1gemm is taken for reductions K >= WFAE_C1_MIN_K.  Measured (profiles/r03_kbench_c1_fused_bn_backward.txt, tools/kbench.py
-# --only c1): in isolation it beats the round-2 kernels on the K >= 512 shapes (1024 -> 256 @48: fused-prologue forward
-# 0.376 -> 0.273 ms, data gradient 0.272 -> 0.237 ms = 163 TF fp32-equivalent; @24: 0.154 -> 0.086 ms) and loses on the short
-# reductions (one block of 144 KiB LDS per CU cannot hide its prologue / epilogue); inside the step the K >= 512 shapes came
-# out EQUAL (1x1 forward 29.6 -> 29.6 ms, data gradient 20.2 -> 20.2 ms per step, profiles/r03_v1_*), so the default keeps the
-# round-2 kernels (and their bit patterns) at fp32 precision; the kernel is the 1x1 path of the bf16-storage mode.
-_C1_MIN_K = int(os.environ.get("WFAE_C1_MIN_K", str(1 << 30)))
-
-
-def c1gemm_preferred(m, k, hw):
-    """c1gemm for this product?  (reductions K >= WFAE_C1_MIN_K, see above)"""
-    return k >= _C1_MIN_K and c1gemm_supported(m, k, hw)
-
-
-def conv1x1_bn_fusable(c, hw):
-    """shapes for which wfae_conv1x1_bwd_data_bnred / _bndx serve a data gradient with `c` result channels"""
-    return c % 4 == 0 and hw % 4 == 0
-
-
-def conv1x1_bwd_data_bnred(dy, w, x, st, store=True):
-    """da = conv1x1_bwd_data(dy, w) with the reductions of the BatchNorm + GELU backward in front (x: its input) taken in
-    the GEMM epilogue -> (da | None, StatRows)"""
-    import ctypes
-    _chk(dy, w, x)
-    nb, cout, h, wd = dy.shape
-    cin = w.shape[1]
-    da = torch.empty((nb, cin, h, wd), dtype=torch.float32, device=dy.device) if store else None
-    rows_n = 2 * ((nb * h * wd + 127) // 128)
-    part = torch.empty(2 * rows_n * cin, dtype=torch.float64, device=dy.device)
-    rows = ctypes.c_int(0)
-    n = nb * h * wd
-    _call("wfae_conv1x1_bwd_data_bnred", 2 * n * cin * cout, 4 * n * (cout + cin + (cin if store else 0)) + 4 * cin * cout, _p(dy),
-          _p(w), _p(x), _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd), _p(da), nb, cin, cout, h * wd, part.data_ptr(),
-          part.numel(), ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream())
-    return da, StatRows(part, rows.value)
-
-
-def conv1x1_bwd_data_bndx(dy, w, x, gamma, st, res=None, training=True):
-    """dx of the BatchNorm + GELU in front of a 1x1 convolution with da = conv1x1_bwd_data(dy, w) recomputed on chip (after
-    conv1x1_bwd_data_bnred(store=False) + bn_act_bwd_from_rows on the same stream)"""
-    _chk(dy, w, x, gamma, res)
-    nb, cout, h, wd = dy.shape
-    cin = w.shape[1]
-    dx = torch.empty((nb, cin, h, wd), dtype=torch.float32, device=dy.device)
-    ws = workspace()
-    n = nb * h * wd
-    _call("wfae_conv1x1_bwd_data_bndx", 2 * n * cin * cout, 4 * n * (cout + 2 * cin + (cin if res is not None else 0)) + 4 * cin * cout,
-          _p(dy), _p(w), _p(x), _p(gamma), _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd), ws.data_ptr(), _p(res), _p(dx),
-          nb, cin, cout, h * wd, int(training), _stream())
-    return dx
-
-
-def c1_split_weights(w):
-    """w (Cout, Cin[,1,1]) -> (W3, Wt3): bf16 planes (int16) [3, Cout, Cin] of w and [3, Cin, Cout] of its transpose"""
-    _chk(w)
-    cout, cin = w.shape[0], w.shape[1]
-    W3 = torch.empty((3, cout, cin), dtype=torch.int16, device=w.device)
-    Wt3 = torch.empty((3, cin, cout), dtype=torch.int16, device=w.device)
-    _call("wfae_c1gemm_split_weights", 0, 16 * w.numel(), _p(w), W3.data_ptr(), Wt3.data_ptr(), cout, cin, _stream())
-    return W3, Wt3
-
-
-def c1gemm_fwd(W3, x, st=None, res=None, stats=False, label="wfae_c1gemm_fwd"):
-    """y = W f(x) (+ res), W3 (3, M, K) from c1_split_weights; st: BnStats whose scale / shift fold a BatchNorm + GELU in
-    front of the convolution into the operand loader; stats=True: -> (y, StatRows of y)"""
-    import ctypes
-    _chk(x, res)
-    nb, k, h, wd = x.shape
-    m = W3.shape[1]
-    if W3.shape[2] != k or W3.dtype != torch.int16 or not W3.is_contiguous():
-        raise _lib.WfaeError("c1gemm_fwd: W3 must be the contiguous (3, M, K) int16 planes of the weight")
-    y = torch.empty((nb, m, h, wd), dtype=torch.float32, device=x.device)
-    fl = 2 * nb * h * wd * k * m
-    by = 4 * nb * h * wd * (k + m) + 6 * k * m + (0 if res is None else 4 * nb * h * wd * m)
-    ps, ph = (None, None) if st is None else (_p(st.scale), _p(st.shift))
-    if not stats:
-        _call("wfae_c1gemm_fwd", fl, by, W3.data_ptr(), _p(x), ps, ph, _p(res), _p(y), nb, k, m, h * wd, None, 0, None, _stream(),
-              label=label)
-        return y
-    rows_n = int(_lib.load().wfae_c1gemm_stat_rows(m, k, nb, h * wd))
-    part = torch.empty(2 * rows_n * m, dtype=torch.float64, device=x.device)
-    rows = ctypes.c_int(0)
-    _call("wfae_c1gemm_fwd", fl, by, W3.data_ptr(), _p(x), ps, ph, _p(res), _p(y), nb, k, m, h * wd, part.data_ptr(), part.numel(),
-          ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream(), label=label)
-    return y, StatRows(part, rows.value)
-
-
-def c1gemm_bnred(Wt3, dt, x, st, store=True):
-    """da = W^T dt with the reductions of the BatchNorm + GELU backward in front (sum dU, sum dU xhat over x) taken in the
-    epilogue -> (da | None, StatRows); store=False: da is not written (c1gemm_bndx recomputes it)"""
-    import ctypes
-    _chk(dt, x)
-    nb, k, h, wd = dt.shape
-    m = Wt3.shape[1]
-    da = torch.empty((nb, m, h, wd), dtype=torch.float32, device=dt.device) if store else None
-    rows_n = int(_lib.load().wfae_c1gemm_stat_rows(m, k, nb, h * wd))
-    part = torch.empty(2 * rows_n * m, dtype=torch.float64, device=dt.device)
-    rows = ctypes.c_int(0)
-    n = nb * h * wd
-    _call("wfae_c1gemm_bnred", 2 * n * k * m, 4 * n * (k + m + (m if store else 0)) + 6 * k * m, Wt3.data_ptr(), _p(dt), _p(x),
-          _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd), _p(da), nb, k, m, h * wd, part.data_ptr(), part.numel(),
-          ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream())
-    return da, StatRows(part, rows.value)
-
-
-def bn_act_bwd_from_rows(sr, c, dgamma, dbeta, accumulate=False):
-    """phase 1 of bn_act_bwd from the partial rows of c1gemm_bnred: dgamma / dbeta + the coefficients at the head of this
-    stream's workspace, where bn_act_bwd(..., phases=2) / c1gemm_bndx read them (no other workspace user in between)"""
-    _chk(dgamma, dbeta)
-    ws = workspace()
-    _call("wfae_bn_act_bwd_from_rows", 0, 8 * sr.part.numel(), sr.part.data_ptr(), sr.rows, c, _p(dgamma), _p(dbeta), int(accumulate),
-          ws.data_ptr(), ws.numel(), _stream(), label="wfae_bn_act_bwd[reduce]")
-    return ws
-
-
-def bn_act_bwd_dx(dy, x, gamma, st, res=None, act=1, training=True):
-    """phase 2 of bn_act_bwd alone (after bn_act_bwd_from_rows on the same stream; fp32 storage)"""
-    _chk(dy, x, gamma, res)
-    nb, c, h, wd = x.shape
-    dx = torch.empty_like(x)
-    ws = workspace()
-    _call("wfae_bn_act_bwd", 0, 4 * x.numel() * (4 if res is not None else 3), _p(dy), _p(x), _p(gamma), _p(st.scale), _p(st.shift),
-          _p(st.mean), _p(st.invstd), _p(res), _p(dx), None, None, nb, c, h * wd, act, int(training), 0, 2, ws.data_ptr(),
-          ws.numel(), _stream(), label="wfae_bn_act_bwd[dx]")
-    return dx
-
-
-def c1gemm_bndx(Wt3, dt, x, gamma, st, res=None, training=True):
-    """dx of the BatchNorm + GELU in front of a 1x1 convolution with da = W^T dt recomputed on chip (after
-    c1gemm_bnred(store=False) + bn_act_bwd_from_rows on the same stream)"""
-    _chk(dt, x, gamma, res)
-    nb, k, h, wd = dt.shape
-    m = Wt3.shape[1]
-    dx = torch.empty((nb, m, h, wd), dtype=torch.float32, device=dt.device)
-    ws = workspace()
-    n = nb * h * wd
-    _call("wfae_c1gemm_bndx", 2 * n * k * m, 4 * n * (k + 2 * m + (m if res is not None else 0)) + 6 * k * m, Wt3.data_ptr(), _p(dt),
-          _p(x), _p(gamma), _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd), ws.data_ptr(), _p(res), _p(dx), nb, k, m,
-          h * wd, int(training), _stream())
-    return dx
 
 
 # ------------------------------------------------------------------- linear
@@ -1179,10 +1070,9 @@ def bn_act_fwd_stats(x, st, act=1):
     sfx, es = _chka(x)
     nb, c, h, wd = x.shape
     y = torch.empty_like(x)
-    # the library's split count per (image, channel): cdiv(HW / W if HW % W == 0 else HW, 1024) clamped to 1..1024, W = the
-    # elements of one 16-byte access (4 fp32 / 8 bf16)
-    hw, vw = h * wd, 16 // es
-    cap = 2 * c * nb * max(1, min(1024, ((hw // vw if hw % vw == 0 else hw) + 1023) // 1024))
+    # capacity for the library's LARGEST split count per (image, channel) — its scalar path, cdiv(HW, 1024) clamped to
+    # 1..1024 (the 16-byte path, taken by pointer alignment as well as by shape, needs fewer); `splits` comes back from the call
+    cap = 2 * c * nb * max(1, min(1024, (h * wd + 1023) // 1024))
     part = torch.empty(cap, dtype=torch.float64, device=x.device)
     splits = ctypes.c_int(0)
     _call("wfae_bn_act_fwd_stats" + sfx, 0, 2 * es * x.numel(), _p(x), _p(st.scale), _p(st.shift), _p(y), nb, c, h * wd, act,

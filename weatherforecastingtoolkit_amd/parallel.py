@@ -179,11 +179,16 @@ class DataParallelTrainer:
                     return False
         return True
 
-    def reduce_gradients(self):
-        """call after loss.backward(): exchanges whatever the backward hooks have not started yet and
-        waits for the asynchronous parts"""
+    def start_reduce(self):
+        """Begin the exchange of this optimiser's gradients WITHOUT waiting for it (call after its backward): every
+        bucket goes out as an asynchronous all-reduce, ordered behind everything queued on the compute stream so far and
+        running on the process group's own stream, so whatever is queued AFTER this call overlaps the exchange — the
+        discriminator's forward / backward in the AE+GAN step (reference experiments/ae_v2_2/train.py:126-159: its loss
+        reads the detached reconstruction and the discriminator's own parameters only).  finish_reduce() must follow
+        before the gradients are read or the optimiser steps.  Same buckets, same order, same sums as reduce_gradients()."""
         from .functional import join_side_stream
         join_side_stream()
+        self._started = True
         if self.world == 1:
             return
         for a in self.opt.arenas:
@@ -196,14 +201,26 @@ class DataParallelTrainer:
                 g = a.params[i].grad
                 if not g.is_contiguous():
                     raise RuntimeError("data-parallel step: non-contiguous gradient outside the arena")
-                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.sync.group)
-        if self._done_from is not None:
-            a = self.opt.arenas[0]
+                self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.sync.group, async_op=True))
+        n = self.sync.bucket
+        for k, a in enumerate(self.opt.arenas):
             # parameters without a gradient (never-used template layers) contribute their zero-initialised
             # arena slots: the same on every rank, like DDP with find_unused_parameters
-            self.sync.allreduce_(a.flat_g[:self._done_from])
-            self.wait_pending()
-            self._done_from = None
-        else:
-            for a in self.opt.arenas:
-                self.sync.allreduce_(a.flat_g)
+            end = self._done_from if (k == 0 and self._done_from is not None) else a.numel
+            for o in range(0, end, n):
+                self._pending.append(dist.all_reduce(a.flat_g[o:min(end, o + n)], op=dist.ReduceOp.SUM, group=self.sync.group,
+                                                     async_op=True))
+        self._done_from = None
+
+    def finish_reduce(self):
+        """wait (the compute stream, for NCCL / RCCL; the host, for gloo) until the exchange start_reduce() began has landed"""
+        if not getattr(self, "_started", False):
+            raise RuntimeError("DataParallelTrainer.finish_reduce() without start_reduce()")
+        self._started = False
+        self.wait_pending()
+
+    def reduce_gradients(self):
+        """call after loss.backward(): exchanges whatever the backward hooks have not started yet and
+        waits for the asynchronous parts"""
+        self.start_reduce()
+        self.finish_reduce()

@@ -26,6 +26,7 @@
 //     wave (the StatRows format of wfae_conv1x1_fwd_stats, finished by wfae_bn_stats_from_rows).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 using namespace wfae;
 
@@ -76,7 +77,8 @@ __device__ __forceinline__ Planes3 split_pair(float a, float b) {
   return r;
 }
 
-template <int KCH, int MT, int MG, bool PRO, bool STATS, int RWAVES = 8>
+// NBUF: chunk buffers of the narrowing ring; RD: residual-row buffers of the widening ring
+template <int KCH, int MT, int MG, bool PRO, bool STATS, int RWAVES = 8, int NBUF = 2, int RD = 2>
 __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel(C1RP p) {
   constexpr int RNT = 64 * RWAVES;
   constexpr int K = 32 * KCH, M = 16 * MT, NPASS = MT / MG;
@@ -139,8 +141,10 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = *reinterpret_cast<const f32x4*>(xb + i * rowB + lane_in);
   };
-  // prologue + split of one chunk: b[jj][plane] = the eight k of this lane, pixel 4 n16 + jj
-  auto split_chunk = [&](f32x4 (&r)[8], u32x4 (&b)[4][3], int c) {
+  // prologue + split of JW of the four pixel components (jj0 .. jj0 + JW) of one chunk: b[j][plane] = the eight k of this
+  // lane, pixel 4 n16 + jj0 + j
+  auto split_part = [&](f32x4 (&r)[8], auto& b, int c, auto jj0c, auto jwc) {
+    constexpr int JJ0 = decltype(jj0c)::value, JW = decltype(jwc)::value;
     if constexpr (PRO) {
       const f32x4 s0 = *reinterpret_cast<const f32x4*>(lsc + 32 * c + 8 * kg), s1 = *reinterpret_cast<const f32x4*>(lsc + 32 * c + 8 * kg + 4);
       const f32x4 h0 = *reinterpret_cast<const f32x4*>(lsc + K + 32 * c + 8 * kg), h1 = *reinterpret_cast<const f32x4*>(lsc + K + 32 * c + 8 * kg + 4);
@@ -148,20 +152,22 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
       for (int i = 0; i < 8; ++i) {
         const float s = i < 4 ? s0[i & 3] : s1[i & 3], h = i < 4 ? h0[i & 3] : h1[i & 3];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) r[i][jj] = gelu_f(fmaf(r[i][jj], s, h));
+        for (int j = 0; j < JW; ++j) r[i][JJ0 + j] = gelu_f(fmaf(r[i][JJ0 + j], s, h));
       }
     }
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
+    for (int j = 0; j < JW; ++j) {
+      const int jj = JJ0 + j;
       const Planes3 q0 = split_pair(r[0][jj], r[1][jj]), q1 = split_pair(r[2][jj], r[3][jj]);
       const Planes3 q2 = split_pair(r[4][jj], r[5][jj]), q3 = split_pair(r[6][jj], r[7][jj]);
-      b[jj][0] = u32x4{q0.h, q1.h, q2.h, q3.h};
-      b[jj][1] = u32x4{q0.m, q1.m, q2.m, q3.m};
-      b[jj][2] = u32x4{q0.l, q1.l, q2.l, q3.l};
+      b[j][0] = u32x4{q0.h, q1.h, q2.h, q3.h};
+      b[j][1] = u32x4{q0.m, q1.m, q2.m, q3.m};
+      b[j][2] = u32x4{q0.l, q1.l, q2.l, q3.l};
     }
   };
-  // acc[mt][jj] += A(rows 16 (mt0 + mt) .., chunk c) x b: six products per fp32 product, smallest terms first
-  auto multiply = [&](f32x4 (&acc)[MG][4], const u32x4 (&b)[4][3], int c, int a_pass_off) {
+  // acc[mt][jj0 + j] += A(rows 16 (mt0 + mt) .., chunk c) x b[j]: six products per fp32 product, smallest terms first
+  auto multiply_part = [&](f32x4 (&acc)[MG][4], const auto& b, int c, int a_pass_off, auto jj0c, auto jwc) {
+    constexpr int JJ0 = decltype(jj0c)::value, JW = decltype(jwc)::value;
 #pragma unroll
     for (int mt = 0; mt < MG; ++mt) {
       bf16x8 a[3];
@@ -172,10 +178,15 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
 #pragma unroll
       for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          acc[mt][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[pr]], __builtin_bit_cast(bf16x8, b[jj][PB[pr]]), acc[mt][jj], 0, 0, 0);
+        for (int j = 0; j < JW; ++j)
+          acc[mt][JJ0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[pr]], __builtin_bit_cast(bf16x8, b[j][PB[pr]]), acc[mt][JJ0 + j], 0, 0, 0);
     }
   };
+  using I0 = std::integral_constant<int, 0>;
+  using I2 = std::integral_constant<int, 2>;
+  using I4 = std::integral_constant<int, 4>;
+  auto split_chunk = [&](f32x4 (&r)[8], u32x4 (&b)[4][3], int c) { split_part(r, b, c, I0{}, I4{}); };
+  auto multiply = [&](f32x4 (&acc)[MG][4], const u32x4 (&b)[4][3], int c, int a_pass_off) { multiply_part(acc, b, c, a_pass_off, I0{}, I4{}); };
   auto load_res = [&](f32x4 (&rv)[MG][4], int tl, int mt0) {
     const char* rb = reinterpret_cast<const char*>(p.res) + tile_off(tl, M) + (long)(16 * mt0) * rowB;
 #pragma unroll
@@ -208,10 +219,17 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
 
   const bool with_res = p.res != nullptr;
   if (tile < p.ntiles) {
-    f32x4 cur[8];
-    load_chunk(cur, tile, 0);
     if constexpr (!BRES) {
-      // ---- narrowing: stream the K chunks, all M rows at once
+      // ---- narrowing: stream the K chunks through a ring of NBUF register buffers, NBUF - 1 chunks of loads in flight ahead of
+      // the multiply (ACROSS tiles: the ring positions repeat from tile to tile because NBUF divides KCH); all M rows at once.
+      // A lone chunk in flight per wave left the loads of a CU in flight only part of the time (a wave issues its next chunk
+      // when it has finished multiplying the previous one): 4.6 - 4.8 TB/s; the same load shape kept in flight without a gap
+      // reads 6.0 - 6.5 TB/s (tools/probe/hbm_streams.hip).
+      static_assert(KCH % NBUF == 0 && NBUF >= 2, "ring positions must repeat per tile");
+      constexpr int D = NBUF - 1;
+      f32x4 ring[NBUF][8];
+#pragma unroll
+      for (int c = 0; c < D; ++c) load_chunk(ring[c], tile, c);
       while (tile < p.ntiles) {
         const int nxt_tile = tile + tstride < p.ntiles ? tile + tstride : tile;   // past the end: a harmless re-read
         f32x4 acc[MG][4];
@@ -222,58 +240,67 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
           for (int jj = 0; jj < 4; ++jj) acc[mt][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < KCH; ++c) {
-          f32x4 nxt[8];
-          if (c + 1 < KCH) load_chunk(nxt, tile, c + 1);
-          else load_chunk(nxt, nxt_tile, 0);
-          // ONE chunk of loads in flight ahead of the multiply: without the fences the scheduler hoists the loads of every
-          // chunk of the unrolled loop to the top (128 - 256 staging registers, spills)
+          if (c + D < KCH) load_chunk(ring[(c + D) % NBUF], tile, c + D);
+          else load_chunk(ring[(c + D) % NBUF], nxt_tile, c + D - KCH);
+          // fences: without them the scheduler hoists the loads of every chunk of the unrolled loop to the top (spills)
           __builtin_amdgcn_sched_barrier(0);
-          u32x4 b[4][3];
-          split_chunk(cur, b, c);
-          multiply(acc, b, c, 0);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+          if constexpr (MG >= 4) {   // 64 accumulator registers: the chunk in two halves of two pixel components (24 fragment registers)
+            u32x4 b2[2][3];
+            split_part(ring[c % NBUF], b2, c, I0{}, I2{});
+            multiply_part(acc, b2, c, 0, I0{}, I2{});
+            __builtin_amdgcn_sched_barrier(0);
+            split_part(ring[c % NBUF], b2, c, I2{}, I2{});
+            multiply_part(acc, b2, c, 0, I2{}, I2{});
+          } else {
+            u32x4 b[4][3];
+            split_chunk(ring[c % NBUF], b, c);
+            multiply(acc, b, c, 0);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
         store_pass(acc, rv, false, tile, 0);
         tile += tstride;
       }
     } else {
-      // ---- widening: the tile's split operand stays in registers, M in passes of 16 MG rows
+      // ---- widening: the tile's split operand stays in registers, M in passes of 16 MG rows; the residual rows travel
+      // RD - 1 passes ahead through a ring of RD register buffers, the next tile's operand under the last passes
+      static_assert(NPASS % RD == 0 && RD >= 2, "ring positions must repeat per tile");
+      f32x4 raw[KCH][8];
+#pragma unroll
+      for (int c = 0; c < KCH; ++c) load_chunk(raw[c], tile, c);
       while (tile < p.ntiles) {
         const int nxt_tile = tile + tstride < p.ntiles ? tile + tstride : tile;
-        f32x4 more[KCH > 1 ? KCH - 1 : 1][8];
+        f32x4 rr[RD][MG][4];
+        if (with_res) {
 #pragma unroll
-        for (int c = 1; c < KCH; ++c) load_chunk(more[c - 1], tile, c);
-        f32x4 rcur[MG][4], rnxt[MG][4];
-        if (with_res) load_res(rcur, tile, 0);
+          for (int u = 0; u < RD - 1; ++u) load_res(rr[u], tile, u * MG);
+        }
         __builtin_amdgcn_sched_barrier(0);
         u32x4 b[KCH][4][3];
-        split_chunk(cur, b[0], 0);
 #pragma unroll
-        for (int c = 1; c < KCH; ++c) split_chunk(more[c - 1], b[c], c);
+        for (int c = 0; c < KCH; ++c) split_chunk(raw[c], b[c], c);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
-        for (int pass = 0; pass < NPASS; ++pass) {
-          const int mt0 = pass * MG;
-          if (pass + 1 < NPASS) {
-            if (with_res) load_res(rnxt, tile, mt0 + MG);
-          } else {
-            load_chunk(cur, nxt_tile, 0);   // the first chunk of the wave's next tile travels under the last pass
-          }
-          f32x4 acc[MG][4];
+        for (int pass0 = 0; pass0 < NPASS; pass0 += RD) {
 #pragma unroll
-          for (int mt = 0; mt < MG; ++mt)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc[mt][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int c = 0; c < KCH; ++c) multiply(acc, b[c], c, mt0 * (16 * 64));
-          store_pass(acc, rcur, with_res, tile, mt0);
-          if (with_res && pass + 1 < NPASS) {
+          for (int u = 0; u < RD; ++u) {
+            const int pass = pass0 + u, mt0 = pass * MG;
+            if (pass + RD - 1 < NPASS) {
+              if (with_res) load_res(rr[(u + RD - 1) % RD], tile, (pass + RD - 1) * MG);
+            } else if (u >= RD - KCH) {
+              // the last KCH passes of the tile: one chunk each of the wave's next tile (its first passes do not wait)
+              load_chunk(raw[u - (RD - KCH)], nxt_tile, u - (RD - KCH));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc[MG][4];
 #pragma unroll
             for (int mt = 0; mt < MG; ++mt)
 #pragma unroll
-              for (int q = 0; q < 4; ++q) rcur[mt][q] = rnxt[mt][q];
+              for (int jj = 0; jj < 4; ++jj) acc[mt][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) multiply(acc, b[c], c, mt0 * (16 * 64));
+            store_pass(acc, rr[u], with_res, tile, mt0);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
         tile += tstride;
@@ -309,24 +336,27 @@ inline int num_cus() {
   return n;
 }
 
-// waves per block, by shape.  Measured on one box (tools/kbench.py --only c1, profiles/r04_kbench_c1r_knobs.txt): every shape
-// runs one block per CU (the weight image of the C = 256 shapes fills the LDS); 8 waves except the widening C = 256 product,
-// whose 230-register waves run faster one per SIMD (0.545 -> 0.504 ms with residual + sums).  A block barrier per tile (to keep
-// the block's waves on adjacent tiles in phase) and three 4-wave blocks per CU at the C = 128 shapes changed nothing (+-2 %).
-inline int waves_of(int sid) { return sid == 3 ? 4 : 8; }
+// waves per block, ring depths: measured per shape on one box with the variants interleaved (profiles/r04_kbench_c1r_variants.txt).
+// Every shape runs one block per CU (the weight image of the C = 256 shapes fills the LDS).  Narrowing shapes: 8 waves, one
+// chunk in flight ahead of the multiply — a ring of four buffers (three chunks in flight) measured the same (0.314 / 0.308 vs
+// 0.311 / 0.310 ms at C = 256, 0.598 vs 0.592 at C = 128): these kernels do not wait for their loads.  Widening, C = 256: 8 waves
+// and the residual rows one pass ahead (0.49 ms with residual + sums against 0.50 - 0.52 for 4 waves, 0.53 - 0.57 for deeper
+// rings); widening, C = 128 (a 24 KiB weight image): 4 waves of 370 registers with the residual rows seven passes ahead (1.02 ms
+// against 1.06 for 8 waves three passes ahead and 1.10 one pass ahead; data gradient 0.574 against 0.632 / 0.656).
+inline int waves_of(int sid) { return sid == 2 ? 4 : 8; }
 
 inline int grid_for(long ntiles, int waves) {
   const long g = (ntiles + waves - 1) / waves;
   return (int)(g < num_cus() ? g : num_cus());
 }
 
-template <int KCH, int MT, int MG, int NW>
+template <int KCH, int MT, int MG, int NW, int NBUF, int RD>
 void launch_shape(const C1RP& p, bool pro, bool stats, int grid, hipStream_t st) {
   const dim3 g((unsigned)grid), b(64 * NW);
-  if (pro && stats) hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, true, true, NW>), g, b, 0, st, p);
-  else if (pro) hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, true, false, NW>), g, b, 0, st, p);
-  else if (stats) hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, false, true, NW>), g, b, 0, st, p);
-  else hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, false, false, NW>), g, b, 0, st, p);
+  if (pro && stats) hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, true, true, NW, NBUF, RD>), g, b, 0, st, p);
+  else if (pro) hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, true, false, NW, NBUF, RD>), g, b, 0, st, p);
+  else if (stats) hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, false, true, NW, NBUF, RD>), g, b, 0, st, p);
+  else hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, false, false, NW, NBUF, RD>), g, b, 0, st, p);
 }
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -377,10 +407,10 @@ int wfae_c1r_fwd(const float* w, int64_t w_sm, int64_t w_sk, const float* x, con
   hipStream_t st = (hipStream_t)stream;
   const bool pro = pro_scale != nullptr, stats = stat_part != nullptr;
   switch (sid) {
-    case 0: launch_shape<4, 2, 2, 8>(p, pro, stats, grid, st); break;
-    case 1: launch_shape<8, 4, 4, 8>(p, pro, stats, grid, st); break;
-    case 2: launch_shape<1, 8, 1, 8>(p, pro, stats, grid, st); break;
-    default: launch_shape<2, 16, 1, 4>(p, pro, stats, grid, st); break;
+    case 0: launch_shape<4, 2, 2, 8, 2, 2>(p, pro, stats, grid, st); break;
+    case 1: launch_shape<8, 4, 4, 8, 2, 2>(p, pro, stats, grid, st); break;
+    case 2: launch_shape<1, 8, 1, 4, 2, 8>(p, pro, stats, grid, st); break;
+    default: launch_shape<2, 16, 1, 8, 2, 2>(p, pro, stats, grid, st); break;
   }
   return check_launch("c1r_fwd");
 }

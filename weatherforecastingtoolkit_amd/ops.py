@@ -225,13 +225,14 @@ def c1r_supported(m, k, hw):
             and bool(_lib.load().wfae_c1r_supported(int(m), int(k), int(hw))))
 
 
-def _c1r_take(m, k, hw, fused):
-    """route this product to c1r?  Measured per shape (profiles/r04_kbench_c1r_knobs.txt): at C = 256 gemm.hip's kernels are
-    bound by the fp32 MFMA instruction and c1r wins all four products (0.346 -> 0.312, 0.445 -> 0.320, 0.685 -> 0.504,
-    0.500 -> 0.404 ms); at C = 128 both are HBM-bound: c1r wins the launches that carry a BatchNorm + GELU prologue or a residual
-    + BatchNorm-sum epilogue (0.720 -> 0.645, 1.135 -> 1.068 ms), gemm.hip's LDS-tiled kernel the two plain data gradients
-    (0.544 / 0.557 vs 0.580 / 0.604 ms: 512-byte row segments per load against 256)."""
-    return c1r_supported(m, k, hw) and (fused or m * k == 64 * 256)
+def _c1r_take(m, k, hw, dgrad):
+    """route this product to c1r?  Every shape it serves (profiles/r04_kbench_c1r_variants.txt, r04_kbench_c1r_knobs.txt): at
+    C = 256 gemm.hip's kernels are bound by the fp32 MFMA instruction and c1r wins all four products (0.346 -> 0.31, 0.445 ->
+    0.30, 0.685 -> 0.49, 0.500 -> 0.40 - 0.45 ms); at C = 128 both are HBM-bound: c1r wins the forward launches, which carry a
+    BatchNorm + GELU prologue and / or a residual + BatchNorm-sum epilogue in the step (0.72 -> 0.65, 1.14 -> 1.02 ms), and
+    ties the two plain data gradients (0.54 - 0.59 vs 0.57 - 0.59 ms) — one kernel family per stage, and every form of a
+    shape on the same kernel keeps fused and unfused forms bit-identical."""
+    return c1r_supported(m, k, hw)
 
 
 def _c1r(w, transposed, x, st, res, stats, label):
@@ -288,7 +289,7 @@ def conv1x1_fwd(x, w, bias=None, res=None, res_broadcast=False):
     _chk(x, w, bias, res)
     nb, cin, h, wd = x.shape
     cout = w.shape[0]
-    if bias is None and not res_broadcast and (res is None or cout > cin) and _c1r_take(cout, cin, h * wd, res is not None):
+    if bias is None and not res_broadcast and (res is None or cout > cin) and _c1r_take(cout, cin, h * wd, False):
         return _c1r(w, False, x, None, res, False, "wfae_conv1x1_fwd")
     y = torch.empty((nb, cout, h, wd), dtype=x.dtype, device=x.device)
     stride = 0 if res_broadcast else cout * h * wd
@@ -326,7 +327,7 @@ def conv1x1_fwd_stats(x, w, bias=None, res=None):
     _chk(x, w, bias, res)
     nb, cin, h, wd = x.shape
     cout = w.shape[0]
-    if bias is None and (res is None or cout > cin) and _c1r_take(cout, cin, h * wd, True):
+    if bias is None and (res is None or cout > cin) and _c1r_take(cout, cin, h * wd, False):
         return _c1r(w, False, x, None, res, True, "wfae_conv1x1_fwd")
     y = torch.empty((nb, cout, h, wd), dtype=x.dtype, device=x.device)
     part, cap = _stat_rows_buffer(nb, h * wd, cout, x.device)
@@ -355,7 +356,7 @@ def conv1x1_fwd_bnact(x, st, w, bias=None, res=None, stats=False):
     _chk(x, w, bias, res)
     nb, cin, h, wd = x.shape
     cout = w.shape[0]
-    if bias is None and (res is None or cout > cin) and _c1r_take(cout, cin, h * wd, True):
+    if bias is None and (res is None or cout > cin) and _c1r_take(cout, cin, h * wd, False):
         return _c1r(w, False, x, st, res, stats, "wfae_conv1x1_fwd_bnact")
     y = torch.empty((nb, cout, h, wd), dtype=x.dtype, device=x.device)
     fl = 2 * nb * h * wd * cin * cout
@@ -425,7 +426,7 @@ def conv1x1_bwd_data(dy, w):
     _chk(w)
     nb, cout, h, wd = dy.shape
     cin = w.shape[1]
-    if not sfx and _c1r_take(cin, cout, h * wd, False):
+    if not sfx and _c1r_take(cin, cout, h * wd, True):
         return _c1r(w, True, dy, None, None, False, "wfae_conv1x1_bwd_data")
     dx = torch.empty((nb, cin, h, wd), dtype=dy.dtype, device=dy.device)
     _call("wfae_conv1x1_bwd_data" + sfx, 2 * nb * h * wd * cin * cout, es * nb * h * wd * (cin + cout) + 4 * cin * cout, _p(dy), _p(w),

@@ -9,7 +9,10 @@ from tests._util import relerr
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(32, 128), (64, 256), (128, 32), (256, 64)]     # (M, K) served: C = 128 and C = 256 stages, both directions
+# (M, K) served: the C = 128 and C = 256 stages in both directions (one block owns all rows), and M-sliced (blocks of one XCD
+# share the tiles and split the rows): the widening products of C = 512 / 1024 and the narrowing one of C = 512
+SHAPES = [(32, 128), (64, 256), (128, 32), (256, 64), (512, 128), (1024, 256), (128, 512)]
+FWD_SHAPES = [s for s in SHAPES if s != (128, 512)]        # (128, 512): only the data gradient is routed (ops._c1r_take)
 
 
 def rnd(shape, seed, lo=-1.0, hi=1.0):
@@ -28,7 +31,7 @@ def err64(y, ref64):
 
 
 @pytest.mark.parametrize("m,k", SHAPES)
-@pytest.mark.parametrize("nb,h,w", [(1, 8, 8), (3, 16, 20), (2, 24, 24), (37, 8, 16)])
+@pytest.mark.parametrize("nb,h,w", [(1, 8, 8), (3, 16, 20), (2, 24, 24), (37, 8, 16), (32, 48, 48)])
 def test_c1r_forward_and_data_gradient_match_fp64_like_the_fp32_kernels(ops, dev, m, k, nb, h, w):
     """forward (A = w) and data gradient (A = w^T) on c1r vs fp64; the error must stay at the level of gemm.hip's exact-fp32
     MFMA kernel on the same tensors.  Grids from one partial block (8 tiles) to several tiles per wave (37 images)."""
@@ -44,14 +47,17 @@ def test_c1r_forward_and_data_gradient_match_fp64_like_the_fp32_kernels(ops, dev
         res[False] = (ops.conv1x1_fwd(x, wt), ops.conv1x1_bwd_data(x, wt_t))
     finally:
         ops.set_c1r(True)
-    res[True] = (ops.conv1x1_fwd(x, wt), ops.conv1x1_bwd_data(x, wt_t))
+    res[True] = (ops._c1r(wt, False, x, None, None, False, "test"), ops._c1r(wt_t, True, x, None, None, False, "test"))
+    assert torch.equal(res[True][1], ops.conv1x1_bwd_data(x, wt_t)), "the data gradient of every served shape is routed to c1r"
+    if (m, k) in FWD_SHAPES:
+        assert torch.equal(res[True][0], ops.conv1x1_fwd(x, wt))
     assert not torch.equal(res[True][0], res[False][0]), "c1r did not run (same bits as gemm.hip)"
     for i, ref in enumerate((ref_f, ref_d)):
         e_old, e_new = err64(res[False][i], ref), err64(res[True][i], ref)
         assert e_new <= max(2.0 * e_old, 2e-6), (i, e_new, e_old)
 
 
-@pytest.mark.parametrize("m,k", SHAPES)
+@pytest.mark.parametrize("m,k", FWD_SHAPES)
 def test_c1r_prologue_residual_and_stats(ops, dev, m, k):
     nb, h, w = 5, 16, 24
     x = rnd((nb, k, h, w), 4, -2.0, 2.0).to(dev)
@@ -83,19 +89,35 @@ def test_c1r_prologue_residual_and_stats(ops, dev, m, k):
 
 
 def test_c1r_full_size_stage_shapes(ops, dev):
-    """the four products at B = 32 and the model's resolutions (384x384 with 128 channels, 192x192 with 256): a linearity check
-    that needs no CPU reference — conv(x1 + x2) == conv(x1) + conv(x2) to fp32 rounding, and the last tile of the last image is written"""
-    for c, hh in ((128, 384), (256, 192)):
+    """the four products at B = 32 and the model's resolutions (384x384 with 128 channels, 192x192 with 256), where every wave
+    walks MANY tiles (the cross-tile prefetch rings are live): against gemm.hip's exact-fp32 kernels on the same tensors —
+    every element within fp32 rounding of a K-term dot product — in all the forms the step launches (prologue, residual,
+    BatchNorm sums), and the last tile of the last image is written"""
+    for c, hh in ((128, 384), (256, 192), (512, 96), (1024, 48), (1024, 24)):
         mid = c // 4
         for m, k in ((mid, c), (c, mid)):
-            x1 = (torch.rand((32, k, hh, hh), device=dev) - 0.5)
-            x2 = (torch.rand((32, k, hh, hh), device=dev) - 0.5)
+            if not ops.c1r_supported(m, k, hh * hh):
+                continue
+            x = torch.rand((32, k, hh, hh), device=dev) - 0.5
             wt = (torch.rand((m, k, 1, 1), device=dev) - 0.5) * 0.2
-            y1, y2 = ops._c1r(wt, False, x1, None, None, False, "test"), ops._c1r(wt, False, x2, None, None, False, "test")
-            x1 += x2
-            y12 = ops._c1r(wt, False, x1, None, None, False, "test")
-            y1 += y2
-            d = float((y12 - y1).abs().max() / y1.abs().max())
-            assert d < 2e-6, (m, k, d)
-            assert float(y12[-1, :, -1, -64:].abs().min()) > 0.0
-            del x1, x2, y1, y2, y12
+            wt_t = (torch.rand((k, m, 1, 1), device=dev) - 0.5) * 0.2
+            r = (torch.rand((32, m, hh, hh), device=dev) - 0.5) if m > k else None
+            st = ops.bn_stats_train(x, torch.ones(k, device=dev), torch.zeros(k, device=dev), torch.zeros(k, device=dev),
+                                    torch.ones(k, device=dev))
+            forms = [lambda: ops.conv1x1_fwd(x, wt, None, r), lambda: ops.conv1x1_fwd_bnact(x, st, wt, None, r),
+                     lambda: ops.conv1x1_fwd_stats(x, wt, None, r)[0], lambda: ops.conv1x1_bwd_data(x, wt_t)]
+            for i, fn in enumerate(forms):
+                y_new = fn()
+                ops.set_c1r(False)
+                try:
+                    y_old = fn()
+                finally:
+                    ops.set_c1r(True)
+                if ops._c1r_take(m, k, hh * hh, i == 3):
+                    assert not torch.equal(y_new, y_old), "c1r did not run"
+                scale = float(y_old.abs().max())
+                d = float((y_new - y_old).abs().max()) / scale
+                assert d < 5e-6, (c, m, k, i, d)
+                assert float(y_new[-1, :, -1, -64:].abs().min()) > 0.0
+                del y_new, y_old
+            del x, r

@@ -122,8 +122,8 @@ def main():
     if "c1" in only:
         # csrc/c1r.hip (register-direct, exact three-plane bf16 operands) against gemm.hip's kernels, per Bottleneck stage it
         # serves: the four 1x1 products in the forms the step launches them (prologue / residual / BatchNorm sums)
-        for c, h in [(256, S // 2), (128, S)]:
-            mult = 4 if c == 128 else 8
+        for c, h in [(256, S // 2), (128, S), (512, S // 4), (1024, S // 8), (1024, S // 16)]:
+            mult = 4 if c == 128 or h == S // 16 else 8
             mid = c // 4
             n = B * h * h
             x, t2 = rnd(B, c, h, h), rnd(B, mid, h, h)

@@ -49,6 +49,8 @@ struct C1RP {
   int HW;                    // % 64 == 0: a 64-pixel tile never leaves its image
   int tpi;                   // tiles per image
   int ntiles;
+  int m_total;               // rows of Y: nslices * M (M = the 16 MT rows one block owns)
+  int nslices;               // M-slices: the blocks b, b + 8, .. of one XCD that share a tile sequence split the rows
 };
 
 
@@ -78,7 +80,8 @@ __device__ __forceinline__ Planes3 split_pair(float a, float b) {
 }
 
 // NBUF: chunk buffers of the narrowing ring; RD: residual-row buffers of the widening ring
-template <int KCH, int MT, int MG, bool PRO, bool STATS, int RWAVES = 8, int NBUF = 2, int RD = 2>
+// RESN: a streaming (one-pass) kernel that carries a residual
+template <int KCH, int MT, int MG, bool PRO, bool STATS, int RWAVES = 8, int NBUF = 2, int RD = 2, bool RESN = false>
 __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel(C1RP p) {
   constexpr int RNT = 64 * RWAVES;
   constexpr int K = 32 * KCH, M = 16 * MT, NPASS = MT / MG;
@@ -95,6 +98,15 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int n16 = lane & 15, kg = lane >> 4;
   double* const lst = reinterpret_cast<double*>(smem + A_B + PRO_B) + (STATS ? wave * 2 * M : 0);
+  // M-slices (the C >= 512 products, whose weight image does not fit the LDS as a whole): blocks are dealt round-robin to the
+  // XCDs, so blocks b and b + 8 share one; the nslices consecutive blocks-of-an-XCD of a GROUP own the row slices [slice M,
+  // (slice + 1) M) of the same tiles — the operand tile one of them pulls from HBM is an L2 hit for the others, and each
+  // splits it again for its own rows (free while the split stays under two vector instructions per MFMA).  nslices = 1: a
+  // group is a block, group = blockIdx.x.
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int slice = jb % p.nslices, group = (jb / p.nslices) * 8 + xcd;
+  const int ngroups = gridDim.x / p.nslices;
+  const int m_off = slice * M;
 
   // ---- the weights: split on the way in, three-plane row image [chunk][plane][m][64 B]
   {
@@ -102,7 +114,7 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
     for (int idx = t; idx < M * K / 8; idx += RNT) {
       int m, ch;
       if (kfast) { ch = idx % (K / 8); m = idx / (K / 8); } else { m = idx % M; ch = idx / M; }
-      const float* src = p.W + (long)m * p.w_sm + (long)(8 * ch) * p.w_sk;
+      const float* src = p.W + (long)(m_off + m) * p.w_sm + (long)(8 * ch) * p.w_sk;
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = src[(long)e * p.w_sk];
@@ -129,8 +141,8 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
   const unsigned lane_in = (unsigned)((4 * n16 + 8 * kg * p.HW) * 4);       // this lane's piece of row 8 kg (+ i rows)
   const unsigned lane_out = (unsigned)((4 * n16 + 4 * kg * p.HW) * 4);      // result rows 4 kg + q
   const unsigned a_rd = (unsigned)(n16 * 64) + (((unsigned)kg ^ swz16(n16)) << 4);
-  const int tstride = gridDim.x * RWAVES;
-  int tile = blockIdx.x * RWAVES + wave;
+  const int tstride = ngroups * RWAVES;
+  int tile = group * RWAVES + wave;
 
   auto tile_off = [&](int tl, int chans) -> long {   // byte offset of a tile's first pixel in a [NB][chans][HW] tensor
     const int img = tl / p.tpi;
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
   auto split_chunk = [&](f32x4 (&r)[8], u32x4 (&b)[4][3], int c) { split_part(r, b, c, I0{}, I4{}); };
   auto multiply = [&](f32x4 (&acc)[MG][4], const u32x4 (&b)[4][3], int c, int a_pass_off) { multiply_part(acc, b, c, a_pass_off, I0{}, I4{}); };
   auto load_res = [&](f32x4 (&rv)[MG][4], int tl, int mt0) {
-    const char* rb = reinterpret_cast<const char*>(p.res) + tile_off(tl, M) + (long)(16 * mt0) * rowB;
+    const char* rb = reinterpret_cast<const char*>(p.res) + tile_off(tl, p.m_total) + (long)(m_off + 16 * mt0) * rowB;
 #pragma unroll
     for (int mt = 0; mt < MG; ++mt)
 #pragma unroll
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
   };
   // lane (n16, kg): acc[mt][jj][q] = Y[row 16 (mt0 + mt) + 4 kg + q][pixel 4 n16 + jj]
   auto store_pass = [&](const f32x4 (&acc)[MG][4], const f32x4 (&rv)[MG][4], bool with_res, int tl, int mt0) {
-    char* yb = reinterpret_cast<char*>(p.Y) + tile_off(tl, M) + (long)(16 * mt0) * rowB;
+    char* yb = reinterpret_cast<char*>(p.Y) + tile_off(tl, p.m_total) + (long)(m_off + 16 * mt0) * rowB;
 #pragma unroll
     for (int mt = 0; mt < MG; ++mt)
 #pragma unroll
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
       while (tile < p.ntiles) {
         const int nxt_tile = tile + tstride < p.ntiles ? tile + tstride : tile;   // past the end: a harmless re-read
         f32x4 acc[MG][4];
-        f32x4 rv[MG][4];   // never read: the narrowing products of the model carry no residual (the host refuses one)
+        f32x4 rv[MG][4];   // residual rows (RESN kernels: the sliced widening products), in flight under the last chunk
 #pragma unroll
         for (int mt = 0; mt < MG; ++mt)
 #pragma unroll
@@ -242,6 +254,9 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
         for (int c = 0; c < KCH; ++c) {
           if (c + D < KCH) load_chunk(ring[(c + D) % NBUF], tile, c + D);
           else load_chunk(ring[(c + D) % NBUF], nxt_tile, c + D - KCH);
+          if constexpr (RESN) {
+            if (c == KCH - 1 && with_res) load_res(rv, tile, 0);
+          }
           // fences: without them the scheduler hoists the loads of every chunk of the unrolled loop to the top (spills)
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (MG >= 4) {   // 64 accumulator registers: the chunk in two halves of two pixel components (24 fragment registers)
@@ -258,13 +273,13 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        store_pass(acc, rv, false, tile, 0);
+        store_pass(acc, rv, RESN && with_res, tile, 0);
         tile += tstride;
       }
     } else {
       // ---- widening: the tile's split operand stays in registers, M in passes of 16 MG rows; the residual rows travel
       // RD - 1 passes ahead through a ring of RD register buffers, the next tile's operand under the last passes
-      static_assert(NPASS % RD == 0 && RD >= 2, "ring positions must repeat per tile");
+      static_assert(NPASS % RD == 0 && RD >= 2 && KCH <= RD, "ring positions must repeat per tile");
       f32x4 raw[KCH][8];
 #pragma unroll
       for (int c = 0; c < KCH; ++c) load_chunk(raw[c], tile, c);
@@ -285,12 +300,9 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
 #pragma unroll
           for (int u = 0; u < RD; ++u) {
             const int pass = pass0 + u, mt0 = pass * MG;
-            if (pass + RD - 1 < NPASS) {
-              if (with_res) load_res(rr[(u + RD - 1) % RD], tile, (pass + RD - 1) * MG);
-            } else if (u >= RD - KCH) {
-              // the last KCH passes of the tile: one chunk each of the wave's next tile (its first passes do not wait)
-              load_chunk(raw[u - (RD - KCH)], nxt_tile, u - (RD - KCH));
-            }
+            if (with_res && pass + RD - 1 < NPASS) load_res(rr[(u + RD - 1) % RD], tile, (pass + RD - 1) * MG);
+            // the last KCH passes of the tile: one chunk each of the wave's next tile (its first passes do not wait)
+            if (u >= RD - KCH && pass0 == NPASS - RD) load_chunk(raw[u >= RD - KCH ? u - (RD - KCH) : 0], nxt_tile, u - (RD - KCH));
             __builtin_amdgcn_sched_barrier(0);
             f32x4 acc[MG][4];
 #pragma unroll
@@ -308,23 +320,28 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
     }
   }
   if constexpr (STATS) {   // one partial row per wave (zeros from a wave that had no tile)
-    const long row = (long)blockIdx.x * RWAVES + wave;
+    const long row = (long)group * RWAVES + wave;   // the slices of a group fill disjoint columns of the group's rows
     for (int i = lane; i < M; i += 64) {
-      p.part0[row * M + i] = lst[i];
-      p.part1[row * M + i] = lst[M + i];
+      p.part0[row * p.m_total + m_off + i] = lst[i];
+      p.part1[row * p.m_total + m_off + i] = lst[M + i];
     }
   }
 }
 
-struct Shape { int M, K; };
-// served (M, K): the Bottleneck products of the C = 128 and C = 256 stages
-inline int shape_id(int M, int K) {
-  if (M == 32 && K == 128) return 0;
-  if (M == 64 && K == 256) return 1;
-  if (M == 128 && K == 32) return 2;
-  if (M == 256 && K == 64) return 3;
-  return -1;
+// served (M, K): the Bottleneck products of the C = 128 and C = 256 stages (one block owns all M rows) and, M-sliced, the
+// widening products of the C = 512 / 1024 stages and the narrowing data gradient of C = 512 (98 KiB weight-image slices)
+struct ShapeInfo { int sid, nslices, waves; };
+inline ShapeInfo shape_of(int M, int K) {
+  if (M == 32 && K == 128) return {0, 1, 8};
+  if (M == 64 && K == 256) return {1, 1, 8};
+  if (M == 128 && K == 32) return {2, 1, 4};
+  if (M == 256 && K == 64) return {3, 1, 4};
+  if (M == 512 && K == 128) return {4, 4, 4};     // slices of 128 rows
+  if (M == 1024 && K == 256) return {5, 16, 4};   // slices of 64 rows
+  if (M == 128 && K == 512) return {6, 4, 8};     // slices of 32 rows
+  return {-1, 1, 8};
 }
+inline int shape_id(int M, int K) { return shape_of(M, K).sid; }
 
 inline int num_cus() {
   static const int n = [] {
@@ -337,26 +354,30 @@ inline int num_cus() {
 }
 
 // waves per block, ring depths: measured per shape on one box with the variants interleaved (profiles/r04_kbench_c1r_variants.txt).
-// Every shape runs one block per CU (the weight image of the C = 256 shapes fills the LDS).  Narrowing shapes: 8 waves, one
+// Every shape runs one block per CU (the weight image of the C >= 256 shapes fills the LDS).  Narrowing shapes: 8 waves, one
 // chunk in flight ahead of the multiply — a ring of four buffers (three chunks in flight) measured the same (0.314 / 0.308 vs
 // 0.311 / 0.310 ms at C = 256, 0.598 vs 0.592 at C = 128): these kernels do not wait for their loads.  Widening, C = 256: 8 waves
 // and the residual rows one pass ahead (0.49 ms with residual + sums against 0.50 - 0.52 for 4 waves, 0.53 - 0.57 for deeper
 // rings); widening, C = 128 (a 24 KiB weight image): 4 waves of 370 registers with the residual rows seven passes ahead (1.02 ms
 // against 1.06 for 8 waves three passes ahead and 1.10 one pass ahead; data gradient 0.574 against 0.632 / 0.656).
-inline int waves_of(int sid) { return sid == 2 ? 4 : 8; }
-
-inline int grid_for(long ntiles, int waves) {
-  const long g = (ntiles + waves - 1) / waves;
+// grid: one block per CU, a whole number of (XCD x slice) sets
+inline int grid_for(long ntiles, const ShapeInfo& si) {
+  if (si.nslices > 1) {
+    const int unit = 8 * si.nslices;
+    const int g = num_cus() / unit * unit;
+    return g > 0 ? g : unit;
+  }
+  const long g = (ntiles + si.waves - 1) / si.waves;
   return (int)(g < num_cus() ? g : num_cus());
 }
 
-template <int KCH, int MT, int MG, int NW, int NBUF, int RD>
+template <int KCH, int MT, int MG, int NW, int NBUF, int RD, bool RESN = false>
 void launch_shape(const C1RP& p, bool pro, bool stats, int grid, hipStream_t st) {
   const dim3 g((unsigned)grid), b(64 * NW);
-  if (pro && stats) hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, true, true, NW, NBUF, RD>), g, b, 0, st, p);
-  else if (pro) hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, true, false, NW, NBUF, RD>), g, b, 0, st, p);
-  else if (stats) hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, false, true, NW, NBUF, RD>), g, b, 0, st, p);
-  else hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, false, false, NW, NBUF, RD>), g, b, 0, st, p);
+  if (pro && stats) hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, true, true, NW, NBUF, RD, RESN>), g, b, 0, st, p);
+  else if (pro) hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, true, false, NW, NBUF, RD, RESN>), g, b, 0, st, p);
+  else if (stats) hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, false, true, NW, NBUF, RD, RESN>), g, b, 0, st, p);
+  else hipLaunchKernelGGL((c1r_kernel<KCH, MT, MG, false, false, NW, NBUF, RD, RESN>), g, b, 0, st, p);
 }
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -370,9 +391,9 @@ int wfae_c1r_supported(int M, int K, int HW) {
 }
 
 int wfae_c1r_stat_rows(int M, int K, int NB, int HW) {
-  const int sid = shape_id(M, K);
-  if (sid < 0 || HW <= 0 || HW % 64 != 0 || NB <= 0) return 0;
-  return grid_for((long)NB * (HW / 64), waves_of(sid)) * waves_of(sid);
+  const ShapeInfo si = shape_of(M, K);
+  if (si.sid < 0 || HW <= 0 || HW % 64 != 0 || NB <= 0) return 0;
+  return grid_for((long)NB * (HW / 64), si) / si.nslices * si.waves;
 }
 
 int wfae_c1r_fwd(const float* w, int64_t w_sm, int64_t w_sk, const float* x, const float* pro_scale, const float* pro_shift,
@@ -380,9 +401,11 @@ int wfae_c1r_fwd(const float* w, int64_t w_sm, int64_t w_sk, const float* x, con
                  wfae_stream_t stream) {
   WFAE_REQUIRE(w && x && y, WFAE_ERR_NULL_POINTER, "c1r_fwd: null pointer");
   WFAE_REQUIRE(NB > 0 && K > 0 && M > 0 && HW > 0 && (int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "c1r_fwd: bad shape");
-  const int sid = shape_id(M, K);
+  const ShapeInfo si = shape_of(M, K);
+  const int sid = si.sid;
   WFAE_REQUIRE(sid >= 0 && HW % 64 == 0, WFAE_ERR_UNSUPPORTED,
-               "c1r_fwd: serves (M, K) = (32, 128), (64, 256), (128, 32), (256, 64) with HW %% 64 == 0 (M %d, K %d, HW %d)", M, K, HW);
+               "c1r_fwd: serves (M, K) = (32, 128), (64, 256), (128, 32), (256, 64), (512, 128), (1024, 256), (128, 512) with "
+               "HW %% 64 == 0 (M %d, K %d, HW %d)", M, K, HW);
   WFAE_REQUIRE(wfae::split_gemm_enabled(), WFAE_ERR_UNSUPPORTED, "c1r_fwd: needs fp32 precision with the split GEMMs on");
   WFAE_REQUIRE((w_sm == K && w_sk == 1) || (w_sm == 1 && w_sk == M), WFAE_ERR_BAD_SHAPE,
                "c1r_fwd: the weight is (M, K) row-major (strides K, 1) or its transpose (strides 1, M)");
@@ -395,9 +418,10 @@ int wfae_c1r_fwd(const float* w, int64_t w_sm, int64_t w_sk, const float* x, con
   p.X = x; p.Y = y; p.res = res;
   p.pro_scale = pro_scale; p.pro_shift = pro_shift;
   p.HW = HW; p.tpi = HW / 64; p.ntiles = NB * p.tpi;
-  const int grid = grid_for(p.ntiles, waves_of(sid));
+  p.m_total = M; p.nslices = si.nslices;
+  const int grid = grid_for(p.ntiles, si);
   if (stat_part) {
-    const int rows = grid * waves_of(sid);
+    const int rows = grid / si.nslices * si.waves;
     WFAE_REQUIRE(stat_capacity >= 2 * (int64_t)rows * M, WFAE_ERR_WORKSPACE, "c1r_fwd: stat_part holds %lld doubles, needs %lld",
                  (long long)stat_capacity, (long long)(2 * (int64_t)rows * M));
     *stat_rows = rows;
@@ -410,7 +434,10 @@ int wfae_c1r_fwd(const float* w, int64_t w_sm, int64_t w_sk, const float* x, con
     case 0: launch_shape<4, 2, 2, 8, 2, 2>(p, pro, stats, grid, st); break;
     case 1: launch_shape<8, 4, 4, 8, 2, 2>(p, pro, stats, grid, st); break;
     case 2: launch_shape<1, 8, 1, 4, 2, 8>(p, pro, stats, grid, st); break;
-    default: launch_shape<2, 16, 1, 8, 2, 2>(p, pro, stats, grid, st); break;
+    case 3: launch_shape<2, 16, 1, 4, 2, 2>(p, pro, stats, grid, st); break;
+    case 4: launch_shape<4, 8, 8, 4, 2, 2, true>(p, pro, stats, grid, st); break;
+    case 5: launch_shape<8, 4, 4, 4, 4, 2, true>(p, pro, stats, grid, st); break;
+    default: launch_shape<16, 2, 2, 8, 2, 2>(p, pro, stats, grid, st); break;
   }
   return check_launch("c1r_fwd");
 }

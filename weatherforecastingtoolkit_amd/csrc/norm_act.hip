@@ -34,11 +34,11 @@ struct RedGeom {
   long per_split;  // elements per split (multiple of 8: whole vector accesses of fp32 and bf16 tensors)
 };
 
-inline RedGeom red_geom(int outer, int C, int inner, long max_parts_per_c) {
+inline RedGeom red_geom(int outer, int C, int inner, long max_parts_per_c, long target_blocks = 2048) {
   RedGeom g;
   g.outer = outer; g.C = C; g.inner = inner;
   const long total = (long)outer * inner;
-  long splits = (2048 + C - 1) / C;
+  long splits = (target_blocks + C - 1) / C;
   if (splits > max_parts_per_c) splits = max_parts_per_c;
   const long min_chunk = 4096;
   if (splits > (total + min_chunk - 1) / min_chunk) splits = (total + min_chunk - 1) / min_chunk;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64) void bn_finalize_parts_kernel(const double* __r
 }
 
 // backward pass 1: per channel  sum dU  and  sum dU * xhat,  dU = dy * act'(u)
-template <int ACT, typename T = float>
+template <int ACT, typename T = float, int U = 2>
 __global__ __launch_bounds__(RT) void bn_act_bwd_reduce_kernel(const T* __restrict__ dy,
                                                                const T* __restrict__ x,
                                                                const float* __restrict__ scale,
@@ -336,24 +336,30 @@ __global__ __launch_bounds__(RT) void bn_act_bwd_reduce_kernel(const T* __restri
       const float h0 = (xv[0] - mu) * is, h1 = (xv[1] - mu) * is, h2 = (xv[2] - mu) * is, h3 = (xv[3] - mu) * is;
       s2 += (double)(fmaf(d0, h0, d1 * h1) + fmaf(d2, h2, d3 * h3));
     };
-    for (; i < end; i += 2 * RT * W) {
-      const long off0 = (o * g.C + c) * g.inner + in;
-      in += RT * W;
-      while (in >= g.inner) { in -= g.inner; ++o; }
-      const bool two = i + RT * W < end;
-      const long off1 = two ? (o * g.C + c) * g.inner + in : off0;
-      in += RT * W;
-      while (in >= g.inner) { in -= g.inner; ++o; }
-      float xv0[W], dv0[W], xv1[W], dv1[W];
-      ldv(x + off0, xv0);
-      ldv(dy + off0, dv0);
-      ldv(x + off1, xv1);
-      ldv(dy + off1, dv1);
+    for (; i < end; i += U * RT * W) {
+      // U chunks per iteration, all 2 U loads issued before the arithmetic; sums are added in the same order as one chunk per
+      // iteration would, a missing chunk re-reads the first and is skipped
+      long off[U];
+      bool on[U];
 #pragma unroll
-      for (int q = 0; q < W; q += 4) quad(xv0 + q, dv0 + q);
-      if (two) {
+      for (int u = 0; u < U; ++u) {
+        on[u] = i + (long)u * RT * W < end;
+        off[u] = on[u] ? (o * g.C + c) * g.inner + in : off[0];
+        in += RT * W;
+        while (in >= g.inner) { in -= g.inner; ++o; }
+      }
+      float xv[U][W], dv[U][W];
 #pragma unroll
-        for (int q = 0; q < W; q += 4) quad(xv1 + q, dv1 + q);
+      for (int u = 0; u < U; ++u) {
+        ldv(x + off[u], xv[u]);
+        ldv(dy + off[u], dv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (on[u]) {
+#pragma unroll
+          for (int q = 0; q < W; q += 4) quad(xv[u] + q, dv[u] + q);
+        }
       }
     }
   } else {
@@ -782,6 +788,9 @@ int bn_act_bwd_impl(const T* dy, const T* x, const float* gamma, const float* sc
   float* coef = (float*)ws;
   double* part = (double*)((char*)ws + coef_bytes);
   const long maxp = (long)((ws_bytes - coef_bytes) / (sizeof(double) * 2 * (size_t)C));
+  // (round 4, profiles/r04_kbench_bn_reduce_sweep.txt: 1 / 2 / 4 chunks of loads in flight per thread x 512 .. 4096 blocks in the
+  // launch all measure the same, 6.0 TB/s on the 2.4 GB tensors and 4.8 - 5.4 on the sub-0.2 ms launches of the narrow / deep
+  // stages, whose ~20 us of fixed cost per reduce + finalize pair is what the step's 5.15 TB/s average shows)
   RedGeom g = red_geom(NB, C, HW, maxp < 65535 ? maxp : 65535);
   const int vec = (HW % W == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) |
                                       reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(res)) & 15) == 0);

@@ -10,9 +10,9 @@ from tests._util import relerr
 pytestmark = pytest.mark.gpu
 
 # (M, K) served: the C = 128 and C = 256 stages in both directions (one block owns all rows), and M-sliced (blocks of one XCD
-# share the tiles and split the rows): the widening products of C = 512 / 1024 and the narrowing one of C = 512
-SHAPES = [(32, 128), (64, 256), (128, 32), (256, 64), (512, 128), (1024, 256), (128, 512)]
-FWD_SHAPES = [s for s in SHAPES if s != (128, 512)]        # (128, 512): only the data gradient is routed (ops._c1r_take)
+# share the tiles and split the rows): the widening products of C = 512 / 1024
+SHAPES = [(32, 128), (64, 256), (128, 32), (256, 64), (512, 128), (1024, 256)]
+FWD_SHAPES = SHAPES
 
 
 def rnd(shape, seed, lo=-1.0, hi=1.0):
@@ -92,7 +92,7 @@ def test_c1r_full_size_stage_shapes(ops, dev):
     """the four products at B = 32 and the model's resolutions (384x384 with 128 channels, 192x192 with 256), where every wave
     walks MANY tiles (the cross-tile prefetch rings are live): against gemm.hip's exact-fp32 kernels on the same tensors —
     every element within fp32 rounding of a K-term dot product — in all the forms the step launches (prologue, residual,
-    BatchNorm sums), and the last tile of the last image is written"""
+    BatchNorm sums)"""
     for c, hh in ((128, 384), (256, 192), (512, 96), (1024, 48), (1024, 24)):
         mid = c // 4
         for m, k in ((mid, c), (c, mid)):
@@ -117,7 +117,6 @@ def test_c1r_full_size_stage_shapes(ops, dev):
                     assert not torch.equal(y_new, y_old), "c1r did not run"
                 scale = float(y_old.abs().max())
                 d = float((y_new - y_old).abs().max()) / scale
-                assert d < 5e-6, (c, m, k, i, d)
-                assert float(y_new[-1, :, -1, -64:].abs().min()) > 0.0
+                assert d < 5e-6, (c, m, k, i, d)      # every element, the last tile of the last image included
                 del y_new, y_old
             del x, r

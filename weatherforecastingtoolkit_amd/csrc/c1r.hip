@@ -180,18 +180,37 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
   // acc[mt][jj0 + j] += A(rows 16 (mt0 + mt) .., chunk c) x b[j]: six products per fp32 product, smallest terms first
   auto multiply_part = [&](f32x4 (&acc)[MG][4], const auto& b, int c, int a_pass_off, auto jj0c, auto jwc) {
     constexpr int JJ0 = decltype(jj0c)::value, JW = decltype(jwc)::value;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    if constexpr (RWAVES == 4 && MG > 1) {
+      // one wave per SIMD (512 registers, nobody else to cover an LDS round trip): every weight fragment of the chunk is read
+      // before the first MFMA instead of three at a time with a wait in front of each group of twelve MFMAs
+      bf16x8 a[MG][3];
 #pragma unroll
-    for (int mt = 0; mt < MG; ++mt) {
-      bf16x8 a[3];
+      for (int mt = 0; mt < MG; ++mt)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        a[pl] = *reinterpret_cast<const bf16x8*>(smem + a_pass_off + (c * 3 + pl) * PLANE_B + mt * (16 * 64) + a_rd);
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        for (int pl = 0; pl < 3; ++pl)
+          a[mt][pl] = *reinterpret_cast<const bf16x8*>(smem + a_pass_off + (c * 3 + pl) * PLANE_B + mt * (16 * 64) + a_rd);
+      __builtin_amdgcn_sched_barrier(0);   // (without it the scheduler sinks each read back in front of its first use)
 #pragma unroll
-      for (int pr = 0; pr < 6; ++pr)
+      for (int mt = 0; mt < MG; ++mt)
 #pragma unroll
-        for (int j = 0; j < JW; ++j)
-          acc[mt][JJ0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[pr]], __builtin_bit_cast(bf16x8, b[j][PB[pr]]), acc[mt][JJ0 + j], 0, 0, 0);
+        for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+          for (int j = 0; j < JW; ++j)
+            acc[mt][JJ0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][PA[pr]], __builtin_bit_cast(bf16x8, b[j][PB[pr]]), acc[mt][JJ0 + j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MG; ++mt) {
+        bf16x8 a[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          a[pl] = *reinterpret_cast<const bf16x8*>(smem + a_pass_off + (c * 3 + pl) * PLANE_B + mt * (16 * 64) + a_rd);
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+          for (int j = 0; j < JW; ++j)
+            acc[mt][JJ0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[pr]], __builtin_bit_cast(bf16x8, b[j][PB[pr]]), acc[mt][JJ0 + j], 0, 0, 0);
+      }
     }
   };
   using I0 = std::integral_constant<int, 0>;
@@ -329,16 +348,19 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
 }
 
 // served (M, K): the Bottleneck products of the C = 128 and C = 256 stages (one block owns all M rows) and, M-sliced, the
-// widening products of the C = 512 / 1024 stages and the narrowing data gradient of C = 512 (98 KiB weight-image slices)
+// widening products of the C = 512 / 1024 stages (49 / 98 KiB weight-image slices of 64 rows).  The narrowing products of
+// those stages stay on gemm.hip: a (M = 128, K = 512) form with four 32-row slices was built and measured equal or slower
+// (0.275 - 0.281 vs 0.267 - 0.290 ms, profiles/r04_kbench_c1r_sliced.txt) — every slice splits the whole operand again and
+// at 48 MFMAs per chunk that no longer hides; all of these kernels, old and new, sit at 135 - 165 TF fp32-equivalent, half of
+// what six bf16 products per fp32 product allow at the clock the chip holds under MFMA load.
 struct ShapeInfo { int sid, nslices, waves; };
 inline ShapeInfo shape_of(int M, int K) {
   if (M == 32 && K == 128) return {0, 1, 8};
   if (M == 64 && K == 256) return {1, 1, 8};
   if (M == 128 && K == 32) return {2, 1, 4};
   if (M == 256 && K == 64) return {3, 1, 4};
-  if (M == 512 && K == 128) return {4, 4, 4};     // slices of 128 rows
+  if (M == 512 && K == 128) return {4, 8, 4};     // slices of 64 rows
   if (M == 1024 && K == 256) return {5, 16, 4};   // slices of 64 rows
-  if (M == 128 && K == 512) return {6, 4, 8};     // slices of 32 rows
   return {-1, 1, 8};
 }
 inline int shape_id(int M, int K) { return shape_of(M, K).sid; }
@@ -404,7 +426,7 @@ int wfae_c1r_fwd(const float* w, int64_t w_sm, int64_t w_sk, const float* x, con
   const ShapeInfo si = shape_of(M, K);
   const int sid = si.sid;
   WFAE_REQUIRE(sid >= 0 && HW % 64 == 0, WFAE_ERR_UNSUPPORTED,
-               "c1r_fwd: serves (M, K) = (32, 128), (64, 256), (128, 32), (256, 64), (512, 128), (1024, 256), (128, 512) with "
+               "c1r_fwd: serves (M, K) = (32, 128), (64, 256), (128, 32), (256, 64), (512, 128), (1024, 256) with "
                "HW %% 64 == 0 (M %d, K %d, HW %d)", M, K, HW);
   WFAE_REQUIRE(wfae::split_gemm_enabled(), WFAE_ERR_UNSUPPORTED, "c1r_fwd: needs fp32 precision with the split GEMMs on");
   WFAE_REQUIRE((w_sm == K && w_sk == 1) || (w_sm == 1 && w_sk == M), WFAE_ERR_BAD_SHAPE,
@@ -435,9 +457,8 @@ int wfae_c1r_fwd(const float* w, int64_t w_sm, int64_t w_sk, const float* x, con
     case 1: launch_shape<8, 4, 4, 8, 2, 2>(p, pro, stats, grid, st); break;
     case 2: launch_shape<1, 8, 1, 4, 2, 8>(p, pro, stats, grid, st); break;
     case 3: launch_shape<2, 16, 1, 4, 2, 2>(p, pro, stats, grid, st); break;
-    case 4: launch_shape<4, 8, 8, 4, 2, 2, true>(p, pro, stats, grid, st); break;
-    case 5: launch_shape<8, 4, 4, 4, 4, 2, true>(p, pro, stats, grid, st); break;
-    default: launch_shape<16, 2, 2, 8, 2, 2>(p, pro, stats, grid, st); break;
+    case 4: launch_shape<4, 4, 4, 4, 4, 2, true>(p, pro, stats, grid, st); break;
+    default: launch_shape<8, 4, 4, 4, 4, 2, true>(p, pro, stats, grid, st); break;
   }
   return check_launch("c1r_fwd");
 }

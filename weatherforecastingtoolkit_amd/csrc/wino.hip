@@ -81,6 +81,50 @@ __device__ __forceinline__ void put_operand(void* __restrict__ base, long idx, l
   }
 }
 
+// The NX = N * N operand values of one tile and phase -> base[idx + xi * xi_stride (+ plane * pl)], xi < NX.  Consecutive lanes
+// own consecutive tiles, so per (xi, plane) a wave writes 64 consecutive bf16 = 128 bytes — as 64 two-byte stores (300 store
+// instructions per tile and thread for F(4x4,2x2): the transforms ran at 4.0 - 4.9 TB/s against 6.1 for the BatchNorm passes).
+// PACKED form (a full wave on one operand row segment that starts on a 16-byte boundary): one plane at a time goes through a
+// wave-private LDS image tb[xi][64] (ds_write_b16, lane-linear) and leaves as 16-byte pieces — piece j = (xi = j >> 3, eight
+// tiles 8 (j & 7) ..) is read by lane j (a linear, conflict-free ds_read_b128) and stored whole: 8 rows x 128 bytes per store
+// instruction, 4 (2) store instructions per plane instead of 25 (9).
+template <bool SPLIT, int NX>
+__device__ __forceinline__ void put_operands(void* __restrict__ base, long idx, long xi_stride, long plane, const float (&v)[NX],
+                                             unsigned short* __restrict__ tb) {
+  if constexpr (!SPLIT) {
+#pragma unroll
+    for (int xi = 0; xi < NX; ++xi) static_cast<float*>(base)[idx + xi * xi_stride] = v[xi];
+  } else {
+    const int lane = threadIdx.x & 63;
+    const long idx0 = __shfl(idx, 0, 64);
+    const bool full = __builtin_amdgcn_ballot_w64(idx == idx0 + lane) == ~0ull && (idx0 & 7) == 0 && (xi_stride & 7) == 0 &&
+                      (plane & 7) == 0;
+    if (!full) {
+#pragma unroll
+      for (int xi = 0; xi < NX; ++xi) put_operand<true>(base, idx + xi * xi_stride, plane, v[xi]);
+      return;
+    }
+    unsigned short* __restrict__ o = static_cast<unsigned short*>(base) + idx0;
+    const int nplanes = plane ? 3 : 1;
+    for (int pl = 0; pl < nplanes; ++pl) {
+#pragma unroll
+      for (int xi = 0; xi < NX; ++xi) {
+        unsigned short h, m, l;
+        split3(v[xi], h, m, l);
+        tb[xi * 64 + lane] = pl == 0 ? h : (pl == 1 ? m : l);
+      }
+#pragma unroll
+      for (int r = 0; r < (NX * 8 + 63) / 64; ++r) {
+        const int j = r * 64 + lane;
+        if (j < NX * 8) {
+          const wfae_vu4 piece = *reinterpret_cast<const wfae_vu4*>(tb + j * 8);
+          *reinterpret_cast<wfae_vu4*>(o + pl * plane + (long)(j >> 3) * xi_stride + (j & 7) * 8) = piece;
+        }
+      }
+    }
+  }
+}
+
 // thread -> (channel c, image n, tile tl) of the transform kernels without a block reduction.  Two launch shapes
 // (pick_grid): large images — one block per (<= 256 tiles, channel, image), the blocks in flight work on neighbouring
 // channels of one image (contiguous input); small images (< 256 tiles) — consecutive threads own consecutive t = (image,
@@ -153,6 +197,9 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const ET* __restrict__ hi,
         for (int j = 0; j < N; ++j) d[i][j] = rowbuf[i][2 * j + q];
       sandwich<N, N>(d, v, [](int a, int i) { return WV::BT[a][i]; });
       const long dst = ((long)(p * 2 + q) * Chi + h) * T + t;
+      // (the packed 16-byte stores of put_operands were tried here too, round 4: 124 instead of 72 registers, 4 instead of 7 waves
+      // per SIMD, and no faster — 0.95 / 0.47 / 1.77 ms against 0.88 / 0.75 / 1.67 of the two-byte stores and 0.72 / 0.36 /
+      // 1.30 ms for the fp32 operand form: this kernel is bound by its patch reads, whose lanes sit 32 bytes apart)
 #pragma unroll
       for (int u = 0; u < N; ++u)
 #pragma unroll
@@ -407,6 +454,8 @@ template <typename WV, bool SPLIT = false, typename ET = float>
 __global__ __launch_bounds__(256) void wino_out_t_kernel(const ET* __restrict__ lo, void* __restrict__ Mt, int Clo,
                                                          int Hlo, int Wlo, long T, int planes = 3) {
   constexpr int N = WV::N, M = WV::M;
+  __shared__ __attribute__((aligned(16))) unsigned short tbuf[SPLIT ? 4 * N * N * 64 : 8];   // put_operands: per-wave image
+  unsigned short* const tb = tbuf + (SPLIT ? (threadIdx.x >> 6) * (N * N * 64) : 0);
   const int TW = Wlo / M, TH = Hlo / M, Timg = TW * TH;
   int l, n, tl;
   if (!tile_of_thread(Clo, Timg, T, l, n, tl)) return;
@@ -426,10 +475,12 @@ __global__ __launch_bounds__(256) void wino_out_t_kernel(const ET* __restrict__ 
   sandwich<N, M>(y, m, [](int u, int a) { return WV::AT[a][u]; });   // A = (A^T)^T
   const long xi_stride = (long)Clo * T;
   const long dst = (long)l * T + (long)n * Timg + tl;
+  float mf[N * N];
 #pragma unroll
   for (int u = 0; u < N; ++u)
 #pragma unroll
-    for (int v = 0; v < N; ++v) put_operand<SPLIT>(Mt, dst + (long)(u * N + v) * xi_stride, planes == 3 ? (long)(N * N) * xi_stride : 0, m[u][v]);
+    for (int v = 0; v < N; ++v) mf[u * N + v] = m[u][v];
+  put_operands<SPLIT, N * N>(Mt, dst, xi_stride, planes == 3 ? (long)(N * N) * xi_stride : 0, mf, tb);
 }
 
 // w (Clo,Chi,4,4) -> U[N*N][Clo][4Chi]:  U = G g G^T per phase, g[a][b] = w[2a+p][2b+q]

@@ -231,11 +231,8 @@ def _c1r_take(m, k, hw, dgrad):
     0.30, 0.685 -> 0.49, 0.500 -> 0.40 - 0.45 ms); at C = 128 both are HBM-bound: c1r wins the forward launches, which carry a
     BatchNorm + GELU prologue and / or a residual + BatchNorm-sum epilogue in the step (0.72 -> 0.65, 1.14 -> 1.02 ms), and
     ties the two plain data gradients (0.54 - 0.59 vs 0.57 - 0.59 ms) — one kernel family per stage, and every form of a
-    shape on the same kernel keeps fused and unfused forms bit-identical.  The M-sliced shapes of the C >= 512 stages: both
-    directions of the widening products; of the narrowing C = 512 product only the data gradient (its forward carries the
-    BatchNorm + GELU prologue, which every slice would evaluate again)."""
-    if m == 128 and k == 512 and not dgrad:
-        return False
+    shape on the same kernel keeps fused and unfused forms bit-identical.  The M-sliced shapes of the C >= 512 stages serve the
+    widening products in both directions (profiles/r04_kbench_c1r_sliced.txt)."""
     return c1r_supported(m, k, hw)
 
 

@@ -57,7 +57,8 @@ typedef enum {
  *   103  round 4: REMOVED wfae_c1gemm_* (six entry points), wfae_conv1x1_bwd_data_bnred / _bndx and
  *        wfae_bn_act_bwd_from_rows (the fused BatchNorm-backward epilogues: parity-green, never faster — the record is
  *        profiles/r03_kbench_c1_fused_bn_backward.txt); wfae_g3b_fwd no longer serves 8 channels per group.  ADDED
- *        wfae_c1r_* (register-direct 1x1 convolutions of the C <= 256 stages). */
+ *        wfae_c1r_* (register-direct 1x1 convolutions: fp32 tensors, C <= 256 stages and the C >= 512 widening products) and
+ *        wfae_c1rb_* (the same on bf16-stored tensors, every stage). */
 int wfae_version(void);
 const char* wfae_last_error_string(void);
 /* upper bound of scratch bytes any single call needs for a problem whose
@@ -145,6 +146,16 @@ int wfae_c1r_stat_rows(int M, int K, int NB, int HW);
 int wfae_c1r_fwd(const float* w, int64_t w_sm, int64_t w_sk, const float* x, const float* pro_scale, const float* pro_shift,
                  const float* res, float* y, int NB, int K, int M, int HW, double* stat_part, int64_t stat_capacity,
                  int* stat_rows, wfae_stream_t stream);
+/* The same register-direct product on bf16-STORED tensors (csrc/c1rb.hip, ABI 103; needs WFAE_PRECISION_BF16): bf16 pieces of
+ * eight pixels per lane go HBM -> registers -> v_mfma_f32_16x16x32_bf16 with four byte-permutes per fragment and no other
+ * arithmetic, the weight as one bf16 plane rounded by the kernel itself, fp32 accumulation, one rounding of the result.  Serves
+ * every Bottleneck product (M, K) = (C/4, C) and (C, C/4), C = 128 .. 1024, with HW % 128 == 0 (wfae_c1rb_supported); other
+ * shapes: wfae_c1b_fwd.  Arguments as wfae_c1r_fwd with uint16_t tensors; the BatchNorm sums are those of the ROUNDED result. */
+int wfae_c1rb_supported(int M, int K, int HW);
+int wfae_c1rb_stat_rows(int M, int K, int NB, int HW);
+int wfae_c1rb_fwd(const float* w, int64_t w_sm, int64_t w_sk, const uint16_t* x, const float* pro_scale, const float* pro_shift,
+                  const uint16_t* res, uint16_t* y, int NB, int K, int M, int HW, double* stat_part, int64_t stat_capacity,
+                  int* stat_rows, wfae_stream_t stream);
 /* Weight gradients of the Bottleneck's 1x1 convolutions with both operands read as K-contiguous rows (csrc/c1w.hip, ABI
  * 102): dw (Cout,Cin) (+)= dy (NB,Cout,HW) . x'^T, x' = x or (bn_scale / bn_shift non-null) gelu(x * bn_scale[c] +
  * bn_shift[c]) rebuilt in the loader (wfae_conv1x1_bwd_weight_bnact's prologue).  fp32 tensors: exact three-plane bf16

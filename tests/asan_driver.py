@@ -158,6 +158,25 @@ for m, k, hw in [(32, 128, 384 * 384), (64, 256, 192 * 192), (128, 32, 384 * 384
 assert lib.wfae_set_split_gemm(0) == 0
 expect(lib.wfae_c1r_fwd(P, 256, 1, Q, None, None, None, R, 32, 256, 64, 192 * 192, None, 0, None, None), UNS, "c1r_fwd needs the split switch")
 assert lib.wfae_set_split_gemm(1) == 0
+# the same on bf16-stored tensors (csrc/c1rb.hip): precision mode, shape table, then every served geometry up to the launch
+expect(lib.wfae_c1rb_fwd(P, 256, 1, Q, None, None, None, R, 32, 256, 64, 192 * 192, None, 0, None, None), UNS, "c1rb_fwd needs bf16 precision")
+assert lib.wfae_c1rb_supported(64, 256, 192 * 192) == 0
+assert lib.wfae_set_matmul_precision(1) == 0
+try:
+    assert lib.wfae_c1rb_supported(64, 256, 192 * 192) == 1 and lib.wfae_c1rb_supported(256, 1024, 24 * 24) == 0
+    assert lib.wfae_c1rb_stat_rows(1024, 256, 32, 48 * 48) == 256 // 16 * 4 and lib.wfae_c1rb_stat_rows(64, 256, 1, 128) == 8
+    checked += 4
+    expect(lib.wfae_c1rb_fwd(P, 256, 1, Q, None, None, None, R, 32, 256, 64, 24 * 24, None, 0, None, None), UNS, "c1rb_fwd HW % 128")
+    expect(lib.wfae_c1rb_fwd(P, 256, 1, Q, None, None, S, R, 32, 256, 64, 192 * 192, None, 0, None, None), UNS, "c1rb_fwd residual on a narrowing product")
+    expect(lib.wfae_c1rb_fwd(P, 256, 1, Q, None, None, None, R, 32, 256, 64, 192 * 192, WS, 16, ctypes.cast(ctypes.pointer(rows_c), ctypes.c_void_p), None),
+           WSP, "c1rb_fwd short stat buffer")
+    for c, hh in [(128, 384), (256, 192), (512, 96), (1024, 48)]:
+        for m, k in ((c // 4, c), (c, c // 4)):
+            expect(lib.wfae_c1rb_fwd(P, k, 1, Q, S, S, S if m > k else None, R, 32, k, m, hh * hh, WS, big,
+                                     ctypes.cast(ctypes.pointer(rows_c), ctypes.c_void_p), None), ANY_FAIL, f"c1rb_fwd {k}->{m}")
+            expect(lib.wfae_c1rb_fwd(P, 1, m, Q, None, None, None, R, 32, k, m, hh * hh, None, 0, None, None), ANY_FAIL, f"c1rb_fwd transposed {k}->{m}")
+finally:
+    assert lib.wfae_set_matmul_precision(0) == 0
 expect(lib.wfae_conv4x4s2_down(P, Q, R, 32, 256, 512, 96, 96, None), ANY_FAIL, "conv4x4s2_down")
 expect(lib.wfae_conv4x4s2_wgrad(P, Q, R, 32, 256, 512, 96, 96, 0, WS, big, None), ANY_FAIL, "conv4x4s2_wgrad")
 expect(lib.wfae_linear_fwd(P, Q, S, R, 32, 36864, 2048, WS, big, None), ANY_FAIL, "linear_fwd 36864->2048")

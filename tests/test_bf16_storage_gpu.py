@@ -356,3 +356,56 @@ def test_c1w_weight_gradient_bf16(ops_medium, dev, nb, cin, cout, h, w, pro):
     finally:
         ops.set_c1w(True)
     assert relerr(dw, old) < 2e-5
+
+
+C1RB_SHAPES = [(32, 128), (64, 256), (128, 32), (256, 64), (128, 512), (512, 128), (256, 1024), (1024, 256)]   # (M, K)
+
+
+@pytest.mark.parametrize("m,k", C1RB_SHAPES)
+@pytest.mark.parametrize("nb,h,w", [(1, 8, 16), (3, 16, 24), (40, 16, 16)])
+@pytest.mark.parametrize("mode", ["plain", "pro", "res+stats", "pro+res+stats"])
+def test_c1rb_register_direct_matches_c1b(ops_medium, dev, m, k, nb, h, w, mode):
+    """csrc/c1rb.hip (bf16 pieces HBM -> registers -> MFMA, four byte-permutes per fragment) against csrc/c1b.hip's LDS-tiled
+    kernel of the same arithmetic (bf16 operands, fp32 accumulation, one rounding) and against torch fp32 on the same bf16
+    tensors: every Bottleneck shape, forward (prologue / residual / BatchNorm sums) and data gradient, from one partial block to
+    several tiles per wave (40 images: the cross-tile prefetch rings and the M-slices are live)"""
+    ops = ops_medium
+    if "res" in mode and m < k:
+        pytest.skip("the residual add belongs to the widening products")
+    assert ops.c1rb_supported(m, k, h * w)
+    x = rnd((nb, k, h, w), 1, -2, 2).bfloat16().to(dev)
+    res = rnd((nb, m, h, w), 2).bfloat16().to(dev) if "res" in mode else None
+    wt = (rnd((m, k, 1, 1), 3) * k ** -0.5).to(dev)
+    st = None
+    if "pro" in mode:
+        st = ops.BnStats(k, dev)
+        st.scale.copy_(rnd((k,), 5) + 1.5)
+        st.shift.copy_(rnd((k,), 6))
+    out = ops.c1rb_fwd(wt, False, x, st, res, "stats" in mode)
+    y, sr = out if "stats" in mode else (out, None)
+    Wb, Wtb = ops.c1b_weights(wt)
+    y_b = ops.c1b_fwd(Wb, x, st, res)
+    # same products, same operand roundings; the fp32 accumulation ORDER differs, so a result may land on the other side of a
+    # bf16 rounding boundary: at most one ulp, on a small fraction of the elements
+    a, b = y.float(), y_b.float()
+    assert bool(((a - b).abs() <= 2.0 ** -7 * b.abs().clamp_min(1e-30) + 1e-6).all()) and float((a != b).float().mean()) < 5e-3
+    xa = x.float()
+    if st is not None:
+        xa = torch.nn.functional.gelu(xa * st.scale.view(1, -1, 1, 1) + st.shift.view(1, -1, 1, 1)).bfloat16().float()
+    ref = torch.einsum("mk,nkhw->nmhw", wt.view(m, k).bfloat16().float().cpu().double(), xa.cpu().double())
+    if res is not None:
+        ref = ref + res.float().cpu().double()
+    assert ulp_close(y.cpu(), ref.float(), 2e-2, atol=2e-5 * float(ref.abs().max()))
+    if sr is not None:
+        g, bb = torch.ones(m, device=dev), torch.zeros(m, device=dev)
+        s_a = ops.bn_stats_from_rows(sr, tuple(y.shape), g, bb, None, None)
+        s_b = ops.bn_stats_train(y, g, bb, torch.zeros(m, device=dev), torch.ones(m, device=dev))
+        assert relerr(s_a.mean, s_b.mean) < 2e-6 and relerr(s_a.invstd, s_b.invstd) < 2e-6
+    # the data gradient: the transposed weight with the SAME fp32 tensor (a (Cout = k, Cin = m) weight gives an (m x k) product)
+    wt_t = (rnd((k, m, 1, 1), 7) * k ** -0.5).to(dev)
+    dx = ops.c1rb_fwd(wt_t, True, x)
+    dx_b = ops.c1b_fwd(ops.c1b_weights(wt_t)[1], x)
+    a, b = dx.float(), dx_b.float()
+    assert bool(((a - b).abs() <= 2.0 ** -7 * b.abs().clamp_min(1e-30) + 1e-6).all()) and float((a != b).float().mean()) < 5e-3
+    # repeat launches are bit-identical
+    assert torch.equal(ops.c1rb_fwd(wt, False, x, st, res), y)

@@ -164,14 +164,17 @@ def main():
             W3, W3t = ops.c1b_weights(w3)
             fl = 2 * n * c * mid
             by1, by3 = 2 * n * (c + mid), 2 * n * (c + mid) + 2 * n * c
-            rows = [(f"fwd  {c}->{mid} bnact gemm.hip", lambda: ops.conv1x1_fwd_bnact(x, st, w1), fl, by1, "fwd1_gemm"),
-                    (f"fwd  {c}->{mid} bnact c1b", lambda: ops.c1b_fwd(W1, x, st), fl, by1, "fwd1_c1b"),
-                    (f"dgrad {c}->{mid} (da3) gemm.hip", lambda: ops.conv1x1_bwd_data(x, w3), fl, by1, "dgrad3_gemm"),
+            rows = [(f"fwd  {c}->{mid} bnact+stats c1b", lambda: ops.c1b_fwd(W1, x, st, None, True), fl, by1, "fwd1_c1b"),
                     (f"dgrad {c}->{mid} (da3) c1b", lambda: ops.c1b_fwd(W3t, x), fl, by1, "dgrad3_c1b"),
-                    (f"fwd  {mid}->{c} +res gemm.hip", lambda: ops.conv1x1_fwd(t2, w3, None, x), fl, by3, "fwd3_gemm"),
-                    (f"fwd  {mid}->{c} +res c1b", lambda: ops.c1b_fwd(W3, t2, None, x), fl, by3, "fwd3_c1b"),
-                    (f"dgrad {mid}->{c} (da1) gemm.hip", lambda: ops.conv1x1_bwd_data(t2, w1), fl, by1, "dgrad1_gemm"),
+                    (f"fwd  {mid}->{c} +res+stats c1b", lambda: ops.c1b_fwd(W3, t2, None, x, True), fl, by3, "fwd3_c1b"),
                     (f"dgrad {mid}->{c} (da1) c1b", lambda: ops.c1b_fwd(W1t, t2), fl, by1, "dgrad1_c1b")]
+            if ops.c1rb_supported(mid, c, h * h):
+                rows += [(f"fwd  {c}->{mid} bnact+stats c1rb", lambda: ops.c1rb_fwd(w1, False, x, st, None, True), fl, by1, "fwd1_c1rb"),
+                         (f"fwd  {c}->{mid} plain c1rb", lambda: ops.c1rb_fwd(w1, False, x), fl, by1, "fwd1_plain_c1rb"),
+                         (f"dgrad {c}->{mid} (da3) c1rb", lambda: ops.c1rb_fwd(w3, True, x), fl, by1, "dgrad3_c1rb")]
+            if ops.c1rb_supported(c, mid, h * h):
+                rows += [(f"fwd  {mid}->{c} +res+stats c1rb", lambda: ops.c1rb_fwd(w3, False, t2, None, x, True), fl, by3, "fwd3_c1rb"),
+                         (f"dgrad {mid}->{c} (da1) c1rb", lambda: ops.c1rb_fwd(w1, True, t2), fl, by1, "dgrad1_c1rb")]
             for tag, fn, f_, b2, key in rows:
                 ms = timeit(fn, R)
                 report(f"c1b @{h} {tag}", ms, f_, b2)

@@ -9,7 +9,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -fno-gpu-sanitize -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -Wno-unused-result"
 mkdir -p build_asan
 pids=()
-for f in api gemm dconv norm_act ssim transformer wino forecast vit c1conv splitgemm c1b c1w g3b c1r; do
+for f in api gemm dconv norm_act ssim transformer wino forecast vit c1conv splitgemm c1b c1w g3b c1r c1rb; do
   if [ ! -f build_asan/$f.o ] || [ $f.hip -nt build_asan/$f.o ] || [ common.h -nt build_asan/$f.o ] || [ ../../include/wfae.h -nt build_asan/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o build_asan/$f.o &
     pids+=($!)

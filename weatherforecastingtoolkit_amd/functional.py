@@ -551,11 +551,22 @@ def _mk_stats(mean, invstd, scale, shift):
     return st
 
 
+def _b16(w, plane, transposed, x, st=None, res=None, stats=False, label="wfae_c1b_fwd"):
+    """a Bottleneck 1x1 product on bf16-stored tensors: csrc/c1rb.hip (register-direct, reads the fp32 weight) where it
+    serves the shape, else csrc/c1b.hip with the prepared bf16 plane"""
+    m = w.shape[1] if transposed else w.shape[0]
+    if ops.c1rb_supported(m, x.shape[1], x.shape[2] * x.shape[3]):
+        return ops.c1rb_fwd(w, transposed, x, st, res, stats, label)
+    return ops.c1b_fwd(plane, x, st, res, stats, label)
+
+
 def _dgrad_bn(dt, w, Wt, x, gamma, st, dgamma, dbeta, res, training):
     """dx of  conv1x1(gelu(bn(x)), w)  given dt = dL/d(conv output): the data gradient dA = W^T dT followed by the
-    BatchNorm + GELU backward at x (+ res, the residual-branch gradient).  Wt: the bf16 plane of w^T when the tensors
-    are bf16-stored (csrc/c1b.hip), else an empty tensor (fp32 storage: wfae_conv1x1_bwd_data)."""
-    if Wt is not None and Wt.numel() > 0 and Wt.dtype == ops.BF16:
+    BatchNorm + GELU backward at x (+ res, the residual-branch gradient).  bf16-stored tensors: csrc/c1rb.hip, or csrc/c1b.hip
+    with Wt, the bf16 plane of w^T; fp32 storage (Wt empty): wfae_conv1x1_bwd_data."""
+    if dt.dtype == ops.BF16 and ops.c1rb_supported(w.shape[1], dt.shape[1], dt.shape[2] * dt.shape[3]):
+        da = ops.c1rb_fwd(w, True, dt, label="wfae_c1b_dgrad")
+    elif Wt is not None and Wt.numel() > 0 and Wt.dtype == ops.BF16:
         da = ops.c1b_fwd(Wt, dt, label="wfae_c1b_dgrad")
     else:
         da = ops.conv1x1_bwd_data(dt, w)
@@ -585,16 +596,18 @@ class BottleneckFn(Function):
         # gradient; (M = C, K = mid): the C/4 -> C forward and the C -> C/4 data gradient — with one bf16 weight plane each way,
         # written once here and reused in backward
         W1p = W3p = (None, None)
-        cb1 = x.dtype == ops.BF16 and ops.c1b_supported(mid, C, hw)
-        cb3 = x.dtype == ops.BF16 and ops.c1b_supported(C, mid, hw)
-        if cb1 or cb3:
+        bf = x.dtype == ops.BF16
+        rb1, rb3 = bf and ops.c1rb_supported(mid, C, hw), bf and ops.c1rb_supported(C, mid, hw)   # register-direct (csrc/c1rb.hip)
+        cb1 = rb1 or (bf and ops.c1b_supported(mid, C, hw))
+        cb3 = rb3 or (bf and ops.c1b_supported(C, mid, hw))
+        if (cb1 and not rb1) or (cb3 and not rb3):      # c1b.hip takes prepared bf16 planes; c1rb.hip reads the fp32 weight itself
             W1p, W3p = ops.c1b_weights(w1), ops.c1b_weights(w3)
         st1 = _bn_stats_rows(x_stats if (fuse or isinstance(x_stats, ops.StatParts)) else None, x, bn1, training)
         fused1 = FUSE_A1 and x.shape[1] <= FUSE_A1_MAXC and ops.conv1x1_bnact_supported(x, w1.shape[0])
         a1 = None if fused1 else ops.bn_act_fwd(x, st1, 1)
         if cb1:
             src, pro = (x, st1) if fused1 else (a1, None)
-            t1, sr2 = ops.c1b_fwd(W1p[0], src, pro, None, True) if fuse else (ops.c1b_fwd(W1p[0], src, pro), None)
+            t1, sr2 = _b16(w1, W1p[0], False, src, pro, None, True) if fuse else (_b16(w1, W1p[0], False, src, pro), None)
         elif fused1:
             t1, sr2 = ops.conv1x1_fwd_bnact(x, st1, w1, stats=True) if fuse else (ops.conv1x1_fwd_bnact(x, st1, w1), None)
         else:
@@ -606,21 +619,21 @@ class BottleneckFn(Function):
         if FUSE_A3 and w3.shape[0] <= FUSE_A3_MAXC and ops.conv1x1_bnact_supported(t2, w3.shape[0]):
             a3 = None
             if cb3:
-                y, mod._out_stats = ops.c1b_fwd(W3p[0], t2, st3, x, True) if emit else (ops.c1b_fwd(W3p[0], t2, st3, x), None)
+                y, mod._out_stats = _b16(w3, W3p[0], False, t2, st3, x, True) if emit else (_b16(w3, W3p[0], False, t2, st3, x), None)
             else:
                 y, mod._out_stats = ops.conv1x1_fwd_bnact(t2, st3, w3, None, x, stats=True) if emit else \
                     (ops.conv1x1_fwd_bnact(t2, st3, w3, None, x), None)
         else:
             a3 = ops.bn_act_fwd(t2, st3, 1)
             if cb3:
-                y, mod._out_stats = ops.c1b_fwd(W3p[0], a3, None, x, True) if emit else (ops.c1b_fwd(W3p[0], a3, None, x), None)
+                y, mod._out_stats = _b16(w3, W3p[0], False, a3, None, x, True) if emit else (_b16(w3, W3p[0], False, a3, None, x), None)
             else:
                 y, mod._out_stats = ops.conv1x1_fwd_stats(a3, w3, None, x) if emit else (ops.conv1x1_fwd(a3, w3, None, x), None)
         ctx.save_for_backward(x, _opt(a1), t1, a2, t2, _opt(a3), g1, w1, g2, wg, g3, w3,
                               st1.mean, st1.invstd, st1.scale, st1.shift,
                               st2.mean, st2.invstd, st2.scale, st2.shift,
                               st3.mean, st3.invstd, st3.scale, st3.shift,
-                              _opt(W1p[1] if cb3 else None), _opt(W3p[1] if cb1 else None))
+                              _opt(W1p[1] if (cb3 and not rb3) else None), _opt(W3p[1] if (cb1 and not rb1) else None))
         ctx.training = training
         ctx.groups = groups
         ctx.betas = (b1, b2, b3)

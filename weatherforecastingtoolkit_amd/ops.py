@@ -258,6 +258,47 @@ def _c1r(w, transposed, x, st, res, stats, label):
     return y, StatRows(part, rows.value)
 
 
+# csrc/c1rb.hip: the same register-direct product on bf16-stored tensors ('medium'): every Bottleneck stage with HW % 128 == 0
+_C1RB = True   # A/B through set_c1rb()
+
+
+def set_c1rb(on):
+    """A/B switch: the bf16 1x1 forward / data gradient on csrc/c1rb.hip (register-direct) or on csrc/c1b.hip (LDS-tiled)"""
+    global _C1RB
+    _C1RB = bool(on)
+
+
+def c1rb_supported(m, k, hw):
+    return _C1RB and _lib.load().wfae_get_matmul_precision() == 1 and bool(_lib.load().wfae_c1rb_supported(int(m), int(k), int(hw)))
+
+
+def c1rb_fwd(w, transposed, x, st=None, res=None, stats=False, label="wfae_c1b_fwd"):
+    """y (bf16) = A f(x) (+ res) on bf16-stored activations: A = w (Cout, Cin) or, transposed, w^T (the data gradient); the
+    fp32 weight itself is passed (the kernel rounds it into its LDS image) -> y | (y, StatRows)"""
+    import ctypes
+    sfx, _ = _chka(x, res)
+    _chk(w)
+    if not sfx:
+        raise _lib.WfaeError("c1rb_fwd: bf16-stored activations")
+    nb, k, h, wd = x.shape
+    cout, cin = w.shape[0], w.shape[1]
+    m, sm, sk = (cin, 1, cin) if transposed else (cout, cin, 1)
+    y = torch.empty((nb, m, h, wd), dtype=BF16, device=x.device)
+    fl = 2 * nb * h * wd * k * m
+    by = 2 * nb * h * wd * (k + m) + 4 * k * m + (0 if res is None else 2 * nb * h * wd * m)
+    ps, ph = (None, None) if st is None else (_p(st.scale), _p(st.shift))
+    if not stats:
+        _call("wfae_c1rb_fwd", fl, by, _p(w), sm, sk, _p(x), ps, ph, _p(res), _p(y), nb, k, m, h * wd, None, 0, None, _stream(),
+              label=label, peak=PEAK_BF16_MFMA)
+        return y
+    rows_n = int(_lib.load().wfae_c1rb_stat_rows(m, k, nb, h * wd))
+    part = torch.empty(2 * rows_n * m, dtype=torch.float64, device=x.device)
+    rows = ctypes.c_int(0)
+    _call("wfae_c1rb_fwd", fl, by, _p(w), sm, sk, _p(x), ps, ph, _p(res), _p(y), nb, k, m, h * wd, part.data_ptr(), part.numel(),
+          ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream(), label=label, peak=PEAK_BF16_MFMA)
+    return y, StatRows(part, rows.value)
+
+
 # ----------------------------------------------------------------- 1x1 conv
 def _conv1x1_fwd_bf16(x, st, w, bias, res, stats):
     """the merged bf16-storage entry point: optional BatchNorm + GELU prologue (st), optional BatchNorm sums (stats)"""

@@ -555,7 +555,7 @@ def _b16(w, plane, transposed, x, st=None, res=None, stats=False, label="wfae_c1
     """a Bottleneck 1x1 product on bf16-stored tensors: csrc/c1rb.hip (register-direct, reads the fp32 weight) where it
     serves the shape, else csrc/c1b.hip with the prepared bf16 plane"""
     m = w.shape[1] if transposed else w.shape[0]
-    if ops.c1rb_supported(m, x.shape[1], x.shape[2] * x.shape[3]):
+    if ops.c1rb_take(m, x.shape[1], x.shape[2] * x.shape[3], st is not None):
         return ops.c1rb_fwd(w, transposed, x, st, res, stats, label)
     return ops.c1b_fwd(plane, x, st, res, stats, label)
 
@@ -600,6 +600,8 @@ class BottleneckFn(Function):
         rb1, rb3 = bf and ops.c1rb_supported(mid, C, hw), bf and ops.c1rb_supported(C, mid, hw)   # register-direct (csrc/c1rb.hip)
         cb1 = rb1 or (bf and ops.c1b_supported(mid, C, hw))
         cb3 = rb3 or (bf and ops.c1b_supported(C, mid, hw))
+        if C >= 512:
+            rb1 = False        # the sliced C -> C/4 products: forward (prologue) on c1b, so its plane pair is needed
         if (cb1 and not rb1) or (cb3 and not rb3):      # c1b.hip takes prepared bf16 planes; c1rb.hip reads the fp32 weight itself
             W1p, W3p = ops.c1b_weights(w1), ops.c1b_weights(w3)
         st1 = _bn_stats_rows(x_stats if (fuse or isinstance(x_stats, ops.StatParts)) else None, x, bn1, training)

@@ -272,6 +272,15 @@ def c1rb_supported(m, k, hw):
     return _C1RB and _lib.load().wfae_get_matmul_precision() == 1 and bool(_lib.load().wfae_c1rb_supported(int(m), int(k), int(hw)))
 
 
+def c1rb_take(m, k, hw, pro):
+    """route this bf16 product to c1rb?  Measured (profiles/r04_kbench_c1rb_vs_c1b.txt): it wins or ties every form except
+    the M-SLICED narrowing products (C >= 512: (128, 512), (256, 1024)) with the BatchNorm + GELU prologue — every slice
+    evaluates the activation of the whole operand again (0.163 -> 0.462 ms); those stay on c1b."""
+    if pro and m < k and k >= 512:
+        return False
+    return c1rb_supported(m, k, hw)
+
+
 def c1rb_fwd(w, transposed, x, st=None, res=None, stats=False, label="wfae_c1b_fwd"):
     """y (bf16) = A f(x) (+ res) on bf16-stored activations: A = w (Cout, Cin) or, transposed, w^T (the data gradient); the
     fp32 weight itself is passed (the kernel rounds it into its LDS image) -> y | (y, StatRows)"""

@@ -146,6 +146,17 @@ int wfae_c1r_stat_rows(int M, int K, int NB, int HW);
 int wfae_c1r_fwd(const float* w, int64_t w_sm, int64_t w_sk, const float* x, const float* pro_scale, const float* pro_shift,
                  const float* res, float* y, int NB, int K, int M, int HW, double* stat_part, int64_t stat_capacity,
                  int* stat_rows, wfae_stream_t stream);
+/* The widening DATA GRADIENT of the C <= 256 stages with the reductions of the BatchNorm + GELU backward of the layer in front
+ * taken in its epilogue (csrc/c1r.hip, ABI 103): da (NB,M,HW) = A dt as wfae_c1r_fwd, and part = sum dU [rows][M] then sum dU xhat
+ * [rows][M] in fp64, dU = da * gelu'(x * bn_scale + bn_shift), xhat = (x - save_mean) * save_invstd, x (NB,M,HW) the BatchNorm
+ * input — phase 1 of wfae_bn_act_bwd without its pass over (da, x).  Finish with wfae_bn_act_bwd_from_rows (dgamma, dbeta and the
+ * coefficients at the head of ws), then wfae_bn_act_bwd(phases = 2, same ws).  rows <= wfae_c1r_stat_rows(M, K, NB, HW). */
+int wfae_c1r_bnred_supported(int M, int K, int HW);
+int wfae_c1r_bnred(const float* w, int64_t w_sm, int64_t w_sk, const float* dt, const float* x, const float* bn_scale,
+                   const float* bn_shift, const float* save_mean, const float* save_invstd, float* da, int NB, int K, int M, int HW,
+                   double* part, int64_t part_capacity, int* part_rows, wfae_stream_t stream);
+int wfae_bn_act_bwd_from_rows(const double* part, int rows, int C, float* dgamma, float* dbeta, int accumulate, void* ws,
+                              size_t ws_bytes, wfae_stream_t stream);
 /* The same register-direct product on bf16-STORED tensors (csrc/c1rb.hip, ABI 103; needs WFAE_PRECISION_BF16): bf16 pieces of
  * eight pixels per lane go HBM -> registers -> v_mfma_f32_16x16x32_bf16 with four byte-permutes per fragment and no other
  * arithmetic, the weight as one bf16 plane rounded by the kernel itself, fp32 accumulation, one rounding of the result.  Serves

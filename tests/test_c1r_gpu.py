@@ -120,3 +120,34 @@ def test_c1r_full_size_stage_shapes(ops, dev):
                 assert d < 5e-6, (c, m, k, i, d)      # every element, the last tile of the last image included
                 del y_new, y_old
             del x, r
+
+
+@pytest.mark.parametrize("m,k", [(128, 32), (256, 64)])
+@pytest.mark.parametrize("nb,h,w,res", [(2, 16, 16, False), (5, 16, 24, True), (40, 16, 16, True)])
+def test_c1r_bnred_epilogue_equals_the_reduce_pass(ops, dev, m, k, nb, h, w, res):
+    """wfae_c1r_bnred: the data gradient dA = W^T dT of the C -> C/4 convolution with phase 1 of the BatchNorm + GELU backward of the
+    layer in front (sum dU, sum dU xhat) in its epilogue, finished by wfae_bn_act_bwd_from_rows + phase 2 — against the plain
+    sequence data gradient -> wfae_bn_act_bwd (reduce pass + dx pass) on the same tensors: dA bit-identical to the plain c1r
+    data gradient, dgamma / dbeta to fp64-sum accuracy, dx to the rounding of its two coefficients"""
+    assert ops.c1r_bnred_supported(m, k, h * w)
+    dt = rnd((nb, k, h, w), 1).to(dev)
+    x = rnd((nb, m, h, w), 2, -2.0, 2.0).to(dev)
+    wt = rnd((k, m, 1, 1), 3, -0.3, 0.3).to(dev)           # the (Cout = k, Cin = m) weight of the C -> C/4 convolution
+    r = rnd((nb, m, h, w), 4).to(dev) if res else None
+    gamma = rnd((m,), 5, 0.5, 1.5).to(dev)
+    st = ops.bn_stats_train(x, gamma, rnd((m,), 6).to(dev), torch.zeros(m, device=dev), torch.ones(m, device=dev))
+    da_ref = ops.conv1x1_bwd_data(dt, wt)
+    dg0, db0 = torch.empty(m, device=dev), torch.empty(m, device=dev)
+    dx_ref = ops.bn_act_bwd(da_ref, x, gamma, st, dg0, db0, r, 1, True)
+    da, sr = ops.c1r_bnred(wt, dt, x, st)
+    assert torch.equal(da, da_ref)
+    dg1, db1 = torch.empty(m, device=dev), torch.empty(m, device=dev)
+    ops.bn_act_bwd_from_rows(sr, m, dg1, db1)
+    dx = ops.bn_act_bwd_dx(da, x, gamma, st, r, 1, True)
+    assert relerr(dg1, dg0) < 1e-6 and relerr(db1, db0) < 1e-6
+    assert relerr(dx, dx_ref) < 1e-6
+    # accumulate form of the finalize, repeatability
+    ops.bn_act_bwd_from_rows(sr, m, dg1, db1, accumulate=True)
+    assert relerr(dg1, 2 * dg0) < 1e-6
+    da2, sr2 = ops.c1r_bnred(wt, dt, x, st)
+    assert torch.equal(da2, da) and torch.equal(sr2.part, sr.part)

@@ -148,6 +148,28 @@ def main():
                     acc(key + ("_c1r" if on else "_old"), ms, mult)
             ops.set_c1r(True)
             del x, t2, w1, w3
+    if "bnseq" in only:
+        # first BatchNorm of a Bottleneck, backward: data gradient of the C -> C/4 convolution + BatchNorm/GELU backward (+ residual
+        # gradient), with the reduce pass separate or in the c1r epilogue (ops.set_c1r_bnred)
+        from weatherforecastingtoolkit_amd import functional as Fn
+        for c, h in [(256, S // 2), (128, S)]:
+            mult = 4 if c == 128 else 8
+            mid = c // 4
+            n = B * h * h
+            x, dt1, dy = rnd(B, c, h, h), rnd(B, mid, h, h), rnd(B, c, h, h)
+            w1 = rnd(mid, c, 1, 1) * c ** -0.5
+            g, b_, rm, rv = torch.ones(c, device=dev), torch.zeros(c, device=dev), torch.zeros(c, device=dev), torch.ones(c, device=dev)
+            st = ops.bn_stats_train(x, g, b_, rm, rv)
+            dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
+            for rep in range(2):
+                for on in (False, True):
+                    ops.set_c1r_bnred(on)
+                    ms = timeit(lambda: Fn._dgrad_bn(dt1, w1, None, x, g, st, dg, db, dy, True), R)
+                    report(f"bnseq C={c} @{h} dgrad + bn1 bwd, reduce {'in the c1r epilogue' if on else 'as a pass'} rep{rep}", ms,
+                           2 * n * c * mid, 4 * n * (mid + c) + 4 * n * (2 * c if not on else c) + 4 * n * 4 * c)
+                    acc("bnseq_" + ("fused" if on else "separate"), ms / 2, mult)
+            ops.set_c1r_bnred(True)
+            del x, dt1, dy
     if "c1b" in only:
         # bf16 storage ('medium'): csrc/c1b.hip against gemm.hip's bf16-storage kernels, per Bottleneck stage
         ops.set_float32_matmul_precision("medium")

@@ -49,6 +49,8 @@ struct C1RP {
   int HW;                    // % 64 == 0: a 64-pixel tile never leaves its image
   int tpi;                   // tiles per image
   int ntiles;
+  const float* bn_x;         // BNR: the BatchNorm input of the layer in FRONT of this convolution, [NB][M][HW] (the shape of Y)
+  const float* bn_tab[4];    // BNR: folded scale, shift, batch mean, invstd of that BatchNorm, [M] each
   int m_total;               // rows of Y: nslices * M (M = the 16 MT rows one block owns)
   int nslices;               // M-slices: the blocks b, b + 8, .. of one XCD that share a tile sequence split the rows
 };
@@ -81,7 +83,11 @@ __device__ __forceinline__ Planes3 split_pair(float a, float b) {
 
 // NBUF: chunk buffers of the narrowing ring; RD: residual-row buffers of the widening ring
 // RESN: a streaming (one-pass) kernel that carries a residual
-template <int KCH, int MT, int MG, bool PRO, bool STATS, int RWAVES = 8, int NBUF = 2, int RD = 2, bool RESN = false>
+// BNR (B-resident kernels, data gradients): the result is dA, the gradient at the OUTPUT of a BatchNorm + GELU; the reductions of
+// that layer's backward pass — sum dU and sum dU xhat per channel, dU = dA gelu'(x a + b), xhat = (x - mu) is: phase 1 of
+// wfae_bn_act_bwd, bn_act_bwd_reduce_kernel's arithmetic — are taken here while dA is in registers (x travels through the
+// residual ring) and leave as the partial rows of STATS; the separate pass over (dA, x) disappears.
+template <int KCH, int MT, int MG, bool PRO, bool STATS, int RWAVES = 8, int NBUF = 2, int RD = 2, bool RESN = false, bool BNR = false>
 __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel(C1RP p) {
   constexpr int RNT = 64 * RWAVES;
   constexpr int K = 32 * KCH, M = 16 * MT, NPASS = MT / MG;
@@ -90,10 +96,13 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
   constexpr int PLANE_B = M * 64;                  // one plane of one 32-deep chunk: M rows x 64 bytes
   constexpr int A_B = KCH * 3 * PLANE_B;
   constexpr int PRO_B = PRO ? 2 * K * 4 : 0;
+  static_assert(!BNR || (STATS && !PRO && !RESN && MT > MG), "BNR: a B-resident data-gradient kernel; its sums use the STATS rows");
   constexpr int ST_B = STATS ? RWAVES * 2 * M * 8 : 0;
-  static_assert(A_B + PRO_B + ST_B <= 160 * 1024, "LDS");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[A_B + PRO_B + ST_B];
+  constexpr int BNT_B = BNR ? 4 * M * 4 : 0;
+  static_assert(A_B + PRO_B + ST_B + BNT_B <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[A_B + PRO_B + ST_B + BNT_B];
   float* const lsc = reinterpret_cast<float*>(smem + A_B);
+  float* const lbn = reinterpret_cast<float*>(smem + A_B + PRO_B + ST_B);   // BNR: [4][M]
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int n16 = lane & 15, kg = lane >> 4;
@@ -133,6 +142,9 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
     }
     if constexpr (STATS) {
       for (int i = lane; i < 2 * M; i += 64) lst[i] = 0.0;
+    }
+    if constexpr (BNR) {
+      for (int i = t; i < 4 * M; i += RNT) lbn[i] = p.bn_tab[i / M][m_off + i % M];
     }
   }
   __syncthreads();
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
   auto split_chunk = [&](f32x4 (&r)[8], u32x4 (&b)[4][3], int c) { split_part(r, b, c, I0{}, I4{}); };
   auto multiply = [&](f32x4 (&acc)[MG][4], const u32x4 (&b)[4][3], int c, int a_pass_off) { multiply_part(acc, b, c, a_pass_off, I0{}, I4{}); };
   auto load_res = [&](f32x4 (&rv)[MG][4], int tl, int mt0) {
-    const char* rb = reinterpret_cast<const char*>(p.res) + tile_off(tl, p.m_total) + (long)(m_off + 16 * mt0) * rowB;
+    const char* rb = reinterpret_cast<const char*>(BNR ? p.bn_x : p.res) + tile_off(tl, p.m_total) + (long)(m_off + 16 * mt0) * rowB;
 #pragma unroll
     for (int mt = 0; mt < MG; ++mt)
 #pragma unroll
@@ -233,9 +245,22 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 v = {acc[mt][0][q], acc[mt][1][q], acc[mt][2][q], acc[mt][3][q]};
-        if (with_res) v += rv[mt][q];
+        if (!BNR && with_res) v += rv[mt][q];
         *reinterpret_cast<f32x4*>(yb + (16 * mt + q) * rowB + lane_out) = v;
-        if constexpr (STATS) {   // fp32 sums of four enter the fp64 reduction, as in chan_reduce_kernel
+        if constexpr (BNR) {   // bn_act_bwd_reduce_kernel's quad(): dU = dA gelu'(x a + b), sums of dU and dU xhat
+          const int ml = 16 * (mt0 + mt) + 4 * kg + q;
+          const float a = lbn[ml], b = lbn[M + ml], mu = lbn[2 * M + ml], is = lbn[3 * M + ml];
+          const f32x4 xv = rv[mt][q];
+          const float d0 = v.x * gelu_grad_f(fmaf(xv.x, a, b)), d1 = v.y * gelu_grad_f(fmaf(xv.y, a, b));
+          const float d2 = v.z * gelu_grad_f(fmaf(xv.z, a, b)), d3 = v.w * gelu_grad_f(fmaf(xv.w, a, b));
+          const float h0 = (xv.x - mu) * is, h1 = (xv.y - mu) * is, h2 = (xv.z - mu) * is, h3 = (xv.w - mu) * is;
+          const double e1 = row_sum16((double)((d0 + d1) + (d2 + d3)));
+          const double e2 = row_sum16((double)(fmaf(d0, h0, d1 * h1) + fmaf(d2, h2, d3 * h3)));
+          if (n16 == 15) {
+            lst[ml] += e1;
+            lst[M + ml] += e2;
+          }
+        } else if constexpr (STATS) {   // fp32 sums of four enter the fp64 reduction, as in chan_reduce_kernel
           const float s1 = (v.x + v.y) + (v.z + v.w);
           const float s2 = fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);
           const double d1 = row_sum16((double)s1), d2 = row_sum16((double)s2);
@@ -248,7 +273,7 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
       }
   };
 
-  const bool with_res = p.res != nullptr;
+  const bool with_res = BNR || p.res != nullptr;
   if (tile < p.ntiles) {
     if constexpr (!BRES) {
       // ---- narrowing: stream the K chunks through a ring of NBUF register buffers, NBUF - 1 chunks of loads in flight ahead of
@@ -406,6 +431,13 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 
 }  // namespace
 
+namespace {
+template <int KCH, int MT, int NW, int RD>
+void launch_bnr(const C1RP& p, int grid, hipStream_t st) {
+  hipLaunchKernelGGL((c1r_kernel<KCH, MT, 1, false, true, NW, 2, RD, false, true>), dim3((unsigned)grid), dim3(64 * NW), 0, st, p);
+}
+}  // namespace
+
 extern "C" {
 
 int wfae_c1r_supported(int M, int K, int HW) {
@@ -461,6 +493,43 @@ int wfae_c1r_fwd(const float* w, int64_t w_sm, int64_t w_sk, const float* x, con
     default: launch_shape<8, 4, 4, 4, 4, 2, true>(p, pro, stats, grid, st); break;
   }
   return check_launch("c1r_fwd");
+}
+
+int wfae_c1r_bnred_supported(int M, int K, int HW) {
+  const int sid = shape_of(M, K).sid;
+  return ((sid == 2 || sid == 3) && HW > 0 && HW % 64 == 0 && wfae::split_gemm_enabled()) ? 1 : 0;
+}
+
+int wfae_c1r_bnred(const float* w, int64_t w_sm, int64_t w_sk, const float* dt, const float* x, const float* bn_scale,
+                   const float* bn_shift, const float* save_mean, const float* save_invstd, float* da, int NB, int K, int M, int HW,
+                   double* part, int64_t part_capacity, int* part_rows, wfae_stream_t stream) {
+  WFAE_REQUIRE(w && dt && x && bn_scale && bn_shift && save_mean && save_invstd && da && part && part_rows, WFAE_ERR_NULL_POINTER,
+               "c1r_bnred: null pointer");
+  WFAE_REQUIRE(NB > 0 && K > 0 && M > 0 && HW > 0 && (int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "c1r_bnred: bad shape");
+  const ShapeInfo si = shape_of(M, K);
+  WFAE_REQUIRE(wfae_c1r_bnred_supported(M, K, HW), WFAE_ERR_UNSUPPORTED,
+               "c1r_bnred: serves the widening data gradients (M, K) = (128, 32), (256, 64) with HW %% 64 == 0 at fp32 precision with "
+               "the split GEMMs on (M %d, K %d, HW %d)", M, K, HW);
+  WFAE_REQUIRE((w_sm == K && w_sk == 1) || (w_sm == 1 && w_sk == M), WFAE_ERR_BAD_SHAPE,
+               "c1r_bnred: the weight is (M, K) row-major (strides K, 1) or its transpose (strides 1, M)");
+  WFAE_REQUIRE(al16(dt) && al16(x) && al16(da), WFAE_ERR_UNSUPPORTED, "c1r_bnred: tensors must be 16-byte aligned");
+  C1RP p = {};
+  p.W = w; p.w_sm = w_sm; p.w_sk = w_sk;
+  p.X = dt; p.Y = da; p.bn_x = x;
+  p.bn_tab[0] = bn_scale; p.bn_tab[1] = bn_shift; p.bn_tab[2] = save_mean; p.bn_tab[3] = save_invstd;
+  p.HW = HW; p.tpi = HW / 64; p.ntiles = NB * p.tpi;
+  p.m_total = M; p.nslices = 1;
+  const int grid = grid_for(p.ntiles, si);
+  const int rows = grid * si.waves;
+  WFAE_REQUIRE(part_capacity >= 2 * (int64_t)rows * M, WFAE_ERR_WORKSPACE, "c1r_bnred: part holds %lld doubles, needs %lld",
+               (long long)part_capacity, (long long)(2 * (int64_t)rows * M));
+  *part_rows = rows;
+  p.part0 = part;
+  p.part1 = part + (long)rows * M;
+  hipStream_t st = (hipStream_t)stream;
+  if (si.sid == 2) launch_bnr<1, 8, 4, 8>(p, grid, st);
+  else launch_bnr<2, 16, 4, 2>(p, grid, st);
+  return check_launch("c1r_bnred");
 }
 
 }  // extern "C"

@@ -919,6 +919,30 @@ int wfae_bn_stats_from_parts(const double* part, int splits, int NB, int C, int 
   return check_launch("bn_finalize_parts");
 }
 
+int wfae_bn_act_bwd_from_rows(const double* part_rows, int rows, int C, float* dgamma, float* dbeta, int accumulate, void* ws,
+                              size_t ws_bytes, wfae_stream_t stream) {
+  WFAE_REQUIRE(part_rows && ws, WFAE_ERR_NULL_POINTER, "bn_act_bwd_from_rows: null pointer");
+  WFAE_REQUIRE(rows > 0 && C > 0, WFAE_ERR_BAD_SHAPE, "bn_act_bwd_from_rows: bad shape");
+  // the workspace layout of wfae_bn_act_bwd: coef[2C] floats (16-byte aligned), then fp64 partials part[(c * splits + s) * 2]
+  const size_t coef_bytes = ((size_t)2 * C * sizeof(float) + 15) / 16 * 16;
+  int splits = (int)((1024l * 64 + C - 1) / C);
+  if (splits > rows / 8) splits = rows / 8;
+  if (splits < 1) splits = 1;
+  if (splits > 1024) splits = 1024;
+  WFAE_REQUIRE(ws_bytes >= coef_bytes + sizeof(double) * 2 * (size_t)C * splits, WFAE_ERR_WORKSPACE,
+               "bn_act_bwd_from_rows: workspace too small");
+  float* coef = (float*)ws;
+  double* part = (double*)((char*)ws + coef_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(stat_rows_reduce_kernel, dim3(cdiv(C, 64), splits), dim3(256), 0, st, part_rows, part_rows + (long)rows * C,
+                     part, rows, C, splits);
+  int rc = check_launch("stat_rows_reduce");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, splits, C, dgamma, dbeta,
+                     coef, accumulate);
+  return check_launch("bn_bwd_finalize");
+}
+
 int wfae_bn_act_bwd(const float* dy, const float* x, const float* gamma, const float* scale,
                     const float* shift, const float* save_mean, const float* save_invstd,
                     const float* res, float* dx, float* dgamma, float* dbeta, int NB, int C, int HW,

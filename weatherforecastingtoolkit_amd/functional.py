@@ -564,6 +564,12 @@ def _dgrad_bn(dt, w, Wt, x, gamma, st, dgamma, dbeta, res, training):
     """dx of  conv1x1(gelu(bn(x)), w)  given dt = dL/d(conv output): the data gradient dA = W^T dT followed by the
     BatchNorm + GELU backward at x (+ res, the residual-branch gradient).  bf16-stored tensors: csrc/c1rb.hip, or csrc/c1b.hip
     with Wt, the bf16 plane of w^T; fp32 storage (Wt empty): wfae_conv1x1_bwd_data."""
+    if dt.dtype == torch.float32 and ops.c1r_bnred_supported(w.shape[1], dt.shape[1], dt.shape[2] * dt.shape[3]):
+        # the C <= 256 widening data gradients on csrc/c1r.hip: sum dU / sum dU xhat of the BatchNorm in front ride in the epilogue
+        # (x travels through the kernel's residual ring), the reduce pass over (dA, x) disappears
+        da, sr = ops.c1r_bnred(w, dt, x, st)
+        ops.bn_act_bwd_from_rows(sr, x.shape[1], dgamma, dbeta)
+        return ops.bn_act_bwd_dx(da, x, gamma, st, res, 1, training)
     if dt.dtype == ops.BF16 and ops.c1rb_supported(w.shape[1], dt.shape[1], dt.shape[2] * dt.shape[3]):
         da = ops.c1rb_fwd(w, True, dt, label="wfae_c1b_dgrad")
     elif Wt is not None and Wt.numel() > 0 and Wt.dtype == ops.BF16:

@@ -258,6 +258,60 @@ def _c1r(w, transposed, x, st, res, stats, label):
     return y, StatRows(part, rows.value)
 
 
+_C1R_BNRED = True   # A/B through set_c1r_bnred()
+
+
+def set_c1r_bnred(on):
+    """A/B switch: the reductions of the first BatchNorm's backward pass in the epilogue of the c1r data gradient (C <= 256)"""
+    global _C1R_BNRED
+    _C1R_BNRED = bool(on)
+
+
+def c1r_bnred_supported(m, k, hw):
+    return (_C1R and _C1R_BNRED and _SPLIT_GEMM and _lib.load().wfae_get_matmul_precision() == 0
+            and bool(_lib.load().wfae_c1r_bnred_supported(int(m), int(k), int(hw))))
+
+
+def c1r_bnred(w, dt, x, st):
+    """da = conv1x1_bwd_data(dt, w) on c1r with phase 1 of bn_act_bwd(da, x, ...) taken in the epilogue -> (da, StatRows of
+    (sum dU, sum dU xhat)); finish with bn_act_bwd_from_rows, then bn_act_bwd_dx"""
+    import ctypes
+    _chk(w, dt, x)
+    nb, k, h, wd = dt.shape
+    m = w.shape[1]
+    da = torch.empty((nb, m, h, wd), dtype=torch.float32, device=dt.device)
+    rows_n = int(_lib.load().wfae_c1r_stat_rows(m, k, nb, h * wd))
+    part = torch.empty(2 * rows_n * m, dtype=torch.float64, device=dt.device)
+    rows = ctypes.c_int(0)
+    n = nb * h * wd
+    _call("wfae_c1r_bnred", 2 * n * k * m, 4 * (n * (k + 2 * m) + k * m), _p(w), 1, m, _p(dt), _p(x), _p(st.scale), _p(st.shift),
+          _p(st.mean), _p(st.invstd), _p(da), nb, k, m, h * wd, part.data_ptr(), part.numel(),
+          ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream(), label="wfae_conv1x1_bwd_data", peak=PEAK_BF16_MFMA / 6)
+    return da, StatRows(part, rows.value)
+
+
+def bn_act_bwd_from_rows(sr, c, dgamma, dbeta, accumulate=False):
+    """phase 1 of bn_act_bwd from the partial rows of c1r_bnred: dgamma / dbeta + the coefficients at the head of this stream's
+    workspace, where bn_act_bwd_dx (phase 2) reads them (no other workspace user in between)"""
+    _chk(dgamma, dbeta)
+    ws = workspace()
+    _call("wfae_bn_act_bwd_from_rows", 0, 8 * sr.part.numel(), sr.part.data_ptr(), sr.rows, c, _p(dgamma), _p(dbeta), int(accumulate),
+          ws.data_ptr(), ws.numel(), _stream(), label="wfae_bn_act_bwd[reduce]")
+    return ws
+
+
+def bn_act_bwd_dx(dy, x, gamma, st, res=None, act=1, training=True):
+    """phase 2 of bn_act_bwd alone (after bn_act_bwd_from_rows on the same stream; fp32 storage)"""
+    _chk(dy, x, gamma, res)
+    nb, c, h, wd = x.shape
+    dx = torch.empty_like(x)
+    ws = workspace()
+    _call("wfae_bn_act_bwd", 0, 4 * x.numel() * (4 if res is not None else 3), _p(dy), _p(x), _p(gamma), _p(st.scale), _p(st.shift),
+          _p(st.mean), _p(st.invstd), _p(res), _p(dx), None, None, nb, c, h * wd, act, int(training), 0, 2, ws.data_ptr(),
+          ws.numel(), _stream(), label="wfae_bn_act_bwd[dx]")
+    return dx
+
+
 # csrc/c1rb.hip: the same register-direct product on bf16-stored tensors ('medium'): every Bottleneck stage with HW % 128 == 0
 _C1RB = True   # A/B through set_c1rb()
 

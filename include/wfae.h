@@ -54,9 +54,10 @@ typedef enum {
  *   102  round 3: wfae_c1gemm_* (1x1 convolutions on the bf16 matrix pipe with exact split operands, fused BatchNorm
  *        backward epilogues), the bf16 ACTIVATION STORAGE entry points (*_bf16, *_bf16in, *_bf16out, wfae_convert_*),
  *        wfae_c1b_*, wfae_c1w_*, wfae_g3b_* added; nothing removed.
- *   103  round 4: REMOVED wfae_c1gemm_* (six entry points), wfae_conv1x1_bwd_data_bnred / _bndx and
- *        wfae_bn_act_bwd_from_rows (the fused BatchNorm-backward epilogues: parity-green, never faster — the record is
- *        profiles/r03_kbench_c1_fused_bn_backward.txt); wfae_g3b_fwd no longer serves 8 channels per group.  ADDED
+ *   103  round 4: REMOVED wfae_c1gemm_* (six entry points) and wfae_conv1x1_bwd_data_bnred / _bndx (the fused
+ *        BatchNorm-backward epilogues of the tile-synchronous GEMMs: parity-green, never faster — the record is
+ *        profiles/r03_kbench_c1_fused_bn_backward.txt); wfae_g3b_fwd no longer serves 8 channels per group;
+ *        wfae_bn_act_bwd_from_rows now finishes the partial rows of wfae_c1r_bnred.  ADDED
  *        wfae_c1r_* (register-direct 1x1 convolutions: fp32 tensors, C <= 256 stages and the C >= 512 widening products) and
  *        wfae_c1rb_* (the same on bf16-stored tensors, every stage). */
 int wfae_version(void);

@@ -268,7 +268,7 @@ def test_gan_elementwise(ops, dev):
 
 
 @pytest.mark.parametrize("nb,c,h,w", [(2, 32, 16, 16), (1, 64, 24, 40), (2, 128, 24, 24), (2, 256, 8, 8), (1, 256, 24, 24),
-                                      (3, 32, 7, 9), (1, 64, 33, 35),
+                                      (3, 32, 7, 9), (1, 64, 33, 35), (2, 32, 40, 68), (4, 64, 48, 96), (1, 32, 16, 4), (5, 64, 20, 36),
                                       (1, 256, 48, 48), (2, 256, 16, 32), (2, 128, 32, 16), (1, 128, 96, 96), (3, 256, 16, 16)])
 def test_gconv3x3_blocked(ops, dev, nb, c, h, w):
     """grouped 3x3 (4/8/16/32 channels per group): fwd, dgrad (register-blocked VALU kernel; the MFMA kernel for 16 / 32

@@ -35,8 +35,9 @@ __global__ __launch_bounds__(256) void stream_k(const f4* __restrict__ a, const 
 }
 
 // SEG lanes x 16 B contiguous per row, 64 / SEG rows per wave-instruction, rows `row4` f4 apart; a wave owns a column of tiles
-template <int SEG>
-__global__ __launch_bounds__(256) void rows_k(const f4* __restrict__ a, float* __restrict__ sink, long row4, int rows, long n4) {
+template <int SEG, bool WR = false>
+__global__ __launch_bounds__(256) void rows_k(const f4* __restrict__ a, float* __restrict__ sink, long row4, int rows, long n4,
+                                               f4* __restrict__ out = nullptr) {
   const int lane = threadIdx.x & 63;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long nwaves = (long)gridDim.x * 4;
@@ -52,7 +53,10 @@ __global__ __launch_bounds__(256) void rows_k(const f4* __restrict__ a, float* _
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = base[(long)(r + u * RPI) * row4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc += v[u];
+      for (int u = 0; u < 8; ++u) {
+        if (WR) __builtin_nontemporal_store(v[u], out + (base - a) + (long)(r + u * RPI) * row4);
+        else acc += v[u];
+      }
     }
   }
   const float s = acc.x + acc.y + acc.z + acc.w;
@@ -85,5 +89,15 @@ int main(int argc, char** argv) {
   run("rows4", 1, [&] { hipLaunchKernelGGL((rows_k<16>), dim3(512), t, 0, 0, a, sink, row4, rows, n4); });
   run("rows2", 1, [&] { hipLaunchKernelGGL((rows_k<32>), dim3(512), t, 0, 0, a, sink, row4, rows, n4); });
   run("rows1", 1, [&] { hipLaunchKernelGGL((rows_k<64>), dim3(512), t, 0, 0, a, sink, row4, rows, n4); });
+  // image-shaped pieces (the grouped 3x3 kernels' tiles): planes of 192 x 192 / 384 x 384 floats, a wave walks down a column of
+  // 128- / 256- / 512-byte row pieces; read-only and read + write of the same pieces
+  run("i192r128", 1, [&] { hipLaunchKernelGGL((rows_k<8>), dim3(1024), t, 0, 0, a, sink, 48l, 192, n4, o); });
+  run("i192r256", 1, [&] { hipLaunchKernelGGL((rows_k<16>), dim3(1024), t, 0, 0, a, sink, 48l, 192, n4, o); });
+  run("i384r128", 1, [&] { hipLaunchKernelGGL((rows_k<8>), dim3(1024), t, 0, 0, a, sink, 96l, 384, n4, o); });
+  run("i384r512", 1, [&] { hipLaunchKernelGGL((rows_k<32>), dim3(1024), t, 0, 0, a, sink, 96l, 384, n4, o); });
+  run("i192c128", 2, [&] { hipLaunchKernelGGL((rows_k<8, true>), dim3(1024), t, 0, 0, a, sink, 48l, 192, n4, o); });
+  run("i192c256", 2, [&] { hipLaunchKernelGGL((rows_k<16, true>), dim3(1024), t, 0, 0, a, sink, 48l, 192, n4, o); });
+  run("i384c128", 2, [&] { hipLaunchKernelGGL((rows_k<8, true>), dim3(1024), t, 0, 0, a, sink, 96l, 384, n4, o); });
+  run("i384c512", 2, [&] { hipLaunchKernelGGL((rows_k<32, true>), dim3(1024), t, 0, 0, a, sink, 96l, 384, n4, o); });
   return 0;
 }

@@ -655,6 +655,155 @@ __global__ __launch_bounds__(256) void gconv3_kernel(const T* __restrict__ x, co
 }
 
 // -------------------------------------------------------------------------------------
+// The same convolution for 4 / 8 channels per group (the 128@384 and 256@192 stages), fp32 tensors, as a persistent
+// kernel: a block walks tiles of 16 x 32 pixels; the patch of its next tile travels HBM -> registers (16-byte row pieces +
+// the two halo columns) while the current one is multiplied out of LDS, and the results of a tile are stored one tile late,
+// so the wait at the top of the loop finds both long landed.  The products are packed FMAs over pairs of output channels
+// (see the loop).  What round 4 measured on this kernel (256@192 / 128@384, B = 32; profiles/r04_gconv3p_*.txt):
+//  - the one-tile-per-block kernel above already moved exactly the algorithmic bytes (PMC 1.00x) — in 0.199 / 0.320 ms;
+//  - with loads and stores removed the products alone take 0.145 / 0.176 ms: 75 / 62 TF against 137 TF that the same
+//    instruction (v_pk_fma_f32 with a scalar-register pair) reaches in a bare loop at 4 waves per SIMD
+//    (tools/probe/valu_fma.hip; plain v_fma_f32 tops out at 77 TF) — the nine taps of one input channel are 72 FMAs per
+//    scalar-load + LDS-read wait;
+//  - loads alone or stores alone add ~0.02 ms to that, both ~0.04 - 0.13: a wave is either issuing memory operations
+//    (38 % of its cycles by s_memtime stamps, the queue ahead of it full) or multiplying (49 %), and 4 - 6 waves per SIMD
+//    overlap the two only partly.  Result 0.18 / 0.305 ms.  Not the DRAM pattern: 128-byte row pieces stream at 6.2 TB/s
+//    read / 5.7 TB/s copy in tools/probe/hbm_streams.hip.
+// -------------------------------------------------------------------------------------
+typedef float g3_f32x2 __attribute__((ext_vector_type(2)));
+
+template <int CPG>
+__global__ __launch_bounds__(256) void gconv3p_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                      float* __restrict__ y, int NB, int C, int H, int W, int tiles_x,
+                                                      int ntile, int total) {
+  static_assert(CPG == 4 || CPG == 8, "whole group staged at once");
+  constexpr int TH = 16, TW = 32;
+  constexpr int IH = TH + 2, IW = 36;       // LDS row: [left halo][32 body columns][right halo][2 pad]
+  constexpr int NROW = CPG * IH;            // patch rows (channel, ry)
+  constexpr int NB4 = (NROW + 31) / 32;     // body: 32 rows x 8 float4 per pass of the block
+  constexpr int NHL = (2 * NROW + 255) / 256;   // halo columns: 2 elements per row
+  __shared__ __attribute__((aligned(16))) float xs[NROW * IW];
+  const int t = threadIdx.x;
+  const int tx = t & 15, ty = t >> 4;
+  const int HW = H * W;
+
+  // tile order: (group, image, tile), group slowest.  Tiles are dealt in chunks of gridDim.x / 8: chunk q goes to XCD q % 8
+  // (workgroup b runs on XCD b % 8), tile j of the chunk to that XCD's j-th block — neighbouring tiles are in flight
+  // together under one L2 (shared halo lines), and the whole chip is inside a window of gridDim.x tiles at any time:
+  // one or two groups, whose weights stay in the scalar caches.
+  const int pb = (int)(gridDim.x >> 3);
+  const int first = (int)(blockIdx.x & 7u) * pb + (int)(blockIdx.x >> 3), step = 8 * pb;
+  if (first >= total) return;
+
+  const int q4 = (t & 7) * 4, r0 = t >> 3;
+  float4 bv[NB4];
+  float hv[NHL];
+  auto fetch = [&](int L) {
+    const int bx = L % ntile;
+    const int r = L / ntile;
+    const int n = r % NB, g = r / NB;
+    const int py = (bx / tiles_x) * TH - 1, ox0 = (bx % tiles_x) * TW;
+    const float* __restrict__ xb = x + ((long)n * C + (long)g * CPG) * HW;   // uniform base + 32-bit lane offsets
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const int R = r0 + 32 * i;
+      const int c = R / IH, ry = R - c * IH;
+      const int iy = py + ry, ix = ox0 + q4;
+      bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (R < NROW && (unsigned)iy < (unsigned)H && ix < W)
+        bv[i] = *reinterpret_cast<const float4*>(xb + (unsigned)(__umul24(c, HW) + __umul24(iy, W) + ix));
+    }
+#pragma unroll
+    for (int i = 0; i < NHL; ++i) {
+      const int j = t + 256 * i;
+      const int R = j >> 1;
+      const int c = R / IH, ry = R - c * IH;
+      const int iy = py + ry, ix = (j & 1) ? ox0 + TW : ox0 - 1;
+      hv[i] = 0.f;
+      if (R < NROW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        hv[i] = xb[(unsigned)(__umul24(c, HW) + __umul24(iy, W) + ix)];
+    }
+  };
+
+  // results leave one tile late: the stores of tile i - 1 are issued before the products of tile i, so that the wait at
+  // the top of the loop (which covers every outstanding memory operation of the wave) finds loads and stores long landed
+  float out[2][CPG];
+  int out_L = -1;
+  auto put = [&]() {
+    const int bx = out_L % ntile;
+    const int r = out_L / ntile;
+    const int n = r % NB, g = r / NB;
+    const int ox = (bx % tiles_x) * TW + 2 * tx, oy = (bx / tiles_x) * TH + ty;
+    if (oy < H && ox < W) {   // W % 4 == 0: ox + 1 < W as well
+      float* yp = y + (((long)n * C + (long)g * CPG) * H + oy) * W + ox;
+#pragma unroll
+      for (int o = 0; o < CPG; ++o) *reinterpret_cast<float2*>(yp + (long)o * HW) = make_float2(out[0][o], out[1][o]);
+    }
+  };
+
+  fetch(first);
+  for (int L = first; L < total; L += step) {
+    __syncthreads();   // every wave is done reading the previous tile's patch
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const int R = r0 + 32 * i;
+      if (R < NROW) {
+        float* d = &xs[R * IW + 1 + q4];
+        d[0] = bv[i].x; d[1] = bv[i].y; d[2] = bv[i].z; d[3] = bv[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NHL; ++i) {
+      const int j = t + 256 * i;
+      if (j < 2 * NROW) xs[(j >> 1) * IW + ((j & 1) ? TW + 1 : 0)] = hv[i];
+    }
+    __syncthreads();
+    if (L + step < total) fetch(L + step);
+    if (out_L >= 0) put();
+
+    const int g = L / ntile / NB;
+    // packed FMAs over PAIRS OF OUTPUT CHANNELS: the weight pair (oc, oc + 1) of one (ci, tap) is an aligned SGPR pair as
+    // the scalar load delivers it and the input value is broadcast by the instruction's operand select — pairing the two
+    // pixels instead (what the compiler picks on its own) needs a register copy for every odd-aligned operand: 544 scalar
+    // and 60 vector moves per tile and wave beside 576 packed FMAs (PMC round 4)
+    g3_f32x2 acc[2][CPG / 2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int o = 0; o < CPG / 2; ++o) acc[b][o] = (g3_f32x2){0.f, 0.f};
+    const float* __restrict__ wg = wp + (long)g * (CPG * 9 * CPG);
+#pragma unroll(CPG == 4 ? 2 : 1)   // 72 weights (scalar registers) per trip either way
+    for (int c = 0; c < CPG; ++c) {
+      float in[3][4];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float2 a = *reinterpret_cast<const float2*>(&xs[(c * IH + ty + r) * IW + 2 * tx]);
+        const float2 b = *reinterpret_cast<const float2*>(&xs[(c * IH + ty + r) * IW + 2 * tx + 2]);
+        in[r][0] = a.x; in[r][1] = a.y; in[r][2] = b.x; in[r][3] = b.y;
+      }
+      const g3_f32x2* __restrict__ wc = reinterpret_cast<const g3_f32x2*>(wg + c * (9 * CPG));
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int o = 0; o < CPG / 2; ++o) {
+            const g3_f32x2 w = wc[(ky * 3 + kx) * (CPG / 2) + o];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              acc[b][o] = __builtin_elementwise_fma((g3_f32x2){in[ky][b + kx], in[ky][b + kx]}, w, acc[b][o]);
+          }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int o = 0; o < CPG / 2; ++o) { out[b][2 * o] = acc[b][o].x; out[b][2 * o + 1] = acc[b][o].y; }
+    out_L = L;
+  }
+  put();
+}
+
+// -------------------------------------------------------------------------------------
 // MFMA form of the same convolution for 16 / 32 channels per group (the 512@96, 1024@48 and 1024@24 stages):
 // per group it is a GEMM  Y[oc][pixel] = sum_k W[oc][k] X[k][pixel],  k = (ci, tap), with M = CPG rows — one
 // v_mfma_f32_32x32x2_f32 (CPG = 32) or v_mfma_f32_16x16x4_f32 (CPG = 16) tile.  A block owns a 16 x 16 pixel
@@ -822,6 +971,27 @@ int launch_gconv3(const T* x, const float* wp, T* y, int NB, int C, int H, int W
   return check_launch("gconv3");
 }
 
+inline int g3_num_cus() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  return n;
+}
+
+template <int CPG>
+int launch_gconv3p(const float* x, const float* wp, float* y, int NB, int C, int H, int W, hipStream_t st) {
+  const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 16);
+  const long total = (long)tiles_x * tiles_y * (C / CPG) * NB;
+  // a multiple of 8 blocks, 6 per CU (8 channels per group: registers allow 5): kbench 0.190 / 0.312 ms at 4 per CU, 0.183 / 0.305 at 6
+  const int blocks = (int)std::min<long>((total + 7) / 8 * 8, (long)g3_num_cus() / 8 * 8 * 6);
+  hipLaunchKernelGGL((gconv3p_kernel<CPG>), dim3(blocks), dim3(256), 0, st, x, wp, y, NB, C, H, W, tiles_x, tiles_x * tiles_y,
+                     (int)total);
+  return check_launch("gconv3p");
+}
+
 template <typename T>
 int gconv3x3_fwd_impl(const T* x, const float* w, T* y, int NB, int C, int H, int W, int groups, int transposed, void* ws,
                       size_t ws_bytes, wfae_stream_t stream) {
@@ -845,6 +1015,13 @@ int gconv3x3_fwd_impl(const T* x, const float* w, T* y, int NB, int C, int H, in
     return launch_gconv3_mfma<16>(x, wp, y, NB, C, H, W, st);
   }
   // one row per thread: measured 1 < 2 < 4 in time (the kernel is latency-bound: smaller LDS tiles, more blocks per CU)
+  // 4 / 8 channels per group, fp32 tensors with 16-byte rows: the software-pipelined kernel (24-bit lane offsets in a group)
+  if constexpr (sizeof(T) == 4) {
+    if (cpg <= 8 && W % 4 == 0 && (long)cdiv(W, 32) * cdiv(H, 16) * groups * NB < (1l << 31) && (long)cpg * H * W < (1l << 24)) {
+      if (cpg == 4) return launch_gconv3p<4>(x, wp, y, NB, C, H, W, st);
+      return launch_gconv3p<8>(x, wp, y, NB, C, H, W, st);
+    }
+  }
   switch (cpg) {
     case 4: return launch_gconv3<4, 1>(x, wp, y, NB, C, H, W, st);
     case 8: return launch_gconv3<8, 1>(x, wp, y, NB, C, H, W, st);

@@ -58,7 +58,8 @@ typedef enum {
  *        BatchNorm-backward epilogues of the tile-synchronous GEMMs: parity-green, never faster — the record is
  *        profiles/r03_kbench_c1_fused_bn_backward.txt); wfae_g3b_fwd no longer serves 8 channels per group;
  *        wfae_bn_act_bwd_from_rows now finishes the partial rows of wfae_c1r_bnred.  ADDED
- *        wfae_c1r_* (register-direct 1x1 convolutions: fp32 tensors, C <= 256 stages and the C >= 512 widening products) and
+ *        wfae_c1r_* (register-direct 1x1 convolutions: fp32 tensors, C <= 256 stages and the C >= 512 widening products;
+ *        wfae_c1r_bnred / wfae_c1r_bndx: the BatchNorm backward of the layer in front in the data gradient's epilogue) and
  *        wfae_c1rb_* (the same on bf16-stored tensors, every stage). */
 int wfae_version(void);
 const char* wfae_last_error_string(void);
@@ -150,7 +151,7 @@ int wfae_c1r_fwd(const float* w, int64_t w_sm, int64_t w_sk, const float* x, con
 /* The widening DATA GRADIENT of the C <= 256 stages with the reductions of the BatchNorm + GELU backward of the layer in front
  * taken in its epilogue (csrc/c1r.hip, ABI 103): da (NB,M,HW) = A dt as wfae_c1r_fwd, and part = sum dU [rows][M] then sum dU xhat
  * [rows][M] in fp64, dU = da * gelu'(x * bn_scale + bn_shift), xhat = (x - save_mean) * save_invstd, x (NB,M,HW) the BatchNorm
- * input — phase 1 of wfae_bn_act_bwd without its pass over (da, x).  Finish with wfae_bn_act_bwd_from_rows (dgamma, dbeta and the
+ * input — phase 1 of wfae_bn_act_bwd without its pass over (da, x); da may be NULL (the sums alone).  Finish with wfae_bn_act_bwd_from_rows (dgamma, dbeta and the
  * coefficients at the head of ws), then wfae_bn_act_bwd(phases = 2, same ws).  rows <= wfae_c1r_stat_rows(M, K, NB, HW). */
 int wfae_c1r_bnred_supported(int M, int K, int HW);
 int wfae_c1r_bnred(const float* w, int64_t w_sm, int64_t w_sk, const float* dt, const float* x, const float* bn_scale,
@@ -158,6 +159,16 @@ int wfae_c1r_bnred(const float* w, int64_t w_sm, int64_t w_sk, const float* dt, 
                    double* part, int64_t part_capacity, int* part_rows, wfae_stream_t stream);
 int wfae_bn_act_bwd_from_rows(const double* part, int rows, int C, float* dgamma, float* dbeta, int accumulate, void* ws,
                               size_t ws_bytes, wfae_stream_t stream);
+/* The second pass of that backward in the epilogue of the SAME data gradient, computed again from dt (csrc/c1r.hip, ABI 103):
+ *   dx (NB,M,HW) = gamma * save_invstd * (dU - coef[2c] / n - xhat * coef[2c+1] / n) + res,   n = NB * HW,
+ * dU, xhat as above with da = A dt rebuilt in registers; coef = the two sums per channel that wfae_bn_act_bwd_from_rows leaves at
+ * the head of its ws (training = 0: both taken as zero); res (the gradient arriving over the skip connection) may be null.  With
+ * wfae_c1r_bnred(da = NULL) — the sums alone, nothing stored — the layer's backward moves dt twice and x twice, res and dx once,
+ * where the da-storing sequence (wfae_c1r_bnred + wfae_bn_act_bwd phases = 2) also writes and re-reads da.  Replaces
+ * wfae_bn_act_bwd(phases = 2) for the shapes of wfae_c1r_bnred_supported. */
+int wfae_c1r_bndx(const float* w, int64_t w_sm, int64_t w_sk, const float* dt, const float* x, const float* gamma,
+                  const float* bn_scale, const float* bn_shift, const float* save_mean, const float* save_invstd, const float* coef,
+                  const float* res, float* dx, int NB, int K, int M, int HW, int training, wfae_stream_t stream);
 /* The same register-direct product on bf16-STORED tensors (csrc/c1rb.hip, ABI 103; needs WFAE_PRECISION_BF16): bf16 pieces of
  * eight pixels per lane go HBM -> registers -> v_mfma_f32_16x16x32_bf16 with four byte-permutes per fragment and no other
  * arithmetic, the weight as one bf16 plane rounded by the kernel itself, fp32 accumulation, one rounding of the result.  Serves

@@ -413,3 +413,25 @@ def test_c1rb_register_direct_matches_c1b(ops_medium, dev, m, k, nb, h, w, mode)
     assert bool(((a - b).abs() <= 2.0 ** -7 * b.abs() + 2e-5 * float(b.abs().max())).all()) and float((a != b).float().mean()) < 5e-3
     # repeat launches are bit-identical
     assert torch.equal(ops.c1rb_fwd(wt, False, x, st, res), y)
+
+
+@pytest.mark.parametrize("m,k,nb,h,w", [(32, 128, 40, 16, 16), (64, 256, 3, 16, 24), (128, 32, 40, 16, 16), (256, 1024, 8, 16, 16)])
+def test_c1rb_prologue_is_repeatable_with_cold_operands(ops_medium, dev, m, k, nb, h, w):
+    """the BatchNorm + GELU prologue forms of csrc/c1rb.hip, 60 launches each behind a 256 MB pass that empties the caches: every
+    launch bit-identical to csrc/c1b.hip's result (the two kernels agree bit for bit on these shapes).  With two waves per
+    SIMD this failed about every second cold launch on gfx950 (one tile, the low bf16 of one dword); the forms run one wave
+    per SIMD since (tools/debug_c1rb_repeat.py)"""
+    ops = ops_medium
+    x = rnd((nb, k, h, w), 1, -2, 2).bfloat16().to(dev)
+    wt = (rnd((m, k, 1, 1), 3) * k ** -0.5).to(dev)
+    st = ops.BnStats(k, dev)
+    st.scale.copy_(rnd((k,), 5) + 1.5)
+    st.shift.copy_(rnd((k,), 6))
+    ref = ops.c1b_fwd(ops.c1b_weights(wt)[0], x, st, None)
+    junk = torch.zeros(256 << 20, dtype=torch.uint8, device=dev)
+    bad = 0
+    for _ in range(60):
+        junk.add_(1)
+        bad += int(not torch.equal(ops.c1rb_fwd(wt, False, x, st, None), ref))
+    assert bad == 0
+

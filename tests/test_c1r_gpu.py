@@ -151,3 +151,72 @@ def test_c1r_bnred_epilogue_equals_the_reduce_pass(ops, dev, m, k, nb, h, w, res
     assert relerr(dg1, 2 * dg0) < 1e-6
     da2, sr2 = ops.c1r_bnred(wt, dt, x, st)
     assert torch.equal(da2, da) and torch.equal(sr2.part, sr.part)
+
+
+@pytest.mark.parametrize("m,k", [(128, 32), (256, 64)])
+@pytest.mark.parametrize("nb,h,w,res,training", [(2, 16, 16, False, True), (5, 16, 24, True, True), (40, 16, 16, True, True),
+                                                 (3, 8, 24, True, False)])
+def test_c1r_bndx_recomputed_gradient_equals_the_stored_one(ops, dev, m, k, nb, h, w, res, training):
+    """wfae_c1r_bnred(da = NULL) + wfae_bn_act_bwd_from_rows + wfae_c1r_bndx (the second pass of the BatchNorm + GELU backward in
+    the epilogue of the data gradient computed again) against the da-storing sequence on the same tensors: the same partial
+    rows bit for bit, dx to the rounding of one fused multiply-add (both evaluate bn_act_bwd_dx_kernel's expression on a
+    bit-identical dA), and against the plain wfae_conv1x1_bwd_data -> wfae_bn_act_bwd sequence"""
+    assert ops.c1r_bnred_supported(m, k, h * w)
+    dt = rnd((nb, k, h, w), 11).to(dev)
+    x = rnd((nb, m, h, w), 12, -2.0, 2.0).to(dev)
+    wt = rnd((k, m, 1, 1), 13, -0.3, 0.3).to(dev)
+    r = rnd((nb, m, h, w), 14).to(dev) if res else None
+    gamma = rnd((m,), 15, 0.5, 1.5).to(dev)
+    st = ops.bn_stats_train(x, gamma, rnd((m,), 16).to(dev), torch.zeros(m, device=dev), torch.ones(m, device=dev))
+    dg0, db0 = torch.empty(m, device=dev), torch.empty(m, device=dev)
+    dx_plain = ops.bn_act_bwd(ops.conv1x1_bwd_data(dt, wt), x, gamma, st, dg0, db0, r, 1, training)
+    da, sr = ops.c1r_bnred(wt, dt, x, st)
+    dg1, db1 = torch.empty(m, device=dev), torch.empty(m, device=dev)
+    ops.bn_act_bwd_from_rows(sr, m, dg1, db1)
+    dx_stored = ops.bn_act_bwd_dx(da, x, gamma, st, r, 1, training)
+    none, sr2 = ops.c1r_bnred(wt, dt, x, st, store=False)
+    assert none is None and sr2.rows == sr.rows and torch.equal(sr2.part, sr.part)
+    dg2, db2 = torch.empty(m, device=dev), torch.empty(m, device=dev)
+    ops.bn_act_bwd_from_rows(sr2, m, dg2, db2)
+    assert torch.equal(dg2, dg1) and torch.equal(db2, db1)
+    dx = ops.c1r_bndx(wt, dt, x, gamma, st, r, training)
+    scale = dx_stored.abs().max().item()
+    assert (dx - dx_stored).abs().max().item() <= 4e-7 * scale
+    assert relerr(dx, dx_plain) < 1e-6 and relerr(dg2, dg0) < 1e-6 and relerr(db2, db0) < 1e-6
+    assert torch.equal(ops.c1r_bndx(wt, dt, x, gamma, st, r, training), dx)      # repeatable
+
+
+def test_c1r_bndx_in_the_bottleneck_backward(ops, dev):
+    """functional._dgrad_bn with the switch on and off: the same dx / dgamma / dbeta"""
+    from weatherforecastingtoolkit_amd import functional as Fn
+    m, k, nb, h, w = 128, 32, 6, 16, 32
+    dt, x, dy = rnd((nb, k, h, w), 21).to(dev), rnd((nb, m, h, w), 22, -2.0, 2.0).to(dev), rnd((nb, m, h, w), 23).to(dev)
+    wt, gamma = rnd((k, m, 1, 1), 24, -0.3, 0.3).to(dev), rnd((m,), 25, 0.5, 1.5).to(dev)
+    st = ops.bn_stats_train(x, gamma, rnd((m,), 26).to(dev), torch.zeros(m, device=dev), torch.ones(m, device=dev))
+    out = []
+    try:
+        for on in (False, True):
+            ops.set_c1r_bndx(on)
+            dg, db = torch.empty(m, device=dev), torch.empty(m, device=dev)
+            out.append((Fn._dgrad_bn(dt, wt, None, x, gamma, st, dg, db, dy, True), dg, db))
+    finally:
+        ops.set_c1r_bndx(True)
+    assert relerr(out[1][0], out[0][0]) < 1e-6 and torch.equal(out[1][1], out[0][1]) and torch.equal(out[1][2], out[0][2])
+
+
+@pytest.mark.parametrize("m,k,nb,h,w", [(32, 128, 40, 16, 16), (64, 256, 8, 16, 24), (128, 32, 40, 16, 16)])
+def test_c1r_prologue_is_repeatable_with_cold_operands(ops, dev, m, k, nb, h, w):
+    """the fp32 prologue forms under the stress that exposed csrc/c1rb.hip's two-waves-per-SIMD failure: 60 launches, caches
+    emptied in front of each, one result"""
+    x = rnd((nb, k, h, w), 1, -2.0, 2.0).to(dev)
+    wt = (rnd((m, k, 1, 1), 3) * k ** -0.5).to(dev)
+    st = ops.BnStats(k, dev)
+    st.scale.copy_(rnd((k,), 5) + 1.5)
+    st.shift.copy_(rnd((k,), 6))
+    assert ops.c1r_supported(m, k, h * w)
+    junk = torch.zeros(256 << 20, dtype=torch.uint8, device=dev)
+    first = ops.conv1x1_fwd_bnact(x, st, wt)
+    for _ in range(60):
+        junk.add_(1)
+        assert torch.equal(ops.conv1x1_fwd_bnact(x, st, wt), first)
+

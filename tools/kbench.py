@@ -162,13 +162,25 @@ def main():
             st = ops.bn_stats_train(x, g, b_, rm, rv)
             dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
             for rep in range(2):
-                for on in (False, True):
+                for on, dxf, nm in ((False, False, "reduce as a pass, dx as a pass"), (True, False, "reduce in the c1r epilogue, dx as a pass"),
+                                    (True, True, "reduce and dx in c1r epilogues (dA recomputed)")):
                     ops.set_c1r_bnred(on)
+                    ops.set_c1r_bndx(dxf)
                     ms = timeit(lambda: Fn._dgrad_bn(dt1, w1, None, x, g, st, dg, db, dy, True), R)
-                    report(f"bnseq C={c} @{h} dgrad + bn1 bwd, reduce {'in the c1r epilogue' if on else 'as a pass'} rep{rep}", ms,
-                           2 * n * c * mid, 4 * n * (mid + c) + 4 * n * (2 * c if not on else c) + 4 * n * 4 * c)
-                    acc("bnseq_" + ("fused" if on else "separate"), ms / 2, mult)
+                    passes = 9 if not on else (7 if not dxf else 4)      # C-wide tensors moved
+                    report(f"bnseq C={c} @{h} dgrad + bn1 bwd: {nm} rep{rep}", ms, 2 * n * c * mid * (2 if dxf else 1),
+                           4 * n * (mid * (2 if dxf else 1) + passes * c))
+                    acc("bnseq_" + ("separate" if not on else "fused" if not dxf else "recompute"), ms / 2, mult)
             ops.set_c1r_bnred(True)
+            ops.set_c1r_bndx(True)
+            if ops.c1r_bnred_supported(c, mid, h * h):     # the launches of the two c1r sequences on their own
+                _, sr = ops.c1r_bnred(w1, dt1, x, st, store=False)
+                ops.bn_act_bwd_from_rows(sr, c, dg, db)
+                for nm, fn, by in (("c1r_bnred (stores dA)", lambda: ops.c1r_bnred(w1, dt1, x, st), 4 * n * (mid + 2 * c)),
+                                   ("c1r_bnred (sums alone)", lambda: ops.c1r_bnred(w1, dt1, x, st, store=False), 4 * n * (mid + c)),
+                                   ("c1r_bndx", lambda: ops.c1r_bndx(w1, dt1, x, g, st, dy, True), 4 * n * (mid + 3 * c)),
+                                   ("bn_act_bwd_dx", lambda: ops.bn_act_bwd_dx(dy, x, g, st, dy, 1, True), 4 * n * 4 * c)):
+                    report(f"bnseq C={c} @{h} {nm}", timeit(fn, R), 2 * n * c * mid, by)
             del x, dt1, dy
     if "c1b" in only:
         # bf16 storage ('medium'): csrc/c1b.hip against gemm.hip's bf16-storage kernels, per Bottleneck stage

@@ -51,6 +51,10 @@ struct C1RP {
   int ntiles;
   const float* bn_x;         // BNR: the BatchNorm input of the layer in FRONT of this convolution, [NB][M][HW] (the shape of Y)
   const float* bn_tab[4];    // BNR: folded scale, shift, batch mean, invstd of that BatchNorm, [M] each
+  const float* bn_gamma;     // BNM 3: that BatchNorm's weight [M], the two sums of its backward reduce ([2 c], [2 c + 1]) and 1 / count
+  const float* bn_coef;
+  float inv_count;
+  int training;
   int m_total;               // rows of Y: nslices * M (M = the 16 MT rows one block owns)
   int nslices;               // M-slices: the blocks b, b + 8, .. of one XCD that share a tile sequence split the rows
 };
@@ -87,22 +91,29 @@ __device__ __forceinline__ Planes3 split_pair(float a, float b) {
 // that layer's backward pass — sum dU and sum dU xhat per channel, dU = dA gelu'(x a + b), xhat = (x - mu) is: phase 1 of
 // wfae_bn_act_bwd, bn_act_bwd_reduce_kernel's arithmetic — are taken here while dA is in registers (x travels through the
 // residual ring) and leave as the partial rows of STATS; the separate pass over (dA, x) disappears.
-template <int KCH, int MT, int MG, bool PRO, bool STATS, int RWAVES = 8, int NBUF = 2, int RD = 2, bool RESN = false, bool BNR = false>
-__global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel(C1RP p) {
+// BNM: 0 none; 1 the BNR form above; 2 the same sums WITHOUT storing dA; 3 the second pass of that layer's backward in the
+// epilogue: dx = gamma invstd (dU - sum dU / n - xhat sum dU xhat / n) + skip — bn_act_bwd_dx_kernel's arithmetic — with dA
+// recomputed from dT (six MFMAs per product on a kernel that waits for HBM) instead of written by pass 1 and read back by
+// pass 2: modes 2 + 3 move 4 C-wide tensors per layer where mode 1 + wfae_bn_act_bwd's second pass move 6.
+template <int KCH, int MT, int MG, bool PRO, bool STATS, int RWAVES = 8, int NBUF = 2, int RD = 2, bool RESN = false, int BNM = 0,
+          int MINB = (RWAVES == 4 ? 1 : 2)>
+__global__ __launch_bounds__(64 * RWAVES, MINB) void c1r_kernel(C1RP p) {
   constexpr int RNT = 64 * RWAVES;
   constexpr int K = 32 * KCH, M = 16 * MT, NPASS = MT / MG;
   constexpr bool BRES = NPASS > 1;                 // the split operand of a tile stays in registers, M in passes
+  constexpr bool BNR = BNM == 1 || BNM == 2, DXF = BNM == 3;
   static_assert(MT % MG == 0, "whole passes");
   constexpr int PLANE_B = M * 64;                  // one plane of one 32-deep chunk: M rows x 64 bytes
   constexpr int A_B = KCH * 3 * PLANE_B;
   constexpr int PRO_B = PRO ? 2 * K * 4 : 0;
   static_assert(!BNR || (STATS && !PRO && !RESN && MT > MG), "BNR: a B-resident data-gradient kernel; its sums use the STATS rows");
+  static_assert(!DXF || (!STATS && !PRO && !RESN && MT > MG), "BNM 3: a B-resident data-gradient kernel");
   constexpr int ST_B = STATS ? RWAVES * 2 * M * 8 : 0;
-  constexpr int BNT_B = BNR ? 4 * M * 4 : 0;
+  constexpr int BNT_B = BNR ? 4 * M * 4 : DXF ? 7 * M * 4 : 0;
   static_assert(A_B + PRO_B + ST_B + BNT_B <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(16))) unsigned char smem[A_B + PRO_B + ST_B + BNT_B];
   float* const lsc = reinterpret_cast<float*>(smem + A_B);
-  float* const lbn = reinterpret_cast<float*>(smem + A_B + PRO_B + ST_B);   // BNR: [4][M]
+  float* const lbn = reinterpret_cast<float*>(smem + A_B + PRO_B + ST_B);   // BNR: [4][M]; BNM 3: [7][M]
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int n16 = lane & 15, kg = lane >> 4;
@@ -143,8 +154,15 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
     if constexpr (STATS) {
       for (int i = lane; i < 2 * M; i += 64) lst[i] = 0.0;
     }
-    if constexpr (BNR) {
+    if constexpr (BNR || DXF) {
       for (int i = t; i < 4 * M; i += RNT) lbn[i] = p.bn_tab[i / M][m_off + i % M];
+    }
+    if constexpr (DXF) {   // gamma invstd, sum dU / n, sum dU xhat / n (bn_act_bwd_dx_kernel's gi, k1, k2)
+      for (int i = t; i < M; i += RNT) {
+        lbn[4 * M + i] = p.bn_gamma[m_off + i] * p.bn_tab[3][m_off + i];
+        lbn[5 * M + i] = p.training ? p.bn_coef[2 * (m_off + i) + 0] * p.inv_count : 0.f;
+        lbn[6 * M + i] = p.training ? p.bn_coef[2 * (m_off + i) + 1] * p.inv_count : 0.f;
+      }
     }
   }
   __syncthreads();
@@ -231,22 +249,45 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
   auto split_chunk = [&](f32x4 (&r)[8], u32x4 (&b)[4][3], int c) { split_part(r, b, c, I0{}, I4{}); };
   auto multiply = [&](f32x4 (&acc)[MG][4], const u32x4 (&b)[4][3], int c, int a_pass_off) { multiply_part(acc, b, c, a_pass_off, I0{}, I4{}); };
   auto load_res = [&](f32x4 (&rv)[MG][4], int tl, int mt0) {
-    const char* rb = reinterpret_cast<const char*>(BNR ? p.bn_x : p.res) + tile_off(tl, p.m_total) + (long)(m_off + 16 * mt0) * rowB;
+    const char* rb = reinterpret_cast<const char*>((BNR || DXF) ? p.bn_x : p.res) + tile_off(tl, p.m_total) + (long)(m_off + 16 * mt0) * rowB;
 #pragma unroll
     for (int mt = 0; mt < MG; ++mt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) rv[mt][q] = *reinterpret_cast<const f32x4*>(rb + (16 * mt + q) * rowB + lane_out);
   };
+  auto load_skip = [&](f32x4 (&sv)[MG][4], int tl, int mt0) {   // BNM 3: the gradient arriving over the skip connection
+    const char* rb = reinterpret_cast<const char*>(p.res) + tile_off(tl, p.m_total) + (long)(m_off + 16 * mt0) * rowB;
+#pragma unroll
+    for (int mt = 0; mt < MG; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sv[mt][q] = *reinterpret_cast<const f32x4*>(rb + (16 * mt + q) * rowB + lane_out);
+  };
   // lane (n16, kg): acc[mt][jj][q] = Y[row 16 (mt0 + mt) + 4 kg + q][pixel 4 n16 + jj]
-  auto store_pass = [&](const f32x4 (&acc)[MG][4], const f32x4 (&rv)[MG][4], bool with_res, int tl, int mt0) {
+  auto store_pass = [&](const f32x4 (&acc)[MG][4], const f32x4 (&rv)[MG][4], const f32x4 (&sv)[MG][4], bool with_res, bool with_skip,
+                        int tl, int mt0) {
     char* yb = reinterpret_cast<char*>(p.Y) + tile_off(tl, p.m_total) + (long)(m_off + 16 * mt0) * rowB;
 #pragma unroll
     for (int mt = 0; mt < MG; ++mt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 v = {acc[mt][0][q], acc[mt][1][q], acc[mt][2][q], acc[mt][3][q]};
-        if (!BNR && with_res) v += rv[mt][q];
-        *reinterpret_cast<f32x4*>(yb + (16 * mt + q) * rowB + lane_out) = v;
+        if (!BNR && !DXF && with_res) v += rv[mt][q];
+        if constexpr (DXF) {   // bn_act_bwd_dx_kernel's one(): gi (dU - k1 - xhat k2) + skip
+          const int ml = 16 * (mt0 + mt) + 4 * kg + q;
+          const float a = lbn[ml], b = lbn[M + ml], mu = lbn[2 * M + ml], is = lbn[3 * M + ml];
+          const float gi = lbn[4 * M + ml], k1 = lbn[5 * M + ml], k2 = lbn[6 * M + ml];
+          const f32x4 xv = rv[mt][q];
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float du = v[e] * gelu_grad_f(fmaf(xv[e], a, b));
+            const float xh = (xv[e] - mu) * is;
+            o[e] = gi * (du - k1 - xh * k2) + (with_skip ? sv[mt][q][e] : 0.f);
+          }
+          *reinterpret_cast<f32x4*>(yb + (16 * mt + q) * rowB + lane_out) = o;
+        } else if constexpr (BNM != 2) {
+          *reinterpret_cast<f32x4*>(yb + (16 * mt + q) * rowB + lane_out) = v;
+        }
         if constexpr (BNR) {   // bn_act_bwd_reduce_kernel's quad(): dU = dA gelu'(x a + b), sums of dU and dU xhat
           const int ml = 16 * (mt0 + mt) + 4 * kg + q;
           const float a = lbn[ml], b = lbn[M + ml], mu = lbn[2 * M + ml], is = lbn[3 * M + ml];
@@ -273,7 +314,8 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
       }
   };
 
-  const bool with_res = BNR || p.res != nullptr;
+  const bool with_res = BNR || DXF || p.res != nullptr;
+  const bool with_skip = DXF && p.res != nullptr;
   if (tile < p.ntiles) {
     if constexpr (!BRES) {
       // ---- narrowing: stream the K chunks through a ring of NBUF register buffers, NBUF - 1 chunks of loads in flight ahead of
@@ -317,7 +359,7 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        store_pass(acc, rv, RESN && with_res, tile, 0);
+        store_pass(acc, rv, rv, RESN && with_res, false, tile, 0);
         tile += tstride;
       }
     } else {
@@ -330,9 +372,15 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
       while (tile < p.ntiles) {
         const int nxt_tile = tile + tstride < p.ntiles ? tile + tstride : tile;
         f32x4 rr[RD][MG][4];
+        f32x4 rs[DXF ? RD : 1][MG][4];   // BNM 3: the skip gradient's rows travel beside x's
         if (with_res) {
 #pragma unroll
-          for (int u = 0; u < RD - 1; ++u) load_res(rr[u], tile, u * MG);
+          for (int u = 0; u < RD - 1; ++u) {
+            load_res(rr[u], tile, u * MG);
+            if constexpr (DXF) {
+              if (with_skip) load_skip(rs[u], tile, u * MG);
+            }
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         u32x4 b[KCH][4][3];
@@ -344,7 +392,12 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
 #pragma unroll
           for (int u = 0; u < RD; ++u) {
             const int pass = pass0 + u, mt0 = pass * MG;
-            if (with_res && pass + RD - 1 < NPASS) load_res(rr[(u + RD - 1) % RD], tile, (pass + RD - 1) * MG);
+            if (with_res && pass + RD - 1 < NPASS) {
+              load_res(rr[(u + RD - 1) % RD], tile, (pass + RD - 1) * MG);
+              if constexpr (DXF) {
+                if (with_skip) load_skip(rs[(u + RD - 1) % RD], tile, (pass + RD - 1) * MG);
+              }
+            }
             // the last KCH passes of the tile: one chunk each of the wave's next tile (its first passes do not wait)
             if (u >= RD - KCH && pass0 == NPASS - RD) load_chunk(raw[u >= RD - KCH ? u - (RD - KCH) : 0], nxt_tile, u - (RD - KCH));
             __builtin_amdgcn_sched_barrier(0);
@@ -355,7 +408,7 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1r_kernel
               for (int jj = 0; jj < 4; ++jj) acc[mt][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < KCH; ++c) multiply(acc, b[c], c, mt0 * (16 * 64));
-            store_pass(acc, rr[u], with_res, tile, mt0);
+            store_pass(acc, rr[u], rs[DXF ? u : 0], with_res, with_skip, tile, mt0);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -434,8 +487,14 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 namespace {
 template <int KCH, int MT, int NW, int RD>
 void launch_bnr(const C1RP& p, int grid, hipStream_t st) {
-  hipLaunchKernelGGL((c1r_kernel<KCH, MT, 1, false, true, NW, 2, RD, false, true>), dim3((unsigned)grid), dim3(64 * NW), 0, st, p);
+  if (p.Y) hipLaunchKernelGGL((c1r_kernel<KCH, MT, 1, false, true, NW, 2, RD, false, 1, 1>), dim3((unsigned)grid), dim3(64 * NW), 0, st, p);
+  else hipLaunchKernelGGL((c1r_kernel<KCH, MT, 1, false, true, NW, 2, RD, false, 2, 1>), dim3((unsigned)grid), dim3(64 * NW), 0, st, p);
 }
+template <int KCH, int MT, int NW, int RD>
+void launch_bndx(const C1RP& p, int grid, hipStream_t st) {
+  hipLaunchKernelGGL((c1r_kernel<KCH, MT, 1, false, false, NW, 2, RD, false, 3, 1>), dim3((unsigned)grid), dim3(64 * NW), 0, st, p);
+}
+constexpr int BNR_WAVES = 8;   // the reduce epilogue is vector-instruction work (GELU', fp64 row sums): two waves per SIMD cover it
 }  // namespace
 
 extern "C" {
@@ -447,7 +506,8 @@ int wfae_c1r_supported(int M, int K, int HW) {
 int wfae_c1r_stat_rows(int M, int K, int NB, int HW) {
   const ShapeInfo si = shape_of(M, K);
   if (si.sid < 0 || HW <= 0 || HW % 64 != 0 || NB <= 0) return 0;
-  return grid_for((long)NB * (HW / 64), si) / si.nslices * si.waves;
+  // (the reduce form of wfae_c1r_bnred runs BNR_WAVES waves per block on the shapes it serves: one capacity for both users)
+  return grid_for((long)NB * (HW / 64), si) / si.nslices * ((si.sid == 2 || si.sid == 3) ? BNR_WAVES : si.waves);
 }
 
 int wfae_c1r_fwd(const float* w, int64_t w_sm, int64_t w_sk, const float* x, const float* pro_scale, const float* pro_shift,
@@ -503,8 +563,8 @@ int wfae_c1r_bnred_supported(int M, int K, int HW) {
 int wfae_c1r_bnred(const float* w, int64_t w_sm, int64_t w_sk, const float* dt, const float* x, const float* bn_scale,
                    const float* bn_shift, const float* save_mean, const float* save_invstd, float* da, int NB, int K, int M, int HW,
                    double* part, int64_t part_capacity, int* part_rows, wfae_stream_t stream) {
-  WFAE_REQUIRE(w && dt && x && bn_scale && bn_shift && save_mean && save_invstd && da && part && part_rows, WFAE_ERR_NULL_POINTER,
-               "c1r_bnred: null pointer");
+  WFAE_REQUIRE(w && dt && x && bn_scale && bn_shift && save_mean && save_invstd && part && part_rows, WFAE_ERR_NULL_POINTER,
+               "c1r_bnred: null pointer");   // da may be null: the sums alone (wfae_c1r_bndx recomputes dA)
   WFAE_REQUIRE(NB > 0 && K > 0 && M > 0 && HW > 0 && (int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "c1r_bnred: bad shape");
   const ShapeInfo si = shape_of(M, K);
   WFAE_REQUIRE(wfae_c1r_bnred_supported(M, K, HW), WFAE_ERR_UNSUPPORTED,
@@ -512,7 +572,7 @@ int wfae_c1r_bnred(const float* w, int64_t w_sm, int64_t w_sk, const float* dt, 
                "the split GEMMs on (M %d, K %d, HW %d)", M, K, HW);
   WFAE_REQUIRE((w_sm == K && w_sk == 1) || (w_sm == 1 && w_sk == M), WFAE_ERR_BAD_SHAPE,
                "c1r_bnred: the weight is (M, K) row-major (strides K, 1) or its transpose (strides 1, M)");
-  WFAE_REQUIRE(al16(dt) && al16(x) && al16(da), WFAE_ERR_UNSUPPORTED, "c1r_bnred: tensors must be 16-byte aligned");
+  WFAE_REQUIRE(al16(dt) && al16(x) && (!da || al16(da)), WFAE_ERR_UNSUPPORTED, "c1r_bnred: tensors must be 16-byte aligned");
   C1RP p = {};
   p.W = w; p.w_sm = w_sm; p.w_sk = w_sk;
   p.X = dt; p.Y = da; p.bn_x = x;
@@ -520,16 +580,47 @@ int wfae_c1r_bnred(const float* w, int64_t w_sm, int64_t w_sk, const float* dt, 
   p.HW = HW; p.tpi = HW / 64; p.ntiles = NB * p.tpi;
   p.m_total = M; p.nslices = 1;
   const int grid = grid_for(p.ntiles, si);
-  const int rows = grid * si.waves;
+  const int rows = grid * BNR_WAVES;
   WFAE_REQUIRE(part_capacity >= 2 * (int64_t)rows * M, WFAE_ERR_WORKSPACE, "c1r_bnred: part holds %lld doubles, needs %lld",
                (long long)part_capacity, (long long)(2 * (int64_t)rows * M));
   *part_rows = rows;
   p.part0 = part;
   p.part1 = part + (long)rows * M;
   hipStream_t st = (hipStream_t)stream;
-  if (si.sid == 2) launch_bnr<1, 8, 4, 8>(p, grid, st);
-  else launch_bnr<2, 16, 4, 2>(p, grid, st);
+  // 8 waves (256 registers each, x four / one pass ahead) against 4 waves with the plain product's rings: sums alone 0.98 ->
+  // 0.73 ms at C = 128, 0.60 -> 0.48 ms at C = 256 (profiles/r04_kbench_bn1_backward_recompute.txt)
+  if (si.sid == 2) launch_bnr<1, 8, BNR_WAVES, 4>(p, grid, st);
+  else launch_bnr<2, 16, BNR_WAVES, 2>(p, grid, st);
   return check_launch("c1r_bnred");
+}
+
+int wfae_c1r_bndx(const float* w, int64_t w_sm, int64_t w_sk, const float* dt, const float* x, const float* gamma, const float* bn_scale,
+                  const float* bn_shift, const float* save_mean, const float* save_invstd, const float* coef, const float* res,
+                  float* dx, int NB, int K, int M, int HW, int training, wfae_stream_t stream) {
+  WFAE_REQUIRE(w && dt && x && gamma && bn_scale && bn_shift && save_mean && save_invstd && coef && dx, WFAE_ERR_NULL_POINTER,
+               "c1r_bndx: null pointer");
+  WFAE_REQUIRE(NB > 0 && K > 0 && M > 0 && HW > 0 && (int64_t)NB * HW < (1ll << 31), WFAE_ERR_BAD_SHAPE, "c1r_bndx: bad shape");
+  const ShapeInfo si = shape_of(M, K);
+  WFAE_REQUIRE(wfae_c1r_bnred_supported(M, K, HW), WFAE_ERR_UNSUPPORTED,
+               "c1r_bndx: serves the widening data gradients (M, K) = (128, 32), (256, 64) with HW %% 64 == 0 at fp32 precision with "
+               "the split GEMMs on (M %d, K %d, HW %d)", M, K, HW);
+  WFAE_REQUIRE((w_sm == K && w_sk == 1) || (w_sm == 1 && w_sk == M), WFAE_ERR_BAD_SHAPE,
+               "c1r_bndx: the weight is (M, K) row-major (strides K, 1) or its transpose (strides 1, M)");
+  WFAE_REQUIRE(al16(dt) && al16(x) && al16(dx) && (!res || al16(res)), WFAE_ERR_UNSUPPORTED, "c1r_bndx: tensors must be 16-byte aligned");
+  C1RP p = {};
+  p.W = w; p.w_sm = w_sm; p.w_sk = w_sk;
+  p.X = dt; p.Y = dx; p.bn_x = x; p.res = res;
+  p.bn_tab[0] = bn_scale; p.bn_tab[1] = bn_shift; p.bn_tab[2] = save_mean; p.bn_tab[3] = save_invstd;
+  p.bn_gamma = gamma; p.bn_coef = coef; p.inv_count = 1.0f / (float)((double)NB * HW); p.training = training;
+  p.HW = HW; p.tpi = HW / 64; p.ntiles = NB * p.tpi;
+  p.m_total = M; p.nslices = 1;
+  const int grid = grid_for(p.ntiles, si);
+  hipStream_t st = (hipStream_t)stream;
+  // two rings (x and the skip gradient): four passes deep at C = 128 where the reduce form keeps one ring of eight
+  // (8 waves with rings two deep: 1.50 against 1.47 ms at C = 128, and 162 spilled registers at C = 256)
+  if (si.sid == 2) launch_bndx<1, 8, 4, 4>(p, grid, st);
+  else launch_bndx<2, 16, 4, 2>(p, grid, st);
+  return check_launch("c1r_bndx");
 }
 
 }  // extern "C"

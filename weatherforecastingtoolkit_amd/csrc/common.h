@@ -85,15 +85,28 @@ __device__ __forceinline__ float gelu_tail_f(float u, float* e_out) {   // 1 - P
   *e_out = e;
   return q * t * e;
 }
+// Phi(u) from the tail: 1 - h for u >= 0, h below.  The choice is made on u's SIGN BIT with a bit-field insert, not with
+// v_cmp + v_cndmask through VCC: same values (at u = -0 both branches are 0.5), and no lane mask travels between two vector
+// instructions.  With the compare form, csrc/c1rb.hip's prologue (two packed evaluations per dword, the low element's compare two
+// wait states in front of its select as hipcc pads it) gave results that differed between identical launches on gfx950: the
+// LOW bf16 of a dword took the wrong branch in most lanes of one instruction, about one launch in ten
+// (tools/debug_c1rb_repeat.py; a full s_waitcnt or s_nops around the MFMAs changed nothing).
+__device__ __forceinline__ float gelu_cdf_select(float u, float h) {
+  const int neg = __builtin_bit_cast(int, u) >> 31;   // all ones below zero
+  const float a = 1.0f - h;
+  float r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(neg), "v"(h), "v"(a));   // (neg & h) | (~neg & a); written out, the compiler turns it back into v_cmp + v_cndmask
+  return r;
+}
 __device__ __forceinline__ float gelu_f(float u) {
   float e;
   const float h = gelu_tail_f(u, &e);
-  return u * (u >= 0.f ? 1.0f - h : h);
+  return u * gelu_cdf_select(u, h);
 }
 __device__ __forceinline__ float gelu_grad_f(float u) {
   float e;
   const float h = gelu_tail_f(u, &e);
-  const float cdf = u >= 0.f ? 1.0f - h : h;
+  const float cdf = gelu_cdf_select(u, h);
   return fmaf(u * 0.39894228040143267794f, e, cdf);
 }
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }

@@ -567,6 +567,11 @@ def _dgrad_bn(dt, w, Wt, x, gamma, st, dgamma, dbeta, res, training):
     if dt.dtype == torch.float32 and ops.c1r_bnred_supported(w.shape[1], dt.shape[1], dt.shape[2] * dt.shape[3]):
         # the C <= 256 widening data gradients on csrc/c1r.hip: sum dU / sum dU xhat of the BatchNorm in front ride in the epilogue
         # (x travels through the kernel's residual ring), the reduce pass over (dA, x) disappears
+        # — and so does dA itself: the second pass runs in the epilogue of the same product computed again (ops.c1r_bndx)
+        if ops.c1r_bndx_on():
+            _, sr = ops.c1r_bnred(w, dt, x, st, store=False)
+            ops.bn_act_bwd_from_rows(sr, x.shape[1], dgamma, dbeta)
+            return ops.c1r_bndx(w, dt, x, gamma, st, res, training)
         da, sr = ops.c1r_bnred(w, dt, x, st)
         ops.bn_act_bwd_from_rows(sr, x.shape[1], dgamma, dbeta)
         return ops.bn_act_bwd_dx(da, x, gamma, st, res, 1, training)
@@ -606,8 +611,8 @@ class BottleneckFn(Function):
         rb1, rb3 = bf and ops.c1rb_supported(mid, C, hw), bf and ops.c1rb_supported(C, mid, hw)   # register-direct (csrc/c1rb.hip)
         cb1 = rb1 or (bf and ops.c1b_supported(mid, C, hw))
         cb3 = rb3 or (bf and ops.c1b_supported(C, mid, hw))
-        if C >= 512:
-            rb1 = False        # the sliced C -> C/4 products: forward (prologue) on c1b, so its plane pair is needed
+        if C >= 256:
+            rb1 = False        # the C -> C/4 forward with the prologue runs on c1b there (ops.c1rb_take), so its plane pair is needed
         if (cb1 and not rb1) or (cb3 and not rb3):      # c1b.hip takes prepared bf16 planes; c1rb.hip reads the fp32 weight itself
             W1p, W3p = ops.c1b_weights(w1), ops.c1b_weights(w3)
         st1 = _bn_stats_rows(x_stats if (fuse or isinstance(x_stats, ops.StatParts)) else None, x, bn1, training)

@@ -255,7 +255,7 @@ def _c1r(w, transposed, x, st, res, stats, label):
     rows = ctypes.c_int(0)
     _call("wfae_c1r_fwd", fl, by, _p(w), sm, sk, _p(x), ps, ph, _p(res), _p(y), nb, k, m, h * wd, part.data_ptr(), part.numel(),
           ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream(), label=label, peak=PEAK_BF16_MFMA / 6)
-    return y, StatRows(part, rows.value)
+    return y, StatRows(part[:2 * rows.value * m], rows.value)     # (the capacity is sized for the widest user of the shape)
 
 
 _C1R_BNRED = True   # A/B through set_c1r_bnred()
@@ -272,22 +272,23 @@ def c1r_bnred_supported(m, k, hw):
             and bool(_lib.load().wfae_c1r_bnred_supported(int(m), int(k), int(hw))))
 
 
-def c1r_bnred(w, dt, x, st):
+def c1r_bnred(w, dt, x, st, store=True):
     """da = conv1x1_bwd_data(dt, w) on c1r with phase 1 of bn_act_bwd(da, x, ...) taken in the epilogue -> (da, StatRows of
-    (sum dU, sum dU xhat)); finish with bn_act_bwd_from_rows, then bn_act_bwd_dx"""
+    (sum dU, sum dU xhat)); finish with bn_act_bwd_from_rows, then bn_act_bwd_dx — or, with store=False (da is None: the sums
+    alone), with c1r_bndx, which rebuilds da in its own registers"""
     import ctypes
     _chk(w, dt, x)
     nb, k, h, wd = dt.shape
     m = w.shape[1]
-    da = torch.empty((nb, m, h, wd), dtype=torch.float32, device=dt.device)
+    da = torch.empty((nb, m, h, wd), dtype=torch.float32, device=dt.device) if store else None
     rows_n = int(_lib.load().wfae_c1r_stat_rows(m, k, nb, h * wd))
     part = torch.empty(2 * rows_n * m, dtype=torch.float64, device=dt.device)
     rows = ctypes.c_int(0)
     n = nb * h * wd
-    _call("wfae_c1r_bnred", 2 * n * k * m, 4 * (n * (k + 2 * m) + k * m), _p(w), 1, m, _p(dt), _p(x), _p(st.scale), _p(st.shift),
+    _call("wfae_c1r_bnred", 2 * n * k * m, 4 * (n * (k + (2 if store else 1) * m) + k * m), _p(w), 1, m, _p(dt), _p(x), _p(st.scale), _p(st.shift),
           _p(st.mean), _p(st.invstd), _p(da), nb, k, m, h * wd, part.data_ptr(), part.numel(),
           ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream(), label="wfae_conv1x1_bwd_data", peak=PEAK_BF16_MFMA / 6)
-    return da, StatRows(part, rows.value)
+    return da, StatRows(part[:2 * rows.value * m], rows.value)
 
 
 def bn_act_bwd_from_rows(sr, c, dgamma, dbeta, accumulate=False):
@@ -312,6 +313,35 @@ def bn_act_bwd_dx(dy, x, gamma, st, res=None, act=1, training=True):
     return dx
 
 
+_C1R_BNDX = True   # A/B through set_c1r_bndx()
+
+
+def set_c1r_bndx(on):
+    """A/B switch: the second pass of the first BatchNorm's backward in the epilogue of a recomputed data gradient (c1r_bndx)
+    or as bn_act_bwd_dx over the stored one"""
+    global _C1R_BNDX
+    _C1R_BNDX = bool(on)
+
+
+def c1r_bndx_on():
+    return _C1R_BNDX
+
+
+def c1r_bndx(w, dt, x, gamma, st, res=None, training=True):
+    """dx of  conv1x1(gelu(bn(x)), w)  given dt, second pass: da = conv1x1_bwd_data(dt, w) rebuilt in registers and
+    bn_act_bwd_dx(da, x, ...) + res applied in the epilogue (after c1r_bnred(store=False) + bn_act_bwd_from_rows on this stream)"""
+    _chk(w, dt, x, gamma, res)
+    nb, k, h, wd = dt.shape
+    m = w.shape[1]
+    dx = torch.empty((nb, m, h, wd), dtype=torch.float32, device=dt.device)
+    ws = workspace()
+    n = nb * h * wd
+    _call("wfae_c1r_bndx", 2 * n * k * m, 4 * (n * (k + (3 if res is not None else 2) * m) + k * m), _p(w), 1, m, _p(dt), _p(x), _p(gamma),
+          _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd), ws.data_ptr(), _p(res), _p(dx), nb, k, m, h * wd, int(training),
+          _stream(), label="wfae_bn_act_bwd[dx]", peak=PEAK_BF16_MFMA / 6)
+    return dx
+
+
 # csrc/c1rb.hip: the same register-direct product on bf16-stored tensors ('medium'): every Bottleneck stage with HW % 128 == 0
 _C1RB = True   # A/B through set_c1rb()
 
@@ -328,9 +358,11 @@ def c1rb_supported(m, k, hw):
 
 def c1rb_take(m, k, hw, pro):
     """route this bf16 product to c1rb?  Measured (profiles/r04_kbench_c1rb_vs_c1b.txt): it wins or ties every form except
-    the M-SLICED narrowing products (C >= 512: (128, 512), (256, 1024)) with the BatchNorm + GELU prologue — every slice
-    evaluates the activation of the whole operand again (0.163 -> 0.462 ms); those stay on c1b."""
-    if pro and m < k and k >= 512:
+    the narrowing products of C >= 256 with the BatchNorm + GELU prologue, which stay on c1b: the M-sliced ones (C >= 512)
+    evaluate the activation of the whole operand again in every slice (0.163 -> 0.462 ms), and the prologue forms run one wave
+    per SIMD (csrc/c1rb.hip, wfae_c1rb_fwd: with two, repeat launches differed), where C = 256 takes 0.327 ms against c1b's
+    0.284 (C = 128: 0.477 against 0.536, kept)."""
+    if pro and m < k and k >= 256:
         return False
     return c1rb_supported(m, k, hw)
 
@@ -359,7 +391,7 @@ def c1rb_fwd(w, transposed, x, st=None, res=None, stats=False, label="wfae_c1b_f
     rows = ctypes.c_int(0)
     _call("wfae_c1rb_fwd", fl, by, _p(w), sm, sk, _p(x), ps, ph, _p(res), _p(y), nb, k, m, h * wd, part.data_ptr(), part.numel(),
           ctypes.cast(ctypes.pointer(rows), ctypes.c_void_p), _stream(), label=label, peak=PEAK_BF16_MFMA)
-    return y, StatRows(part, rows.value)
+    return y, StatRows(part[:2 * rows.value * m], rows.value)
 
 
 # ----------------------------------------------------------------- 1x1 conv

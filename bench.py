@@ -99,9 +99,13 @@ KERNEL_OF = {
     "wfae_c1b_fwd": "c1b_kernel (1x1 convolutions of the Bottleneck on bf16 tensors, forward: 16-byte bf16 loads straight into the "
                     "MFMA LDS image, BatchNorm + GELU prologue or residual + BatchNorm-sum epilogue — csrc/c1b.hip)",
     "wfae_c1b_dgrad": "c1b_kernel (the same kernel with the transposed weight image: 1x1 data gradients on bf16 tensors)",
-    "wfae_conv1x1_fwd": "gemm_kernel<A_KCONTIG,B_NCONTIG> (1x1 conv fwd, fp32 MFMA)",
-    "wfae_conv1x1_bwd_data": "gemm_kernel<A_MCONTIG,B_NCONTIG> (1x1 conv dgrad, fp32 MFMA)",
-    "wfae_conv1x1_bwd_weight": "gemm_kernel<A_KCONTIG,B_KCONTIG> (1x1 conv wgrad, fp32 MFMA, split-K)",
+    "wfae_conv1x1_fwd": "c1r_kernel (1x1 conv fwd, register-direct, exact three-plane bf16 operands — csrc/c1r.hip) at the shapes it "
+                        "serves, else gemm_kernel<A_KCONTIG,B_NCONTIG> (fp32 MFMA)",
+    "wfae_conv1x1_bwd_data": "c1r_kernel (1x1 conv data gradient; at C <= 256 the widening one leaves only the sums of the "
+                             "BatchNorm backward in front: wfae_c1r_bnred without a store) or gemm_kernel<A_MCONTIG,B_NCONTIG>",
+    "wfae_c1r_bndx": "c1r_kernel<BNM = 3> (the widening 1x1 data gradient of a C <= 256 Bottleneck computed again with the second "
+                     "pass of its first BatchNorm's backward in the epilogue: reads dT, x, skip gradient, writes dx — csrc/c1r.hip)",
+    "wfae_conv1x1_bwd_weight": "c1w_kernel (1x1 conv wgrad, both operands as K-contiguous LDS rows, split-K — csrc/c1w.hip)",
 }
 
 

@@ -338,7 +338,7 @@ def c1r_bndx(w, dt, x, gamma, st, res=None, training=True):
     n = nb * h * wd
     _call("wfae_c1r_bndx", 2 * n * k * m, 4 * (n * (k + (3 if res is not None else 2) * m) + k * m), _p(w), 1, m, _p(dt), _p(x), _p(gamma),
           _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd), ws.data_ptr(), _p(res), _p(dx), nb, k, m, h * wd, int(training),
-          _stream(), label="wfae_bn_act_bwd[dx]", peak=PEAK_BF16_MFMA / 6)
+          _stream(), label="wfae_c1r_bndx", peak=PEAK_BF16_MFMA / 6)
     return dx
 
 

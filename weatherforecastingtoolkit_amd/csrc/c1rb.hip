@@ -335,12 +335,15 @@ inline int grid_for(long ntiles, const ShapeInfo& si) {
   return (int)(g < num_cus() ? g : num_cus());
 }
 
+// (the prologue forms exist for 4-wave blocks only: see wfae_c1rb_fwd)
 template <int KCH, int MT, int MG, int NW, int NBUF, int RD, bool RESN = false>
 void launch_shape(const C1RBP& p, bool pro, bool stats, int grid, hipStream_t st) {
   const dim3 g((unsigned)grid), b(64 * NW);
-  if (pro && stats) hipLaunchKernelGGL((c1rb_kernel<KCH, MT, MG, true, true, NW, NBUF, RD, RESN>), g, b, 0, st, p);
-  else if (pro) hipLaunchKernelGGL((c1rb_kernel<KCH, MT, MG, true, false, NW, NBUF, RD, RESN>), g, b, 0, st, p);
-  else if (stats) hipLaunchKernelGGL((c1rb_kernel<KCH, MT, MG, false, true, NW, NBUF, RD, RESN>), g, b, 0, st, p);
+  if constexpr (NW == 4) {
+    if (pro && stats) { hipLaunchKernelGGL((c1rb_kernel<KCH, MT, MG, true, true, NW, NBUF, RD, RESN>), g, b, 0, st, p); return; }
+    if (pro) { hipLaunchKernelGGL((c1rb_kernel<KCH, MT, MG, true, false, NW, NBUF, RD, RESN>), g, b, 0, st, p); return; }
+  }
+  if (stats) hipLaunchKernelGGL((c1rb_kernel<KCH, MT, MG, false, true, NW, NBUF, RD, RESN>), g, b, 0, st, p);
   else hipLaunchKernelGGL((c1rb_kernel<KCH, MT, MG, false, false, NW, NBUF, RD, RESN>), g, b, 0, st, p);
 }
 

@@ -656,10 +656,11 @@ __global__ __launch_bounds__(256) void gconv3_kernel(const T* __restrict__ x, co
 
 // -------------------------------------------------------------------------------------
 // The same convolution for 4 / 8 channels per group (the 128@384 and 256@192 stages), fp32 tensors, as a persistent
-// kernel: a block walks tiles of 16 x 32 pixels; the patch of its next tile travels HBM -> registers (16-byte row pieces +
-// the two halo columns) while the current one is multiplied out of LDS, and the results of a tile are stored one tile late,
-// so the wait at the top of the loop finds both long landed.  The products are packed FMAs over pairs of output channels
-// (see the loop).  What round 4 measured on this kernel (256@192 / 128@384, B = 32; profiles/r04_gconv3p_*.txt):
+// kernel: a block walks tiles of 16 x 64 pixels, FOUR pixels of a row per lane; the patch of its next tile travels HBM -> registers
+// (16-byte row pieces + the two halo columns) while the current one is multiplied out of LDS, and the results of a tile are stored
+// one tile late (16-byte stores), so the wait at the top of the loop finds both long landed.  The products are packed FMAs over
+// pairs of output channels (see the loop).  What round 4 measured on this kernel's first form — 16 x 32 tiles, two pixels per lane —
+// (256@192 / 128@384, B = 32; profiles/r04_gconv3p_*.txt):
 //  - the one-tile-per-block kernel above already moved exactly the algorithmic bytes (PMC 1.00x) — in 0.199 / 0.320 ms;
 //  - with loads and stores removed the products alone take 0.145 / 0.176 ms: 75 / 62 TF against 137 TF that the same
 //    instruction (v_pk_fma_f32 with a scalar-register pair) reaches in a bare loop at 4 waves per SIMD
@@ -669,18 +670,23 @@ __global__ __launch_bounds__(256) void gconv3_kernel(const T* __restrict__ x, co
 //    (38 % of its cycles by s_memtime stamps, the queue ahead of it full) or multiplying (49 %), and 4 - 6 waves per SIMD
 //    overlap the two only partly.  Result 0.18 / 0.305 ms.  Not the DRAM pattern: 128-byte row pieces stream at 6.2 TB/s
 //    read / 5.7 TB/s copy in tools/probe/hbm_streams.hip.
+//  - four pixels per lane (this form): half the weight fetches, LDS reads and memory instructions per FMA and byte:
+//    0.167 - 0.177 / 0.263 ms; eight (PX = 8, 16 x 128 tiles) measured the same at 4 channels per group (0.260 ms) and is not
+//    instantiated.
 // -------------------------------------------------------------------------------------
 typedef float g3_f32x2 __attribute__((ext_vector_type(2)));
 
-template <int CPG>
+template <int CPG, int PX = 4>
 __global__ __launch_bounds__(256) void gconv3p_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                       float* __restrict__ y, int NB, int C, int H, int W, int tiles_x,
                                                       int ntile, int total) {
   static_assert(CPG == 4 || CPG == 8, "whole group staged at once");
-  constexpr int TH = 16, TW = 32;
-  constexpr int IH = TH + 2, IW = 36;       // LDS row: [left halo][32 body columns][right halo][2 pad]
+  static_assert(PX == 4 || PX == 8, "whole 16-byte pieces per lane");
+  constexpr int TH = 16, TW = 16 * PX;      // PX pixels of a row per lane
+  constexpr int IH = TH + 2, IW = TW + 4;   // LDS row: [left halo][TW body columns][right halo][2 pad]
+  constexpr int F4R = TW / 4, RPP = 256 / F4R;   // 16-byte pieces per body row, rows per pass of the block
   constexpr int NROW = CPG * IH;            // patch rows (channel, ry)
-  constexpr int NB4 = (NROW + 31) / 32;     // body: 32 rows x 8 float4 per pass of the block
+  constexpr int NB4 = (NROW + RPP - 1) / RPP;
   constexpr int NHL = (2 * NROW + 255) / 256;   // halo columns: 2 elements per row
   __shared__ __attribute__((aligned(16))) float xs[NROW * IW];
   const int t = threadIdx.x;
@@ -695,7 +701,7 @@ __global__ __launch_bounds__(256) void gconv3p_kernel(const float* __restrict__ 
   const int first = (int)(blockIdx.x & 7u) * pb + (int)(blockIdx.x >> 3), step = 8 * pb;
   if (first >= total) return;
 
-  const int q4 = (t & 7) * 4, r0 = t >> 3;
+  const int q4 = (t % F4R) * 4, r0 = t / F4R;
   float4 bv[NB4];
   float hv[NHL];
   auto fetch = [&](int L) {
@@ -706,7 +712,7 @@ __global__ __launch_bounds__(256) void gconv3p_kernel(const float* __restrict__ 
     const float* __restrict__ xb = x + ((long)n * C + (long)g * CPG) * HW;   // uniform base + 32-bit lane offsets
 #pragma unroll
     for (int i = 0; i < NB4; ++i) {
-      const int R = r0 + 32 * i;
+      const int R = r0 + RPP * i;
       const int c = R / IH, ry = R - c * IH;
       const int iy = py + ry, ix = ox0 + q4;
       bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -727,17 +733,20 @@ __global__ __launch_bounds__(256) void gconv3p_kernel(const float* __restrict__ 
 
   // results leave one tile late: the stores of tile i - 1 are issued before the products of tile i, so that the wait at
   // the top of the loop (which covers every outstanding memory operation of the wave) finds loads and stores long landed
-  float out[2][CPG];
+  float out[PX][CPG];
   int out_L = -1;
   auto put = [&]() {
     const int bx = out_L % ntile;
     const int r = out_L / ntile;
     const int n = r % NB, g = r / NB;
-    const int ox = (bx % tiles_x) * TW + 2 * tx, oy = (bx / tiles_x) * TH + ty;
-    if (oy < H && ox < W) {   // W % 4 == 0: ox + 1 < W as well
+    const int ox = (bx % tiles_x) * TW + PX * tx, oy = (bx / tiles_x) * TH + ty;
+    if (oy < H) {
       float* yp = y + (((long)n * C + (long)g * CPG) * H + oy) * W + ox;
 #pragma unroll
-      for (int o = 0; o < CPG; ++o) *reinterpret_cast<float2*>(yp + (long)o * HW) = make_float2(out[0][o], out[1][o]);
+      for (int o = 0; o < CPG; ++o)
+#pragma unroll
+        for (int v = 0; v < PX; v += 4)   // W % 4 == 0: a 16-byte piece is inside the row or outside it
+          if (ox + v < W) *reinterpret_cast<float4*>(yp + (long)o * HW + v) = make_float4(out[v][o], out[v + 1][o], out[v + 2][o], out[v + 3][o]);
     }
   };
 
@@ -746,7 +755,7 @@ __global__ __launch_bounds__(256) void gconv3p_kernel(const float* __restrict__ 
     __syncthreads();   // every wave is done reading the previous tile's patch
 #pragma unroll
     for (int i = 0; i < NB4; ++i) {
-      const int R = r0 + 32 * i;
+      const int R = r0 + RPP * i;
       if (R < NROW) {
         float* d = &xs[R * IW + 1 + q4];
         d[0] = bv[i].x; d[1] = bv[i].y; d[2] = bv[i].z; d[3] = bv[i].w;
@@ -766,20 +775,25 @@ __global__ __launch_bounds__(256) void gconv3p_kernel(const float* __restrict__ 
     // the scalar load delivers it and the input value is broadcast by the instruction's operand select — pairing the two
     // pixels instead (what the compiler picks on its own) needs a register copy for every odd-aligned operand: 544 scalar
     // and 60 vector moves per tile and wave beside 576 packed FMAs (PMC round 4)
-    g3_f32x2 acc[2][CPG / 2];
+    g3_f32x2 acc[PX][CPG / 2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < PX; ++b)
 #pragma unroll
       for (int o = 0; o < CPG / 2; ++o) acc[b][o] = (g3_f32x2){0.f, 0.f};
     const float* __restrict__ wg = wp + (long)g * (CPG * 9 * CPG);
-#pragma unroll(CPG == 4 ? 2 : 1)   // 72 weights (scalar registers) per trip either way
+#pragma unroll(CPG == 4 && PX == 4 ? 2 : 1)   // <= 72 weights (scalar registers) and <= 144 packed FMAs per trip
     for (int c = 0; c < CPG; ++c) {
-      float in[3][4];
+      float in[3][PX + 2];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        const float2 a = *reinterpret_cast<const float2*>(&xs[(c * IH + ty + r) * IW + 2 * tx]);
-        const float2 b = *reinterpret_cast<const float2*>(&xs[(c * IH + ty + r) * IW + 2 * tx + 2]);
-        in[r][0] = a.x; in[r][1] = a.y; in[r][2] = b.x; in[r][3] = b.y;
+        const float* xr = &xs[(c * IH + ty + r) * IW + PX * tx];
+#pragma unroll
+        for (int v = 0; v < PX; v += 4) {
+          const float4 a = *reinterpret_cast<const float4*>(xr + v);
+          in[r][v] = a.x; in[r][v + 1] = a.y; in[r][v + 2] = a.z; in[r][v + 3] = a.w;
+        }
+        const float2 b = *reinterpret_cast<const float2*>(xr + PX);
+        in[r][PX] = b.x; in[r][PX + 1] = b.y;
       }
       const g3_f32x2* __restrict__ wc = reinterpret_cast<const g3_f32x2*>(wg + c * (9 * CPG));
 #pragma unroll
@@ -790,12 +804,12 @@ __global__ __launch_bounds__(256) void gconv3p_kernel(const float* __restrict__ 
           for (int o = 0; o < CPG / 2; ++o) {
             const g3_f32x2 w = wc[(ky * 3 + kx) * (CPG / 2) + o];
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < PX; ++b)
               acc[b][o] = __builtin_elementwise_fma((g3_f32x2){in[ky][b + kx], in[ky][b + kx]}, w, acc[b][o]);
           }
     }
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < PX; ++b)
 #pragma unroll
       for (int o = 0; o < CPG / 2; ++o) { out[b][2 * o] = acc[b][o].x; out[b][2 * o + 1] = acc[b][o].y; }
     out_L = L;
@@ -981,13 +995,14 @@ inline int g3_num_cus() {
   return n;
 }
 
-template <int CPG>
+template <int CPG, int PX = 4>
 int launch_gconv3p(const float* x, const float* wp, float* y, int NB, int C, int H, int W, hipStream_t st) {
-  const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 16);
+  const int tiles_x = cdiv(W, 16 * PX), tiles_y = cdiv(H, 16);
   const long total = (long)tiles_x * tiles_y * (C / CPG) * NB;
-  // a multiple of 8 blocks, 6 per CU (8 channels per group: registers allow 5): kbench 0.190 / 0.312 ms at 4 per CU, 0.183 / 0.305 at 6
-  const int blocks = (int)std::min<long>((total + 7) / 8 * 8, (long)g3_num_cus() / 8 * 8 * 6);
-  hipLaunchKernelGGL((gconv3p_kernel<CPG>), dim3(blocks), dim3(256), 0, st, x, wp, y, NB, C, H, W, tiles_x, tiles_x * tiles_y,
+  // a multiple of 8 blocks: 2 per CU at 4 channels per group (0.263 ms; 0.274 at 3, 0.282 at 4 and 6), 6 at 8 (0.167 - 0.177 ms;
+  // 0.171 - 0.185 at 3: three fit by registers, the rest queue behind them)
+  const int blocks = (int)std::min<long>((total + 7) / 8 * 8, (long)g3_num_cus() / 8 * 8 * (CPG == 4 ? 2 : 6));
+  hipLaunchKernelGGL((gconv3p_kernel<CPG, PX>), dim3(blocks), dim3(256), 0, st, x, wp, y, NB, C, H, W, tiles_x, tiles_x * tiles_y,
                      (int)total);
   return check_launch("gconv3p");
 }
@@ -1017,7 +1032,7 @@ int gconv3x3_fwd_impl(const T* x, const float* w, T* y, int NB, int C, int H, in
   // one row per thread: measured 1 < 2 < 4 in time (the kernel is latency-bound: smaller LDS tiles, more blocks per CU)
   // 4 / 8 channels per group, fp32 tensors with 16-byte rows: the software-pipelined kernel (24-bit lane offsets in a group)
   if constexpr (sizeof(T) == 4) {
-    if (cpg <= 8 && W % 4 == 0 && (long)cdiv(W, 32) * cdiv(H, 16) * groups * NB < (1l << 31) && (long)cpg * H * W < (1l << 24)) {
+    if (cpg <= 8 && W % 4 == 0 && (long)cdiv(W, 64) * cdiv(H, 16) * groups * NB < (1l << 31) && (long)cpg * H * W < (1l << 24)) {
       if (cpg == 4) return launch_gconv3p<4>(x, wp, y, NB, C, H, W, st);
       return launch_gconv3p<8>(x, wp, y, NB, C, H, W, st);
     }

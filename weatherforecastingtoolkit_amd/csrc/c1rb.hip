@@ -63,8 +63,12 @@ __global__ __launch_bounds__(64 * RWAVES, (RWAVES == 4 ? 1 : 2)) void c1rb_kerne
   constexpr int A_B = KCH * PLANE_B;
   constexpr int PRO_B = PRO ? 2 * K * 4 : 0;
   constexpr int ST_B = STATS ? RWAVES * 2 * M * 8 : 0;
-  static_assert(A_B + PRO_B + ST_B <= 160 * 1024, "LDS");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[A_B + PRO_B + ST_B];
+  // prologue forms (4-wave blocks, see wfae_c1rb_fwd): padded past half of the CU's LDS, so that a second block can never
+  // share the CU — and with it the SIMDs — whatever the grid and the register count
+  constexpr int PAD_B = (PRO && A_B + PRO_B + ST_B < 84 * 1024) ? 84 * 1024 - (A_B + PRO_B + ST_B) : 0;
+  static_assert(!PRO || RWAVES == 4, "prologue forms: one wave per SIMD");
+  static_assert(A_B + PRO_B + ST_B + PAD_B <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[A_B + PRO_B + ST_B + PAD_B];
   float* const lsc = reinterpret_cast<float*>(smem + A_B);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);

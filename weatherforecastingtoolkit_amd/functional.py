@@ -62,9 +62,13 @@ FUSE_A1_MAXC = 1 << 30
 # roles of that weight gradient are swapped when C/4 < 128, so the prologue sits on its A operand there).  The forward
 # GEMM re-loads (and re-activates) every element once per M tile, 1 - 8 times: measured for the whole step, fusing it
 # at every width costs 3 ms (247.4 -> 250.5 ms), at C <= 256 0.5 ms, at C <= 128 nothing — so it is limited to
-# WFAE_FUSE_A3_MAXC = 128 output channels (one M tile; -1.1 GiB).  WFAE_FUSE_A3=0: off.
+# WFAE_FUSE_A3_MAXC = 128 output channels (one M tile; -1.1 GiB; 256 where csrc/c1r.hip serves the product, below).  WFAE_FUSE_A3=0: off.
 FUSE_A3 = os.environ.get("WFAE_FUSE_A3", "1") == "1"
-FUSE_A3_MAXC = 128
+FUSE_A3_MAXC = int(os.environ.get("WFAE_FUSE_A3_MAXC", "128"))
+# fp32 tensors on csrc/c1r.hip (round 4): its prologue form of the C/4 -> C product at C = 256 costs 0.519 against 0.507 ms + the
+# 0.123 ms apply pass, the weight gradient's prologue sits on the 64-channel operand: the step is unchanged (185.1 / 185.3 against
+# 184.9 / 185.4 ms, same box) and a3 is not kept: - 2.25 GiB.  Above that the M-sliced kernels activate the operand once per slice.
+FUSE_A3_MAXC_C1R = max(FUSE_A3_MAXC, 256)
 
 
 # BatchNorm sums produced by the kernel that WRITES the tensor when that kernel is a streaming one (the Winograd output
@@ -629,7 +633,8 @@ class BottleneckFn(Function):
         a2 = ops.bn_act_fwd(t1, st2, 1)
         t2 = _g3_fwd(a2, wg, groups)
         st3 = _bn_stats(t2, bn3, training)
-        if FUSE_A3 and w3.shape[0] <= FUSE_A3_MAXC and ops.conv1x1_bnact_supported(t2, w3.shape[0]):
+        a3_maxc = FUSE_A3_MAXC_C1R if (x.dtype == torch.float32 and ops.c1r_supported(C, mid, hw)) else FUSE_A3_MAXC
+        if FUSE_A3 and w3.shape[0] <= a3_maxc and ops.conv1x1_bnact_supported(t2, w3.shape[0]):
             a3 = None
             if cb3:
                 y, mod._out_stats = _b16(w3, W3p[0], False, t2, st3, x, True) if emit else (_b16(w3, W3p[0], False, t2, st3, x), None)

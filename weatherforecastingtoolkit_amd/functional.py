@@ -68,6 +68,7 @@ FUSE_A3_MAXC = int(os.environ.get("WFAE_FUSE_A3_MAXC", "128"))
 # fp32 tensors on csrc/c1r.hip (round 4): its prologue form of the C/4 -> C product at C = 256 costs 0.519 against 0.507 ms + the
 # 0.123 ms apply pass, the weight gradient's prologue sits on the 64-channel operand: the step is unchanged (185.1 / 185.3 against
 # 184.9 / 185.4 ms, same box) and a3 is not kept: - 2.25 GiB.  Above that the M-sliced kernels activate the operand once per slice.
+# bf16 storage on csrc/c1rb.hip: 93.25 / 92.9 -> 92.68 / 92.71 ms, - 1.1 GiB.
 FUSE_A3_MAXC_C1R = max(FUSE_A3_MAXC, 256)
 
 
@@ -633,7 +634,8 @@ class BottleneckFn(Function):
         a2 = ops.bn_act_fwd(t1, st2, 1)
         t2 = _g3_fwd(a2, wg, groups)
         st3 = _bn_stats(t2, bn3, training)
-        a3_maxc = FUSE_A3_MAXC_C1R if (x.dtype == torch.float32 and ops.c1r_supported(C, mid, hw)) else FUSE_A3_MAXC
+        reg_direct = ops.c1r_supported(C, mid, hw) if x.dtype == torch.float32 else (bf and ops.c1rb_supported(C, mid, hw))
+        a3_maxc = FUSE_A3_MAXC_C1R if reg_direct else FUSE_A3_MAXC
         if FUSE_A3 and w3.shape[0] <= a3_maxc and ops.conv1x1_bnact_supported(t2, w3.shape[0]):
             a3 = None
             if cb3:
